@@ -1,0 +1,83 @@
+"""GPU parity of the fused kNN kernel (through the C ABI) against oracle/knn_exact.c.
+
+Gate (gate 1): neighbour indices BIT-EXACT against the oracle's specified
+arithmetic (fp32 FMA chain in channel order, lower index wins ties, nearest first)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import knn_exact as ke
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(x_bcn, k, device):
+    from ahn3_dgcnn_pytorch_amd import ops
+    x = torch.from_numpy(x_bcn).to(device)
+    x_pm = ops.to_point_major(x)
+    idx = ops.knn_pm(x_pm, k)
+    torch.cuda.synchronize()
+    return idx.cpu().numpy()
+
+
+@pytest.mark.parametrize("B,C,N,k", [
+    (2, 4, 256, 8), (2, 64, 256, 30), (1, 4, 1000, 30), (3, 3, 130, 20), (2, 9, 777, 40),
+    (1, 64, 2000, 64), (2, 128, 300, 30), (1, 6, 64, 64), (1, 5, 33, 33), (2, 64, 1, 1),
+])
+def test_knn_bit_exact_random(B, C, N, k, device):
+    rng = np.random.default_rng(1234 + B * 7 + C * 13 + N)
+    x = rng.standard_normal((B, C, N)).astype(np.float32)
+    want = ke.knn_exact(x, k)
+    got = _run(x, k, device)
+    assert got.dtype == np.int32 and got.shape == (B, N, k)
+    np.testing.assert_array_equal(got, want)
+
+
+def test_knn_block_like_coordinates(device):
+    # block-local x,y in [0,30), z, agl in [0,20): the value range of the real tiles
+    rng = np.random.default_rng(7)
+    x = rng.random((2, 4, 3000)).astype(np.float32) * np.array([30, 30, 20, 20], np.float32)[None, :, None]
+    np.testing.assert_array_equal(_run(x, 30, device), ke.knn_exact(x, 30))
+
+
+def test_knn_duplicate_points_lower_index_wins(device):
+    # second half of the cloud is a copy of the first: every distance is tied at least twice.
+    rng = np.random.default_rng(3)
+    half = rng.standard_normal((1, 8, 250)).astype(np.float32)
+    x = np.concatenate([half, half], axis=2)
+    want = ke.knn_exact(x, 20)
+    got = _run(x, 20, device)
+    np.testing.assert_array_equal(got, want)
+    # the fixed tie-break: point i and its copy i+250 share a list that starts (i, i+250)
+    assert (got[0, :250, 0] == np.arange(250)).all() and (got[0, :250, 1] == np.arange(250) + 250).all()
+    assert (got[0, 250:, 0] == np.arange(250)).all()
+
+
+def test_knn_all_points_identical(device):
+    x = np.ones((1, 4, 200), np.float32)
+    got = _run(x, 30, device)
+    np.testing.assert_array_equal(got, np.broadcast_to(np.arange(30, dtype=np.int32), (1, 200, 30)))
+
+
+def test_knn_integer_grid_many_ties(device):
+    # small integer coordinates: all arithmetic exact, massive ties -> pure tie-break test
+    rng = np.random.default_rng(11)
+    x = rng.integers(0, 4, size=(2, 3, 500)).astype(np.float32)
+    np.testing.assert_array_equal(_run(x, 30, device), ke.knn_exact(x, 30))
+
+
+def test_knn_full_size_bit_exact(device):
+    # BASELINE.json configs[1] size: B=8, N=7000, k=30, C=64 (the oracle takes ~1-2 s on 8 cores)
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((8, 64, 7000)).astype(np.float32)
+    got = _run(x, 30, device)
+    want = ke.knn_exact(x, 30)
+    np.testing.assert_array_equal(got, want)
+    assert (got[:, :, 0] == np.arange(7000)[None]).all()  # self is neighbour 0 on tie-free data
+
+
+def test_knn_k_out_of_range(device):
+    from ahn3_dgcnn_pytorch_amd import ops
+    x = torch.zeros((1, 10, 4), device=device)
+    with pytest.raises(RuntimeError, match="out of range"):
+        ops.knn_pm(x, 11)
