@@ -1,0 +1,139 @@
+"""CPU tests (no GPU): the oracles against the golden vectors captured from the reference.
+
+tests/golden/*.npz were produced by tests/golden/gen_golden.py, which imports
+/root/reference/model.py on CPU; here the oracles are re-run and compared with them, so a
+change to oracle/torch_ref.py or oracle/knn_exact.c that drifts from the reference fails."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import knn_exact as ke
+from oracle import torch_ref
+from param_fill import cotangent, fill_module
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(GOLD, name))
+
+
+@pytest.mark.parametrize("tag", ["c4", "c64"])
+@pytest.mark.parametrize("k", [8, 30])
+def test_knn_oracles_match_reference_indices(tag, k):
+    g = load("knn_ggf.npz")
+    x = g["x_" + tag]
+    want = g["idx_%s_k%d" % (tag, k)].astype(np.int64)
+    # C oracle (specified arithmetic): identical lists on tie-free data
+    np.testing.assert_array_equal(ke.knn_exact(x, k).astype(np.int64), want)
+    # torch-op restatement: the reference's own op sequence
+    np.testing.assert_array_equal(torch_ref.pairwise_knn(torch.from_numpy(x), k).numpy(), want)
+
+
+@pytest.mark.parametrize("tag,step", [("c4", 1), ("c64", 16)])
+def test_edge_features_match_reference(tag, step):
+    g = load("knn_ggf.npz")
+    x = torch.from_numpy(g["x_" + tag])
+    idx = torch.from_numpy(g["idx_%s_k8" % tag].astype(np.int64))
+    gf = torch_ref.edge_features(x, k=8, idx=idx)
+    C = x.shape[1]
+    assert gf.shape == (2, 2 * C, 256, 8)
+    assert gf.stride() == (256 * 8 * 2 * C, 1, 8 * 2 * C, 2 * C)  # memory is [B, N, k, 2C]
+    np.testing.assert_array_equal(gf.numpy()[:, :, ::step], g["ggf_%s_k8" % tag])
+
+
+def _small_model(train):
+    g = load("model_small.npz")
+    m = torch_ref.RefDGCNN(int(g["num_classes"]), 4, int(g["k"]), dropout=0.0)
+    fill_module(m)
+    m.train(train)
+    return g, m, torch.from_numpy(g["x"])
+
+
+@pytest.mark.parametrize("depth", range(1, 11))
+def test_ref_model_eval_all_depths(depth):
+    g, m, x = _small_model(False)
+    with torch.no_grad():
+        y, used = m(x, depth=depth, return_idx=True)
+    step = int(g["eval_d%d_step" % depth])
+    np.testing.assert_allclose(y.numpy()[:, ::step], g["eval_d%d" % depth], rtol=0, atol=2e-6)
+    for i, u in enumerate(used):
+        np.testing.assert_array_equal(u.numpy(), g["eval_idx%d" % (i + 1)].astype(np.int64))
+
+
+def test_ref_model_train_step_matches_reference():
+    g, m, x = _small_model(True)
+    y = m(x)
+    np.testing.assert_allclose(y.detach().numpy(), g["train_d10"], rtol=0, atol=2e-6)
+    (y * cotangent(tuple(y.shape))).sum().backward()
+    sd = m.state_dict()
+    for key in g.files:
+        if key.startswith("train_after/"):
+            np.testing.assert_allclose(sd[key.split("/", 1)[1]].numpy(), g[key], rtol=1e-6, atol=1e-7)
+    params = dict(m.named_parameters())
+    n = 0
+    for key in g.files:
+        if key.startswith("grad/"):
+            want = g[key]
+            got = params[key[5:]].grad.numpy()
+            np.testing.assert_allclose(got, want, rtol=0, atol=1e-5 * np.abs(want).max())
+            n += 1
+        elif key.startswith("grad_sample/"):
+            want = g[key]
+            got = params[key[12:]].grad.numpy().reshape(-1)[::97]
+            np.testing.assert_allclose(got, want, rtol=0, atol=1e-5 * np.abs(want).max())
+            n += 1
+    assert n == 25
+
+
+def test_ref_model_readme_config():
+    g = load("model_readme.npz")
+    m = torch_ref.RefDGCNN(5, 4, 30, dropout=0.5)
+    fill_module(m)
+    m.eval()
+    with torch.no_grad():
+        y = m(torch.from_numpy(g["x"]))
+    assert y.shape == (1, 5, 1000)
+    np.testing.assert_allclose(y.numpy(), g["logits"], rtol=0, atol=2e-6)
+
+
+def test_state_dict_contract():
+    with open(os.path.join(GOLD, "state_dict.json")) as f:
+        spec = json.load(f)
+    m = torch_ref.RefDGCNN(5, 4, 30)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(spec["entries"].keys())
+    for k, (shape, dtype) in spec["entries"].items():
+        assert list(sd[k].shape) == shape and str(sd[k].dtype) == "torch." + dtype
+    assert sum(p.numel() for p in m.parameters()) == spec["n_parameters"] == 980864
+    assert len(list(m.parameters())) == spec["n_parameter_tensors"] == 25
+
+
+def test_duplicate_points_document_arbitrary_reference_ties():
+    g = load("dup_points.npz")
+    mine = ke.knn_exact(g["x"], 4)
+    np.testing.assert_array_equal(mine, g["idx_fixed_tiebreak_k4"])
+    ref = g["idx_reference_k4"]
+    # same neighbour SETS, different order inside tie groups: why the tie rule must be ours
+    assert all(set(a) == set(b) for a, b in zip(ref.reshape(-1, 4), mine.reshape(-1, 4)))
+    assert (ref != mine).any()
+
+
+def test_knn_oracle_agreement_rate_with_torch_on_block_like_data():
+    # gate 2 of SURVEY.md 8c: agreement with PyTorch-CPU is a RATE; every disagreement must be a
+    # near-tie under the oracle arithmetic
+    rng = np.random.default_rng(0)
+    x = (rng.random((1, 4, 2000)) * np.array([30, 30, 20, 20])[None, :, None]).astype(np.float32)
+    k = 30
+    mine, pd = ke.knn_exact(x, k + 1, return_pd=True)
+    ref = torch_ref.pairwise_knn(torch.from_numpy(x), k).numpy()
+    rows_equal = (mine[:, :, :k] == ref).all(-1)
+    assert rows_equal.mean() > 0.97
+    b, i = np.nonzero(~rows_equal)
+    for bb, ii in zip(b, i):
+        j = int(np.argmax(mine[bb, ii, :k] != ref[bb, ii]))
+        gap = pd[bb, ii, j] - pd[bb, ii, j + 1]
+        assert gap <= 64 * np.finfo(np.float32).eps * max(1.0, abs(pd[bb, ii, j]) + 2 * float((x[bb, :, ii] ** 2).sum()))
