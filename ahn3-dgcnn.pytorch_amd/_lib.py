@@ -14,6 +14,29 @@ LIB_PATH = os.path.join(_HERE, "libdgcnn_hip.so")
 
 _c_int, _c_i64, _c_sz, _c_vp, _c_f = ctypes.c_int, ctypes.c_int64, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_float
 
+
+
+class BnParams(ctypes.Structure):
+    """mirror of `dgcnn_bn_params` (include/dgcnn_hip.h)"""
+    _fields_ = [("weight", _c_vp), ("bias", _c_vp), ("running_mean", _c_vp), ("running_var", _c_vp)]
+
+
+class EdgeConvDesc(ctypes.Structure):
+    """mirror of `dgcnn_edgeconv_desc` (include/dgcnn_hip.h)"""
+    _fields_ = [("B", ctypes.c_int32), ("N", ctypes.c_int32), ("C", ctypes.c_int32), ("k", ctypes.c_int32),
+                ("n_stage", ctypes.c_int32), ("training", ctypes.c_int32),
+                ("eps", _c_f), ("momentum", _c_f), ("slope", _c_f),
+                ("w1", _c_vp), ("bn1", BnParams), ("w2", _c_vp), ("bn2", BnParams)]
+
+
+class EdgeConvGrads(ctypes.Structure):
+    """mirror of `dgcnn_edgeconv_grads` (include/dgcnn_hip.h)"""
+    _fields_ = [("gx", _c_vp), ("gw1", _c_vp), ("gbn1_w", _c_vp), ("gbn1_b", _c_vp),
+                ("gw2", _c_vp), ("gbn2_w", _c_vp), ("gbn2_b", _c_vp)]
+
+
+_c_desc_p = ctypes.POINTER(EdgeConvDesc)
+
 # name -> (restype, argtypes); must list every symbol of include/dgcnn_hip.h
 SIGNATURES = {
     "dgcnn_last_error": (ctypes.c_char_p, []),
@@ -22,6 +45,14 @@ SIGNATURES = {
     "dgcnn_from_point_major": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_vp, _c_i64, _c_i64, _c_i64, _c_vp]),
     "dgcnn_knn_workspace_bytes": (_c_sz, [_c_int, _c_int, _c_int, _c_int]),
     "dgcnn_knn": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_sz, _c_vp]),
+    "dgcnn_graph_feature_fwd": (_c_int, [_c_vp, _c_vp, _c_int, _c_int, _c_int, _c_int, _c_vp, _c_vp]),
+    "dgcnn_graph_feature_bwd": (_c_int, [_c_vp, _c_vp, _c_int, _c_int, _c_int, _c_int, _c_vp, _c_vp]),
+    "dgcnn_edgeconv_saved_bytes": (_c_sz, [_c_desc_p]),
+    "dgcnn_edgeconv_fwd_workspace_bytes": (_c_sz, [_c_desc_p]),
+    "dgcnn_edgeconv_bwd_workspace_bytes": (_c_sz, [_c_desc_p]),
+    "dgcnn_edgeconv_fwd": (_c_int, [_c_desc_p, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp]),
+    "dgcnn_edgeconv_bwd": (_c_int, [_c_desc_p, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp,
+                                    ctypes.POINTER(EdgeConvGrads), _c_vp, _c_sz, _c_vp]),
 }
 
 _lib = None

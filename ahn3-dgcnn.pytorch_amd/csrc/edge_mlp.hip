@@ -1,0 +1,372 @@
+// edge_mlp.hip -- the per-EDGE 64 -> 64 contraction of the two-stage EdgeConv blocks
+// (conv2 / conv4 of the reference, model.py:119-121,125-127 applied at :149,:156) on
+// v_mfma_f32_32x32x2_f32 (exact fp32), fused with everything around it.
+//
+// One wave processes one point at a time; its k edges are the M dimension of a 32-row MFMA tile
+// (k = 30 -> 30 of 32 rows used; k > 32 -> two tiles):
+//   gather  (lane = channel)  u1[j] = TP[n(i, j)] + TQ[i];  a1 = LReLU(BN1(u1)) -> wave-private LDS tile
+//   MFMA    u2[32 edges][64]  = a1 . W2^T          A from the LDS tile (8 ds_read_b128 per lane),
+//                                                   B = W2 (registers in the forward, LDS image in the backward)
+//   forward epilogue: accumulator layout has the output CHANNEL on the lane and the EDGES in the
+//           16 registers, so BN2 batch sums and the max/min over k are in-lane loops plus one
+//           exchange between the two lane halves; nothing per-edge is written to HBM.
+//   backward: du2 from the recomputed u2; gW2 += du2^T a1 uses the du2 accumulators directly as
+//           the A operand (contraction over the edge rows held in the registers); da1 = du2 W2
+//           goes through one LDS transpose; dv1 = da1 * LReLU'(v1) is written to HBM ([E][64])
+//           for the stage-1 streaming pass, together with the BN1 backward sums.
+#include "edge_kernels.h"
+
+namespace dgcnn {
+
+constexpr int MLP_WAVES = 4;
+constexpr int TSTR = 68;  // LDS tile row stride in floats (64 + 4: conflict-free b128 rows)
+
+int mlp_grid(int P) { return point_grid(P, MLP_WAVES, 32); }
+
+__device__ __forceinline__ double shfl_xor_d(double v, int m)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl_xor(lo, m);
+    hi = __shfl_xor(hi, m);
+    return __hiloint2double(hi, lo);
+}
+
+// gather one M-tile (edges j0 .. j0 + 31 of point pt) and leave a1 (and optionally u1) in LDS
+template <bool KEEP_U>
+__device__ __forceinline__ void gather_tile(const float *__restrict__ Pb, float q, int nv, int kk, float sc1,
+                                            float sh1, float slope, float (*tileA)[TSTR], float (*tileU)[TSTR],
+                                            int lane)
+{
+#pragma unroll
+    for (int j = 0; j < 32; j += 8) {
+        float p[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+            if (j + t < kk) p[t] = Pb[(size_t)__builtin_amdgcn_readlane(nv, j + t) * EC];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            float a = 0.0f, u = 0.0f;
+            if (j + t < kk) {
+                u = p[t] + q;
+                a = lrelu(__builtin_fmaf(u, sc1, sh1), slope);
+            }
+            tileA[j + t][lane] = a;
+            if (KEEP_U) tileU[j + t][lane] = u;
+        }
+    }
+}
+
+// A operand of the 32x32x2 MFMA from a [32][TSTR] tile: lane (i, h) holds row i, columns 32 h + s
+__device__ __forceinline__ void load_a_operand(const float (*tile)[TSTR], int i32, int h, float (&a)[32])
+{
+#pragma unroll
+    for (int s4 = 0; s4 < 8; ++s4) {
+        const float4 v = *reinterpret_cast<const float4 *>(&tile[i32][32 * h + 4 * s4]);
+        a[4 * s4 + 0] = v.x;
+        a[4 * s4 + 1] = v.y;
+        a[4 * s4 + 2] = v.z;
+        a[4 * s4 + 3] = v.w;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void edge_mlp_fwd_kernel(const float *__restrict__ TP, const float *__restrict__ TQ,
+                                                           const int32_t *__restrict__ idx, int N, int k, int P,
+                                                           const float *__restrict__ stats1,
+                                                           const float *__restrict__ w2,
+                                                           const float *__restrict__ gamma2, float slope,
+                                                           float *__restrict__ usel2, double *__restrict__ partial)
+{
+    __shared__ __attribute__((aligned(16))) float tiles[MLP_WAVES][32][TSTR];
+    __shared__ double red[MLP_WAVES][2][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, i32 = lane & 31;
+    float(*tileA)[TSTR] = tiles[wave];
+
+    // B operand: B[k = ci][n = co] = W2[co][ci]; lane (n, h) supplies ci = 32 h + s at step s
+    float wb[2][32];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int s = 0; s < 32; ++s) wb[nt][s] = w2[(size_t)(nt * 32 + i32) * EC + 32 * h + s];
+    bool neg[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) neg[nt] = gamma2[nt * 32 + i32] < 0.0f;
+    const float sc1 = stats1[ST_SC + lane], sh1 = stats1[ST_SH + lane];
+
+    double sum[2] = {0.0, 0.0}, sq[2] = {0.0, 0.0};
+    const PointIter it = point_iter(P, wave, MLP_WAVES);
+    for (int pt = it.cur; pt < it.end; pt += it.step) {
+        const int b = pt / N;
+        const float *Pb = TP + (size_t)b * N * EC + lane;
+        const float q = TQ[(size_t)pt * EC + lane];
+        const int32_t *ip = idx + (size_t)pt * k;
+        float ext[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) ext[nt] = neg[nt] ? __builtin_inff() : -__builtin_inff();
+        for (int j0 = 0; j0 < k; j0 += 32) {
+            const int kk = k - j0 < 32 ? k - j0 : 32;
+            const int nv = lane < kk ? ip[j0 + lane] : 0;
+            gather_tile<false>(Pb, q, nv, kk, sc1, sh1, slope, tileA, nullptr, lane);
+            float a[32];
+            load_a_operand(tileA, i32, h, a);
+            f32x16 acc[2];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
+#pragma unroll
+            for (int s = 0; s < 32; ++s) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], wb[0][s], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], wb[1][s], acc[1], 0, 0, 0);
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (mfma32_row(r, h) < kk) {
+                        const float u = acc[nt][r];
+                        sum[nt] += (double)u;
+                        sq[nt] = __builtin_fma((double)u, (double)u, sq[nt]);
+                        ext[nt] = neg[nt] ? fminf(ext[nt], u) : fmaxf(ext[nt], u);
+                    }
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const float o = __shfl_xor(ext[nt], 32);
+            const float e = neg[nt] ? fminf(ext[nt], o) : fmaxf(ext[nt], o);
+            if (h == 0) usel2[(size_t)pt * EC + nt * 32 + i32] = e;
+        }
+    }
+    // BN2 partial sums: lane (n, h) holds channel nt * 32 + n; fold the halves, then the waves
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const double s = sum[nt] + shfl_xor_d(sum[nt], 32);
+        const double ss = sq[nt] + shfl_xor_d(sq[nt], 32);
+        if (h == 0) {
+            red[wave][0][nt * 32 + i32] = s;
+            red[wave][1][nt * 32 + i32] = ss;
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            double s = red[0][i][lane];
+#pragma unroll
+            for (int w = 1; w < MLP_WAVES; ++w) s += red[w][i][lane];
+            partial[((size_t)blockIdx.x * 2 + i) * 64 + lane] = s;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void edge_mlp_bwd_kernel(
+    const float *__restrict__ TP, const float *__restrict__ TQ, const int32_t *__restrict__ idx, int N, int k, int P,
+    const float *__restrict__ stats1, const float *__restrict__ stats2, const float *__restrict__ cc2,
+    const float *__restrict__ w2, float slope, int training, const float *__restrict__ gy,
+    const float *__restrict__ y, float *__restrict__ dv1, float *__restrict__ partial_dw2,
+    double *__restrict__ partial_bn1)
+{
+    // W2 as the B operand of the two products that contract over a channel index:
+    //   imgU[nt][s][lane (n, h)] = W2[co = nt 32 + n][ci = 32 h + s]     (u2  = a1 . W2^T)
+    //   imgD[nt][s][lane (n, h)] = W2[co = 32 h + s][ci = nt 32 + n]     (da1 = du2 . W2)
+    __shared__ float imgU[2][32][64], imgD[2][32][64];
+    __shared__ __attribute__((aligned(16))) float tiles[MLP_WAVES][3][32][TSTR];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, i32 = lane & 31;
+    float(*tileA)[TSTR] = tiles[wave][0];  // a1 [edge][ci]
+    float(*tileU)[TSTR] = tiles[wave][1];  // u1 [edge][ci]
+    float(*tileD)[TSTR] = tiles[wave][2];  // du2 [edge][co]
+
+    for (int t = threadIdx.x; t < 2 * 32 * 64; t += 256) {
+        const int l = t & 63, s = (t >> 6) & 31, nt = t >> 11;
+        const int n = l & 31, hh = l >> 5;
+        imgU[nt][s][l] = w2[(size_t)(nt * 32 + n) * EC + 32 * hh + s];
+        imgD[nt][s][l] = w2[(size_t)(32 * hh + s) * EC + nt * 32 + n];
+    }
+    __syncthreads();
+
+    // gather-phase constants (lane = channel) and accumulator-layout constants (lane (n, h) = channel nt 32 + n)
+    const float sc1g = stats1[ST_SC + lane], sh1g = stats1[ST_SH + lane];
+    float mean1[2], rstd1[2], mean2[2], rstd2[2], sc2[2], sh2[2], c1[2], c2[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int c = nt * 32 + i32;
+        mean1[nt] = stats1[ST_MEAN + c];
+        rstd1[nt] = stats1[ST_RSTD + c];
+        mean2[nt] = stats2[ST_MEAN + c];
+        rstd2[nt] = stats2[ST_RSTD + c];
+        sc2[nt] = stats2[ST_SC + c];
+        sh2[nt] = stats2[ST_SH + c];
+        c1[nt] = cc2[c];
+        c2[nt] = cc2[64 + c];
+    }
+
+    f32x16 accW[2][2];  // gW2 tile [co tile][ci tile]
+#pragma unroll
+    for (int a_ = 0; a_ < 2; ++a_)
+#pragma unroll
+        for (int b_ = 0; b_ < 2; ++b_)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accW[a_][b_][r] = 0.0f;
+    double sb[2] = {0.0, 0.0}, sg[2] = {0.0, 0.0};  // BN1: sum dv1, sum dv1 * uhat1
+
+    const PointIter it = point_iter(P, wave, MLP_WAVES);
+    for (int pt = it.cur; pt < it.end; pt += it.step) {
+        const int b = pt / N;
+        const float *Pb = TP + (size_t)b * N * EC + lane;
+        const float q = TQ[(size_t)pt * EC + lane];
+        const int32_t *ip = idx + (size_t)pt * k;
+        float yv[2], dvs[2];
+        bool found[2] = {false, false};
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            yv[nt] = y[(size_t)pt * EC + nt * 32 + i32];
+            dvs[nt] = gy[(size_t)pt * EC + nt * 32 + i32] * (yv[nt] > 0.0f ? 1.0f : slope);
+        }
+        for (int j0 = 0; j0 < k; j0 += 32) {
+            const int kk = k - j0 < 32 ? k - j0 : 32;
+            const int nv = lane < kk ? ip[j0 + lane] : 0;
+            gather_tile<true>(Pb, q, nv, kk, sc1g, sh1g, slope, tileA, tileU, lane);
+
+            // ---- u2 = a1 . W2^T
+            float a[32];
+            load_a_operand(tileA, i32, h, a);
+            f32x16 acc[2];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
+#pragma unroll
+            for (int s = 0; s < 32; ++s) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], imgU[0][s][lane], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], imgU[1][s][lane], acc[1], 0, 0, 0);
+            }
+
+            // ---- du2 (in place of u2).  The whole dL/dy goes to the FIRST edge whose activation
+            // equals y (PyTorch's max semantics); the rest of du2 are the dense BatchNorm mean terms.
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                int first = 1000;
+#pragma unroll
+                for (int r = 15; r >= 0; --r) {
+                    const int row = mfma32_row(r, h);
+                    const float a2 = lrelu(__builtin_fmaf(acc[nt][r], sc2[nt], sh2[nt]), slope);
+                    if (row < kk && a2 == yv[nt]) first = row;
+                }
+                const int other = __shfl_xor(first, 32);
+                first = first < other ? first : other;
+                const int hitrow = (!found[nt] && first < 1000) ? first : -1;
+                found[nt] = found[nt] || (first < 1000);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = mfma32_row(r, h);
+                    float du = 0.0f;
+                    if (row < kk) {
+                        const float uhat = (acc[nt][r] - mean2[nt]) * rstd2[nt];
+                        const float dv = (row == hitrow) ? dvs[nt] : 0.0f;
+                        du = training ? sc2[nt] * (dv - c1[nt] - c2[nt] * uhat) : sc2[nt] * dv;
+                    }
+                    acc[nt][r] = du;
+                    tileD[row][nt * 32 + i32] = du;
+                }
+            }
+
+            // ---- gW2[co][ci] += sum_edges du2[edge][co] a1[edge][ci]: the du2 accumulators are the
+            // A operand as they stand (k = edge row of register r), a1 comes back from LDS as B.
+            float ba[2][16];
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ba[ct][r] = tileA[mfma32_row(r, h)][ct * 32 + i32];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+#pragma unroll
+                for (int cot = 0; cot < 2; ++cot)
+#pragma unroll
+                    for (int cit = 0; cit < 2; ++cit)
+                        accW[cot][cit] =
+                            __builtin_amdgcn_mfma_f32_32x32x2f32(acc[cot][r], ba[cit][r], accW[cot][cit], 0, 0, 0);
+            }
+
+            // ---- da1 = du2 . W2 (A operand through the LDS transpose), dv1 = da1 * LReLU'(v1)
+            load_a_operand(tileD, i32, h, a);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
+#pragma unroll
+            for (int s = 0; s < 32; ++s) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], imgD[0][s][lane], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], imgD[1][s][lane], acc[1], 0, 0, 0);
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = mfma32_row(r, h);
+                    if (row < kk) {
+                        const float d = acc[nt][r] * (ba[nt][r] > 0.0f ? 1.0f : slope);
+                        const float uhat = (tileU[row][nt * 32 + i32] - mean1[nt]) * rstd1[nt];
+                        dv1[((size_t)pt * k + j0 + row) * EC + nt * 32 + i32] = d;
+                        sb[nt] += (double)d;
+                        sg[nt] = __builtin_fma((double)d, (double)uhat, sg[nt]);
+                    }
+                }
+        }
+    }
+
+    // ---- workgroup reduction of gW2 and of the BN1 sums (tile memory is free now)
+    __syncthreads();
+    float *scr = &tiles[0][0][0][0];  // 4 waves x 4096 floats fit in the tile area
+#pragma unroll
+    for (int cot = 0; cot < 2; ++cot)
+#pragma unroll
+        for (int cit = 0; cit < 2; ++cit)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                scr[wave * 4096 + (cot * 32 + mfma32_row(r, h)) * 64 + cit * 32 + i32] = accW[cot][cit][r];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 4096; e += 256)
+        partial_dw2[(size_t)blockIdx.x * 4096 + e] = (scr[e] + scr[4096 + e]) + (scr[8192 + e] + scr[12288 + e]);
+    __syncthreads();
+    double *red = reinterpret_cast<double *>(scr);  // [wave][2][64]
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const double s = sb[nt] + shfl_xor_d(sb[nt], 32);
+        const double g = sg[nt] + shfl_xor_d(sg[nt], 32);
+        if (h == 0) {
+            red[(wave * 2 + 0) * 64 + nt * 32 + i32] = s;
+            red[(wave * 2 + 1) * 64 + nt * 32 + i32] = g;
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            double s = red[(0 * 2 + i) * 64 + lane];
+#pragma unroll
+            for (int w = 1; w < MLP_WAVES; ++w) s += red[(w * 2 + i) * 64 + lane];
+            partial_bn1[((size_t)blockIdx.x * 2 + i) * 64 + lane] = s;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+void launch_edge_mlp_fwd(const float *TP, const float *TQ, const int32_t *idx, int N, int k, int P,
+                         const float *stats1, const float *w2, const float *gamma2, float slope, float *usel2,
+                         double *partial, hipStream_t st)
+{
+    hipLaunchKernelGGL(edge_mlp_fwd_kernel, dim3(mlp_grid(P)), dim3(256), 0, st, TP, TQ, idx, N, k, P, stats1, w2,
+                       gamma2, slope, usel2, partial);
+}
+
+void launch_edge_mlp_bwd(const float *TP, const float *TQ, const int32_t *idx, int N, int k, int P,
+                         const float *stats1, const float *stats2, const float *cc2, const float *w2, float slope,
+                         int training, const float *gy, const float *y, float *dv1, float *partial_dw2,
+                         double *partial_bn1, hipStream_t st)
+{
+    hipLaunchKernelGGL(edge_mlp_bwd_kernel, dim3(mlp_grid(P)), dim3(256), 0, st, TP, TQ, idx, N, k, P, stats1, stats2,
+                       cc2, w2, slope, training, gy, y, dv1, partial_dw2, partial_bn1);
+}
+
+}  // namespace dgcnn

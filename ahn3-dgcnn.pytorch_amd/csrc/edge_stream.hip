@@ -1,0 +1,354 @@
+// edge_stream.hip -- the edge-streaming passes of the EdgeConv block (gather, reduce, scatter).
+//
+// Mapping for every pass: one wave = one point at a time, lane = output channel (64).  A
+// neighbour's row of TP is 64 fp32 = 256 contiguous bytes, so each gather is one fully coalesced
+// wave-load and each scatter one 256-byte wave-atomic (the shape that global float atomics run
+// at full rate on MI355X).  The neighbour list of the point sits in one VGPR (lane j holds
+// idx[i][j]) and is broadcast with v_readlane.
+//
+// What the passes compute (reference lines in /root/reference/model.py):
+//   u[i][j]  = TP[n(i, j)] + TQ[i]           the first conv on the edge tuple (model.py:74-81 + :116/:122/:128)
+//   BN stats = sum u, sum u^2 over all edges  (BatchNorm2d batch statistics, model.py:107-111), in fp64
+//   usel[i]  = the extreme of u over the k neighbours that survives max-over-k (model.py:150,157,163):
+//              BN-affine + LeakyReLU is monotone per channel (increasing if gamma >= 0, else
+//              decreasing), and every fp32 rounding in it is monotone too, so
+//              max_j LReLU(BN(u_j)) == LReLU(BN(max_j u_j))  (min_j if gamma < 0)  bit for bit.
+#include "edge_kernels.h"
+
+namespace dgcnn {
+
+constexpr int EDGE_WAVES = 4;  // waves per workgroup in the streaming passes
+
+int edge_grid(int P) { return point_grid(P, EDGE_WAVES, 128); }
+
+// sum the per-lane doubles of the workgroup's 4 waves and write partial[blockIdx][which][64]
+template <int NV>
+__device__ __forceinline__ void block_reduce_store(double (&v)[NV], double *__restrict__ partial)
+{
+    __shared__ double red[EDGE_WAVES][NV][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) red[wave][i][lane] = v[i];
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            double s = red[0][i][lane];
+#pragma unroll
+            for (int w = 1; w < EDGE_WAVES; ++w) s += red[w][i][lane];
+            partial[((size_t)blockIdx.x * NV + i) * 64 + lane] = s;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <bool WANT_EXT>
+__global__ __launch_bounds__(256) void edge_reduce_kernel(const float *__restrict__ TP, const float *__restrict__ TQ,
+                                                          const int32_t *__restrict__ idx, int N, int k, int P,
+                                                          const float *__restrict__ gamma, float *__restrict__ usel,
+                                                          double *__restrict__ partial)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool neg = WANT_EXT ? (gamma[lane] < 0.0f) : false;
+    double acc[2] = {0.0, 0.0};
+    const PointIter it = point_iter(P, wave, EDGE_WAVES);
+    for (int pt = it.cur; pt < it.end; pt += it.step) {
+        const int b = pt / N;
+        const float *Pb = TP + (size_t)b * N * EC + lane;
+        const float q = TQ[(size_t)pt * EC + lane];
+        const int32_t *ip = idx + (size_t)pt * k;
+        float ext = neg ? __builtin_inff() : -__builtin_inff();
+        for (int j0 = 0; j0 < k; j0 += 64) {
+            const int kk = k - j0 < 64 ? k - j0 : 64;
+            const int nv = lane < kk ? ip[j0 + lane] : 0;
+            for (int j = 0; j < kk; j += 8) {
+                float p[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+                    if (j + t < kk) p[t] = Pb[(size_t)__builtin_amdgcn_readlane(nv, j + t) * EC];
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+                    if (j + t < kk) {
+                        const float u = p[t] + q;
+                        acc[0] += (double)u;
+                        acc[1] = __builtin_fma((double)u, (double)u, acc[1]);
+                        if (WANT_EXT) ext = neg ? fminf(ext, u) : fmaxf(ext, u);
+                    }
+            }
+        }
+        if (WANT_EXT) usel[(size_t)pt * EC + lane] = ext;
+    }
+    block_reduce_store<2>(acc, partial);
+}
+
+// one workgroup of 64 threads: thread = channel.  Partials are summed in index order -> deterministic.
+__global__ void bn_finalize_kernel(const double *__restrict__ partial, int nparts, double count, int training,
+                                   dgcnn_bn_params bn, float eps, float momentum, float *__restrict__ stats)
+{
+    const int c = threadIdx.x;
+    float mean, var;
+    if (training) {
+        double s = 0.0, ss = 0.0;
+        for (int g = 0; g < nparts; ++g) {
+            s += partial[((size_t)g * 2 + 0) * 64 + c];
+            ss += partial[((size_t)g * 2 + 1) * 64 + c];
+        }
+        const double m = s / count;
+        double v = ss / count - m * m;  // biased variance, as BatchNorm normalises with
+        if (v < 0.0) v = 0.0;
+        mean = (float)m;
+        var = (float)v;
+        if (bn.running_mean) {
+            const double unbiased = count > 1.0 ? v * count / (count - 1.0) : v;
+            bn.running_mean[c] = (1.0f - momentum) * bn.running_mean[c] + momentum * mean;
+            bn.running_var[c] = (1.0f - momentum) * bn.running_var[c] + momentum * (float)unbiased;
+        }
+    } else {
+        mean = bn.running_mean[c];
+        var = bn.running_var[c];
+    }
+    const float rstd = (float)(1.0 / sqrt((double)var + (double)eps));
+    const float sc = bn.weight[c] * rstd;
+    stats[ST_MEAN + c] = mean;
+    stats[ST_RSTD + c] = rstd;
+    stats[ST_SC + c] = sc;
+    stats[ST_SH + c] = bn.bias[c] - mean * sc;
+}
+
+__global__ void edge_out_kernel(const float *__restrict__ usel, const float *__restrict__ stats, float slope,
+                                size_t n4, float *__restrict__ y)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n4) return;
+    const int c = (int)(t & 15) * 4;
+    const float4 u = reinterpret_cast<const float4 *>(usel)[t];
+    const float4 sc = *reinterpret_cast<const float4 *>(stats + ST_SC + c);
+    const float4 sh = *reinterpret_cast<const float4 *>(stats + ST_SH + c);
+    float4 o;
+    o.x = lrelu(__builtin_fmaf(u.x, sc.x, sh.x), slope);
+    o.y = lrelu(__builtin_fmaf(u.y, sc.y, sh.y), slope);
+    o.z = lrelu(__builtin_fmaf(u.z, sc.z, sh.z), slope);
+    o.w = lrelu(__builtin_fmaf(u.w, sc.w, sh.w), slope);
+    reinterpret_cast<float4 *>(y)[t] = o;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward of the LAST BatchNorm of the block.  Only the arg-max edge of each (point, channel)
+// carries gradient through max-over-k, so  sum dv  and  sum dv * uhat  over all edges reduce to
+// sums over points of quantities at the selected extreme.
+__global__ __launch_bounds__(256) void bwd_point_kernel(const float *__restrict__ gy, const float *__restrict__ usel,
+                                                        const float *__restrict__ stats, float slope, int P,
+                                                        double *__restrict__ partial)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float mean = stats[ST_MEAN + lane], rstd = stats[ST_RSTD + lane];
+    const float sc = stats[ST_SC + lane], sh = stats[ST_SH + lane];
+    double acc[2] = {0.0, 0.0};
+    for (int pt = blockIdx.x * EDGE_WAVES + wave; pt < P; pt += gridDim.x * EDGE_WAVES) {
+        const float us = usel[(size_t)pt * EC + lane];
+        const float v = __builtin_fmaf(us, sc, sh);
+        const float dv = gy[(size_t)pt * EC + lane] * (v > 0.0f ? 1.0f : slope);
+        const float uhat = (us - mean) * rstd;
+        acc[0] += (double)dv;
+        acc[1] = __builtin_fma((double)dv, (double)uhat, acc[1]);
+    }
+    block_reduce_store<2>(acc, partial);
+}
+
+// gbn_b = sum dv, gbn_w = sum dv * uhat;  cc[0..63] = gbn_b / count, cc[64..127] = gbn_w / count
+// (the two mean terms of the BatchNorm input gradient; zero in eval mode, where the statistics
+// are constants).
+__global__ void bn_bwd_finalize_kernel(const double *__restrict__ partial, int nparts, double count, int training,
+                                       float *__restrict__ gbn_w, float *__restrict__ gbn_b, float *__restrict__ cc)
+{
+    const int c = threadIdx.x;
+    double sb = 0.0, sg = 0.0;
+    for (int g = 0; g < nparts; ++g) {
+        sb += partial[((size_t)g * 2 + 0) * 64 + c];
+        sg += partial[((size_t)g * 2 + 1) * 64 + c];
+    }
+    gbn_b[c] = (float)sb;
+    gbn_w[c] = (float)sg;
+    cc[c] = training ? (float)(sb / count) : 0.0f;
+    cc[64 + c] = training ? (float)(sg / count) : 0.0f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stage-1 backward over the edges.  With du = sc * (dv - c1 - c2 * uhat)   (Appendix C.5)
+//   dD[i]        = sum_j du[i][j]                 (gradient of TQ[i]: RepeatBackward0 + Sub/CatBackward0)
+//   dR[n(i, j)] += du[i][j]                       (gradient of TP rows: IndexBackward0, a scatter-add)
+// DENSE = false: dv is non-zero only at the first edge j* whose activation equals y[i] (PyTorch's
+// max routes the whole gradient to the first maximum); the dense mean terms are streamed for all
+// edges and the single dv term is added once per (point, channel).
+// DENSE = true : dv[i][j] comes from the second stage's backward ([E][64] in HBM).
+template <bool DENSE>
+__global__ __launch_bounds__(256) void edge_bwd_kernel(const float *__restrict__ TP, const float *__restrict__ TQ,
+                                                       const int32_t *__restrict__ idx, int N, int k, int P,
+                                                       const float *__restrict__ stats, const float *__restrict__ cc,
+                                                       float slope, int training, const float *__restrict__ gy,
+                                                       const float *__restrict__ y, const float *__restrict__ dv,
+                                                       float *__restrict__ dR, float *__restrict__ dD)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float mean = stats[ST_MEAN + lane], rstd = stats[ST_RSTD + lane];
+    const float sc = stats[ST_SC + lane], sh = stats[ST_SH + lane];
+    const float c1 = cc[lane], c2 = cc[64 + lane];
+    const PointIter it = point_iter(P, wave, EDGE_WAVES);
+    for (int pt = it.cur; pt < it.end; pt += it.step) {
+        const int b = pt / N;
+        const float *Pb = TP + (size_t)b * N * EC + lane;
+        float *Rb = dR + (size_t)b * N * EC + lane;
+        const float q = TQ[(size_t)pt * EC + lane];
+        const int32_t *ip = idx + (size_t)pt * k;
+        float yv = 0.0f, dvs = 0.0f;
+        if (!DENSE) {
+            yv = y[(size_t)pt * EC + lane];
+            dvs = gy[(size_t)pt * EC + lane] * (yv > 0.0f ? 1.0f : slope);
+        }
+        int hit = -1;  // neighbour index of the first edge attaining the maximum activation
+        float dsum = 0.0f;
+        for (int j0 = 0; j0 < k; j0 += 64) {
+            const int kk = k - j0 < 64 ? k - j0 : 64;
+            const int nv = lane < kk ? ip[j0 + lane] : 0;
+            for (int j = 0; j < kk; j += 8) {
+                float p[8], d[8];
+                int n[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+                    if (j + t < kk) {
+                        n[t] = __builtin_amdgcn_readlane(nv, j + t);
+                        p[t] = Pb[(size_t)n[t] * EC];
+                        if (DENSE) d[t] = dv[((size_t)pt * k + j0 + j + t) * EC + lane];
+                    }
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+                    if (j + t < kk) {
+                        const float u = p[t] + q;
+                        if (!DENSE) {
+                            const float a = lrelu(__builtin_fmaf(u, sc, sh), slope);
+                            if (hit < 0 && a == yv) hit = n[t];
+                        }
+                        if (DENSE || training) {
+                            const float uhat = (u - mean) * rstd;
+                            const float du = sc * ((DENSE ? d[t] : 0.0f) - c1 - c2 * uhat);
+                            dsum += du;
+                            atomicAdd(Rb + (size_t)n[t] * EC, du);
+                        }
+                    }
+            }
+        }
+        if (!DENSE) {
+            const float du = sc * dvs;
+            dsum += du;
+            if (hit >= 0) atomicAdd(Rb + (size_t)hit * EC, du);
+        }
+        dD[(size_t)pt * EC + lane] = dsum;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Materialised edge features for the public get_graph_feature API (model.py:64-81).
+// thread = one float of out [B][N][k][2C].
+__global__ void graph_feature_fwd_kernel(const float *__restrict__ x, const int32_t *__restrict__ idx, int N, int C,
+                                         int k, size_t total, float *__restrict__ out)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int c2 = (int)(t % (2 * C));
+    const size_t e = t / (2 * C);  // edge (b, i, j)
+    const size_t pt = e / k;       // point (b, i)
+    const size_t b = pt / N;
+    const float ctr = x[pt * C + (c2 < C ? c2 : c2 - C)];
+    float v = ctr;
+    if (c2 < C) v = x[(b * N + idx[e]) * C + c2] - ctr;
+    out[t] = v;
+}
+
+// gx[b][i] += sum_j (g_ctr[i][j] - g_diff[i][j]);  gx[b][n(i, j)] += g_diff[i][j]
+__global__ void graph_feature_bwd_kernel(const float *__restrict__ gout, const int32_t *__restrict__ idx, int N, int C,
+                                         int k, size_t npc, float *__restrict__ gx)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // (point, channel)
+    if (t >= npc) return;
+    const int c = (int)(t % C);
+    const size_t pt = t / C, b = pt / N;
+    float s = 0.0f;
+    for (int j = 0; j < k; ++j) {
+        const size_t e = pt * k + j;
+        const float gd = gout[e * 2 * C + c], gc = gout[e * 2 * C + C + c];
+        s += gc - gd;
+        atomicAdd(&gx[(b * N + idx[e]) * C + c], gd);
+    }
+    atomicAdd(&gx[t], s);
+}
+
+// ---------------------------------------------------------------------------------------------
+void launch_edge_reduce(const float *TP, const float *TQ, const int32_t *idx, int N, int k, int P, const float *gamma,
+                        float *usel, double *partial, hipStream_t st)
+{
+    const dim3 grid(edge_grid(P)), block(256);
+    if (usel)
+        hipLaunchKernelGGL((edge_reduce_kernel<true>), grid, block, 0, st, TP, TQ, idx, N, k, P, gamma, usel, partial);
+    else
+        hipLaunchKernelGGL((edge_reduce_kernel<false>), grid, block, 0, st, TP, TQ, idx, N, k, P, gamma, usel, partial);
+}
+
+void launch_bn_finalize(const double *partial, int nparts, double count, int training, const dgcnn_bn_params &bn,
+                        float eps, float momentum, float *stats, hipStream_t st)
+{
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, st, partial, nparts, count, training, bn, eps,
+                       momentum, stats);
+}
+
+void launch_edge_out(const float *usel, const float *stats, float slope, int P, float *y, hipStream_t st)
+{
+    const size_t n4 = (size_t)P * EC / 4;
+    hipLaunchKernelGGL(edge_out_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, usel, stats, slope, n4, y);
+}
+
+void launch_bn_bwd_finalize(const double *partial, int nparts, double count, int training, float *gbn_w, float *gbn_b,
+                            float *cc, hipStream_t st)
+{
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(64), 0, st, partial, nparts, count, training, gbn_w,
+                       gbn_b, cc);
+}
+
+void launch_bwd_point(const float *gy, const float *usel, const float *stats, float slope, int P, double count,
+                      int training, double *partial, float *gbn_w, float *gbn_b, float *cc, hipStream_t st)
+{
+    int grid = ceil_div(P, EDGE_WAVES * 8);
+    if (grid > 512) grid = 512;
+    hipLaunchKernelGGL(bwd_point_kernel, dim3(grid), dim3(256), 0, st, gy, usel, stats, slope, P, partial);
+    launch_bn_bwd_finalize(partial, grid, count, training, gbn_w, gbn_b, cc, st);
+}
+
+void launch_edge_bwd(const float *TP, const float *TQ, const int32_t *idx, int N, int k, int P, const float *stats,
+                     const float *cc, float slope, int training, const float *gy, const float *y, const float *dv,
+                     float *dR, float *dD, hipStream_t st)
+{
+    const dim3 grid(edge_grid(P)), block(256);
+    if (dv)
+        hipLaunchKernelGGL((edge_bwd_kernel<true>), grid, block, 0, st, TP, TQ, idx, N, k, P, stats, cc, slope,
+                           training, gy, y, dv, dR, dD);
+    else
+        hipLaunchKernelGGL((edge_bwd_kernel<false>), grid, block, 0, st, TP, TQ, idx, N, k, P, stats, cc, slope,
+                           training, gy, y, dv, dR, dD);
+}
+
+void launch_graph_feature_fwd(const float *x, const int32_t *idx, int B, int N, int C, int k, float *out,
+                              hipStream_t st)
+{
+    const size_t total = (size_t)B * N * k * 2 * C;
+    hipLaunchKernelGGL(graph_feature_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, idx, N, C,
+                       k, total, out);
+}
+
+void launch_graph_feature_bwd(const float *gout, const int32_t *idx, int B, int N, int C, int k, float *gx,
+                              hipStream_t st)
+{
+    const size_t npc = (size_t)B * N * C;
+    hipLaunchKernelGGL(graph_feature_bwd_kernel, dim3((unsigned)((npc + 255) / 256)), dim3(256), 0, st, gout, idx, N,
+                       C, k, npc, gx);
+}
+
+}  // namespace dgcnn

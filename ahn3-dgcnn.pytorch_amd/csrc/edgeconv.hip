@@ -1,0 +1,238 @@
+// edgeconv.hip -- C ABI of the EdgeConv block: validates the descriptor, carves the caller's
+// workspace and enqueues the kernel sequence on the caller's stream (no allocation, no sync).
+//
+// Forward (reference model.py:147-150 / 154-157 / 161-163), P = B N points, E = P k edges:
+//   prep_wcat        Wcat = [Wa ; Wb - Wa] from conv weight W1 = [Wa | Wb]
+//   rowgemm          TP = x Wa^T, TQ = x (Wb - Wa)^T                           (MFMA, per point)
+//   1 stage : edge_reduce   u = TP[n] + TQ[i]: BN batch sums + selected extreme over k
+//             bn_finalize   mean / rstd / affine; running-statistics update
+//   2 stages: edge_reduce   BN1 batch sums only
+//             bn_finalize   BN1
+//             edge_mlp_fwd  a1 = LReLU(BN1(u)); u2 = W2 a1 (MFMA, per edge); BN2 sums + extreme
+//             bn_finalize   BN2
+//   edge_out         y = LReLU(BN(extreme))      == max over k of the activations, exactly
+//
+// Backward (autograd nodes listed in SURVEY.md 2.1 "Bw"; formulas Appendix C.5):
+//   bwd_point        last BN: gbn_w, gbn_b and the two mean terms (per-point sums suffice)
+//   2 stages: edge_mlp_bwd  recompute a1, u2; du2; gW2 partials; dv1 = (W2^T du2) * LReLU'; BN1 sums
+//             sum_partials  gW2;   bn_bwd_finalize  BN1
+//   edge_bwd         du1 -> dD (sum over k) and dR (scatter-add to neighbours)
+//   wgrad + finish   gW1 = [ (dR - dD)^T x | dD^T x ]                           (MFMA, per point)
+//   rowgemm          gx = dR Wa + dD (Wb - Wa)                                   (MFMA, per point)
+#include "edge_kernels.h"
+
+namespace dgcnn {
+
+constexpr int PART_MAX = 2048;  // upper bound on the number of per-workgroup partial records
+
+struct Carver {
+    char *base;
+    size_t off;
+    explicit Carver(void *p) : base((char *)p), off(0) {}
+    template <typename T>
+    T *take(size_t n)
+    {
+        T *r = (T *)(base + off);
+        off += align_up(n * sizeof(T), 256);
+        return r;
+    }
+};
+
+struct SavedLayout {
+    float *TP, *TQ, *usel, *stats1, *stats2;
+    size_t bytes;
+};
+static SavedLayout saved_layout(const dgcnn_edgeconv_desc *d, void *p)
+{
+    Carver c(p);
+    SavedLayout s;
+    const size_t P = (size_t)d->B * d->N;
+    s.TP = c.take<float>(P * EC);
+    s.TQ = c.take<float>(P * EC);
+    s.usel = c.take<float>(P * EC);
+    s.stats1 = c.take<float>(ST_SIZE);
+    s.stats2 = c.take<float>(ST_SIZE);
+    s.bytes = c.off;
+    return s;
+}
+
+struct FwdWs {
+    float *wcatT, *wcat;
+    double *partial;
+    size_t bytes;
+};
+static FwdWs fwd_ws(const dgcnn_edgeconv_desc *d, void *p)
+{
+    Carver c(p);
+    FwdWs w;
+    w.wcatT = c.take<float>((size_t)(d->C + 1) * 128);
+    w.wcat = c.take<float>((size_t)128 * d->C);
+    w.partial = c.take<double>((size_t)PART_MAX * 2 * 64);
+    w.bytes = c.off;
+    return w;
+}
+
+struct BwdWs {
+    float *wcatT, *wcat, *cc1, *cc2, *dR, *dD, *wg_partial, *dv1, *dw2_partial;
+    double *partial, *bn1_partial;
+    size_t bytes;
+};
+static BwdWs bwd_ws(const dgcnn_edgeconv_desc *d, void *p)
+{
+    Carver c(p);
+    BwdWs w;
+    const size_t P = (size_t)d->B * d->N;
+    w.wcatT = c.take<float>((size_t)(d->C + 1) * 128);
+    w.wcat = c.take<float>((size_t)128 * d->C);
+    w.partial = c.take<double>((size_t)PART_MAX * 2 * 64);
+    w.cc1 = c.take<float>(128);
+    w.cc2 = c.take<float>(128);
+    w.dR = c.take<float>(P * EC);
+    w.dD = c.take<float>(P * EC);
+    w.wg_partial = c.take<float>((size_t)wgrad_chunks((int)P) * 128 * d->C);
+    if (d->n_stage == 2) {
+        w.dv1 = c.take<float>(P * d->k * EC);
+        w.dw2_partial = c.take<float>((size_t)PART_MAX * EC * EC);
+        w.bn1_partial = c.take<double>((size_t)PART_MAX * 2 * 64);
+    } else {
+        w.dv1 = nullptr;
+        w.dw2_partial = nullptr;
+        w.bn1_partial = nullptr;
+    }
+    w.bytes = c.off;
+    return w;
+}
+
+static int check_desc(const dgcnn_edgeconv_desc *d, const char *who)
+{
+    DG_REQUIRE(d, "%s: null descriptor", who);
+    DG_REQUIRE(d->B > 0 && d->N > 0 && d->C > 0 && d->k > 0, "%s: bad shape B=%d N=%d C=%d k=%d", who, d->B, d->N,
+               d->C, d->k);
+    DG_REQUIRE(d->C <= 64, "%s: C=%d > 64 unsupported", who, d->C);
+    DG_REQUIRE(d->k <= 96, "%s: k=%d > 96 unsupported", who, d->k);
+    DG_REQUIRE((size_t)d->B * d->N * d->k < ((size_t)1 << 31), "%s: more than 2^31 edges", who);
+    DG_REQUIRE(d->n_stage == 1 || d->n_stage == 2, "%s: n_stage must be 1 or 2", who);
+    DG_REQUIRE(d->w1 && d->bn1.weight && d->bn1.bias, "%s: stage-1 parameters missing", who);
+    DG_REQUIRE(d->training || (d->bn1.running_mean && d->bn1.running_var), "%s: eval mode needs running statistics",
+               who);
+    if (d->n_stage == 2) {
+        DG_REQUIRE(d->w2 && d->bn2.weight && d->bn2.bias, "%s: stage-2 parameters missing", who);
+        DG_REQUIRE(d->training || (d->bn2.running_mean && d->bn2.running_var),
+                   "%s: eval mode needs running statistics", who);
+        DG_REQUIRE(d->k <= 64, "%s: two-stage blocks support k <= 64 (k=%d)", who, d->k);
+    }
+    return 0;
+}
+
+}  // namespace dgcnn
+
+using namespace dgcnn;
+
+extern "C" size_t dgcnn_edgeconv_saved_bytes(const dgcnn_edgeconv_desc *d)
+{
+    return d ? saved_layout(d, nullptr).bytes : 0;
+}
+extern "C" size_t dgcnn_edgeconv_fwd_workspace_bytes(const dgcnn_edgeconv_desc *d)
+{
+    return d ? fwd_ws(d, nullptr).bytes : 0;
+}
+extern "C" size_t dgcnn_edgeconv_bwd_workspace_bytes(const dgcnn_edgeconv_desc *d)
+{
+    return d ? bwd_ws(d, nullptr).bytes : 0;
+}
+
+extern "C" int dgcnn_edgeconv_fwd(const dgcnn_edgeconv_desc *d, const float *x, const int32_t *idx, float *y,
+                                  void *saved, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (check_desc(d, "dgcnn_edgeconv_fwd")) return 1;
+    DG_REQUIRE(x && idx && y && saved && workspace, "dgcnn_edgeconv_fwd: null pointer");
+    const FwdWs w = fwd_ws(d, workspace);
+    DG_REQUIRE(workspace_bytes >= w.bytes, "dgcnn_edgeconv_fwd: workspace too small (%zu < %zu)", workspace_bytes,
+               w.bytes);
+    const SavedLayout s = saved_layout(d, saved);
+    hipStream_t st = (hipStream_t)stream;
+    const int P = d->B * d->N, N = d->N, C = d->C, k = d->k;
+    const double E = (double)P * k;
+
+    launch_prep_wcat(d->w1, C, C, w.wcatT, w.wcat, st);
+    launch_rowgemm(x, C, nullptr, 0, w.wcatT, 128, s.TP, EC, s.TQ, P, st);
+    if (d->n_stage == 1) {
+        if (!d->training) launch_bn_finalize(w.partial, 0, E, 0, d->bn1, d->eps, d->momentum, s.stats1, st);
+        launch_edge_reduce(s.TP, s.TQ, idx, N, k, P, d->bn1.weight, s.usel, w.partial, st);
+        if (d->training)
+            launch_bn_finalize(w.partial, edge_grid(P), E, 1, d->bn1, d->eps, d->momentum, s.stats1, st);
+        launch_edge_out(s.usel, s.stats1, d->slope, P, y, st);
+    } else {
+        if (d->training) {
+            launch_edge_reduce(s.TP, s.TQ, idx, N, k, P, d->bn1.weight, nullptr, w.partial, st);
+            launch_bn_finalize(w.partial, edge_grid(P), E, 1, d->bn1, d->eps, d->momentum, s.stats1, st);
+        } else {
+            launch_bn_finalize(w.partial, 0, E, 0, d->bn1, d->eps, d->momentum, s.stats1, st);
+            launch_bn_finalize(w.partial, 0, E, 0, d->bn2, d->eps, d->momentum, s.stats2, st);
+        }
+        launch_edge_mlp_fwd(s.TP, s.TQ, idx, N, k, P, s.stats1, d->w2, d->bn2.weight, d->slope, s.usel, w.partial, st);
+        if (d->training)
+            launch_bn_finalize(w.partial, mlp_grid(P), E, 1, d->bn2, d->eps, d->momentum, s.stats2, st);
+        launch_edge_out(s.usel, s.stats2, d->slope, P, y, st);
+    }
+    DG_CHECK_LAUNCH("dgcnn_edgeconv_fwd");
+    return 0;
+}
+
+extern "C" int dgcnn_edgeconv_bwd(const dgcnn_edgeconv_desc *d, const float *x, const int32_t *idx, const float *y,
+                                  const float *gy, const void *saved, const dgcnn_edgeconv_grads *g, void *workspace,
+                                  size_t workspace_bytes, void *stream)
+{
+    if (check_desc(d, "dgcnn_edgeconv_bwd")) return 1;
+    DG_REQUIRE(x && idx && y && gy && saved && g && workspace, "dgcnn_edgeconv_bwd: null pointer");
+    DG_REQUIRE(g->gw1 && g->gbn1_w && g->gbn1_b, "dgcnn_edgeconv_bwd: stage-1 gradient outputs missing");
+    if (d->n_stage == 2) DG_REQUIRE(g->gw2 && g->gbn2_w && g->gbn2_b, "dgcnn_edgeconv_bwd: stage-2 gradient outputs missing");
+    const BwdWs w = bwd_ws(d, workspace);
+    DG_REQUIRE(workspace_bytes >= w.bytes, "dgcnn_edgeconv_bwd: workspace too small (%zu < %zu)", workspace_bytes,
+               w.bytes);
+    const SavedLayout s = saved_layout(d, const_cast<void *>(saved));
+    hipStream_t st = (hipStream_t)stream;
+    const int P = d->B * d->N, N = d->N, C = d->C, k = d->k;
+    const double E = (double)P * k;
+
+    launch_prep_wcat(d->w1, C, C, w.wcatT, w.wcat, st);
+    if (hipMemsetAsync(w.dR, 0, (size_t)P * EC * sizeof(float), st) != hipSuccess)
+        DG_FAIL("dgcnn_edgeconv_bwd: hipMemsetAsync failed");
+    if (d->n_stage == 1) {
+        launch_bwd_point(gy, s.usel, s.stats1, d->slope, P, E, d->training, w.partial, g->gbn1_w, g->gbn1_b, w.cc1, st);
+        launch_edge_bwd(s.TP, s.TQ, idx, N, k, P, s.stats1, w.cc1, d->slope, d->training, gy, y, nullptr, w.dR, w.dD,
+                        st);
+    } else {
+        launch_bwd_point(gy, s.usel, s.stats2, d->slope, P, E, d->training, w.partial, g->gbn2_w, g->gbn2_b, w.cc2, st);
+        launch_edge_mlp_bwd(s.TP, s.TQ, idx, N, k, P, s.stats1, s.stats2, w.cc2, d->w2, d->slope, d->training, gy, y,
+                            w.dv1, w.dw2_partial, w.bn1_partial, st);
+        launch_sum_partials(w.dw2_partial, mlp_grid(P), EC * EC, g->gw2, st);
+        launch_bn_bwd_finalize(w.bn1_partial, mlp_grid(P), E, d->training, g->gbn1_w, g->gbn1_b, w.cc1, st);
+        launch_edge_bwd(s.TP, s.TQ, idx, N, k, P, s.stats1, w.cc1, d->slope, d->training, gy, y, w.dv1, w.dR, w.dD, st);
+    }
+    launch_wgrad(w.dR, EC, w.dD, EC, x, C, P, w.wg_partial, st);
+    launch_finish_dw1(w.wg_partial, wgrad_chunks(P), C, g->gw1, st);
+    if (g->gx) launch_rowgemm(w.dR, EC, w.dD, EC, w.wcat, C, g->gx, C, nullptr, P, st);
+    DG_CHECK_LAUNCH("dgcnn_edgeconv_bwd");
+    return 0;
+}
+
+extern "C" int dgcnn_graph_feature_fwd(const float *x, const int32_t *idx, int B, int N, int C, int k, float *out,
+                                       void *stream)
+{
+    DG_REQUIRE(x && idx && out, "dgcnn_graph_feature_fwd: null pointer");
+    DG_REQUIRE(B > 0 && N > 0 && C > 0 && k > 0, "dgcnn_graph_feature_fwd: bad shape");
+    launch_graph_feature_fwd(x, idx, B, N, C, k, out, (hipStream_t)stream);
+    DG_CHECK_LAUNCH("graph_feature_fwd_kernel");
+    return 0;
+}
+
+extern "C" int dgcnn_graph_feature_bwd(const float *gout, const int32_t *idx, int B, int N, int C, int k, float *gx,
+                                       void *stream)
+{
+    DG_REQUIRE(gout && idx && gx, "dgcnn_graph_feature_bwd: null pointer");
+    DG_REQUIRE(B > 0 && N > 0 && C > 0 && k > 0, "dgcnn_graph_feature_bwd: bad shape");
+    launch_graph_feature_bwd(gout, idx, B, N, C, k, gx, (hipStream_t)stream);
+    DG_CHECK_LAUNCH("graph_feature_bwd_kernel");
+    return 0;
+}

@@ -1,0 +1,211 @@
+// pointgemm.hip -- per-POINT fp32 contractions of the EdgeConv block on v_mfma_f32_32x32x2_f32.
+//
+// The first convolution of every block (model.py:116,122,128: Conv2d(2C, 64, 1)) acts on the
+// edge tuple e = [x_j - x_i ; x_i] (model.py:81).  Being linear,
+//     W . e = Wa . x_j + (Wb - Wa) . x_i            (W = [Wa | Wb])
+// so it is evaluated once per point instead of once per edge: TP = x Wa^T, TQ = x (Wb - Wa)^T
+// ([P][64] each); the edge passes then only gather-and-add rows of TP.  The same identity turns
+// the first convolution's backward into two more per-point products (dgrad and wgrad) over the
+// scatter-reduced edge gradients.  All three run here on the exact-fp32 MFMA.
+#include "edge_kernels.h"
+
+namespace dgcnn {
+
+__global__ void prep_wcat_kernel(const float *__restrict__ w1, int C, int Ke, float *__restrict__ wcatT,
+                                 float *__restrict__ wcat)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= Ke * 128) return;
+    const int c = t / 128, o = t % 128;
+    float v = 0.0f;
+    if (c < C) {
+        if (o < EC)
+            v = w1[(size_t)o * 2 * C + c];
+        else
+            v = w1[(size_t)(o - EC) * 2 * C + C + c] - w1[(size_t)(o - EC) * 2 * C + c];
+        wcat[(size_t)o * C + c] = v;
+    }
+    wcatT[(size_t)c * 128 + o] = v;
+}
+
+// One wave = one 32-row tile of points x all NO (<= 32 NT) output columns.
+// MFMA operand maps (32x32x2): A lane (i, h) = A[row i][k = 2 s + h];  B lane (n, h) = B[k = 2 s + h][col n];
+// C/D lane (n, h), register r = D[row mfma32_row(r, h)][col n].
+template <int NT>
+__global__ __launch_bounds__(256) void rowgemm_kernel(const float *__restrict__ A0, int K0,
+                                                      const float *__restrict__ A1, int K1,
+                                                      const float *__restrict__ W, int NO,
+                                                      float *__restrict__ Y0, int NO0, float *__restrict__ Y1,
+                                                      int P)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, i32 = lane & 31;
+    const int p0 = (blockIdx.x * 4 + wave) * 32;
+    if (p0 >= P) return;
+    const int K = K0 + K1, steps = (K + 1) >> 1;
+    const int row = p0 + i32;
+    const bool rv = row < P;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
+
+#pragma unroll 2
+    for (int s = 0; s < steps; ++s) {
+        const int kk = 2 * s + h;
+        float a = 0.0f;
+        if (rv && kk < K) a = (kk < K0) ? A0[(size_t)row * K0 + kk] : A1[(size_t)row * K1 + (kk - K0)];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = nt * 32 + i32;
+            const float b = (kk < K && n < NO) ? W[(size_t)kk * NO + n] : 0.0f;
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[nt], 0, 0, 0);
+        }
+    }
+    const int NO1 = NO - NO0;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = nt * 32 + i32;
+        if (n < NO) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int pr = p0 + mfma32_row(r, h);
+                if (pr < P) {
+                    if (n < NO0)
+                        Y0[(size_t)pr * NO0 + n] = acc[nt][r];
+                    else
+                        Y1[(size_t)pr * NO1 + (n - NO0)] = acc[nt][r];
+                }
+            }
+        }
+    }
+}
+
+constexpr int WGRAD_CHUNK = 256;  // points per wave
+
+// partial[chunk][m][n] = sum_p A(p, m) X[p][n]: contraction over the points (MFMA K dimension).
+template <int MT, int NT>
+__global__ __launch_bounds__(64) void wgrad_kernel(const float *__restrict__ A0, int M0,
+                                                   const float *__restrict__ A1, int M1,
+                                                   const float *__restrict__ X, int C, int P,
+                                                   float *__restrict__ partial)
+{
+    const int lane = threadIdx.x, h = lane >> 5, i32 = lane & 31;
+    const int pbeg = blockIdx.x * WGRAD_CHUNK;
+    const int pend = pbeg + WGRAD_CHUNK < P ? pbeg + WGRAD_CHUNK : P;
+    const int M = M0 + M1;
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+
+    for (int p = pbeg; p < pend; p += 2) {
+        const int pp = p + h;
+        const bool pv = pp < pend;
+        float a[MT], b[NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = mt * 32 + i32;
+            a[mt] = (pv && m < M) ? (m < M0 ? A0[(size_t)pp * M0 + m] : A1[(size_t)pp * M1 + (m - M0)]) : 0.0f;
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = nt * 32 + i32;
+            b[nt] = (pv && n < C) ? X[(size_t)pp * C + n] : 0.0f;
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = nt * 32 + i32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mt * 32 + mfma32_row(r, h);
+                if (m < M && n < C) partial[((size_t)blockIdx.x * M + m) * C + n] = acc[mt][nt][r];
+            }
+        }
+}
+
+__global__ void finish_dw1_kernel(const float *__restrict__ partial, int nchunk, int C, float *__restrict__ gw1)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= EC * 2 * C) return;
+    const int o = t / (2 * C), c = t % (2 * C);
+    const size_t stride = (size_t)128 * C;
+    float ga = 0.0f, gd = 0.0f;  // G[o][c'] (neighbour part), G[64 + o][c'] (centre part)
+    const int cc = c < C ? c : c - C;
+    for (int ch = 0; ch < nchunk; ++ch) {
+        if (c < C) ga += partial[ch * stride + (size_t)o * C + cc];
+        gd += partial[ch * stride + (size_t)(EC + o) * C + cc];
+    }
+    gw1[t] = c < C ? ga - gd : gd;
+}
+
+__global__ void sum_partials_kernel(const float *__restrict__ partial, int nchunk, int n, float *__restrict__ out)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    float s = 0.0f;
+    for (int ch = 0; ch < nchunk; ++ch) s += partial[(size_t)ch * n + t];
+    out[t] = s;
+}
+
+// ---------------------------------------------------------------------------------------------
+void launch_prep_wcat(const float *w1, int C, int Ke, float *wcatT, float *wcat, hipStream_t st)
+{
+    hipLaunchKernelGGL(prep_wcat_kernel, dim3(ceil_div(Ke * 128, 256)), dim3(256), 0, st, w1, C, Ke, wcatT, wcat);
+}
+
+void launch_rowgemm(const float *A0, int K0, const float *A1, int K1, const float *W, int NO, float *Y0, int NO0,
+                    float *Y1, int P, hipStream_t st)
+{
+    const dim3 grid(ceil_div(ceil_div(P, 32), 4)), block(256);
+    const int nt = ceil_div(NO, 32);
+    if (nt <= 1)
+        hipLaunchKernelGGL((rowgemm_kernel<1>), grid, block, 0, st, A0, K0, A1, K1, W, NO, Y0, NO0, Y1, P);
+    else if (nt == 2)
+        hipLaunchKernelGGL((rowgemm_kernel<2>), grid, block, 0, st, A0, K0, A1, K1, W, NO, Y0, NO0, Y1, P);
+    else
+        hipLaunchKernelGGL((rowgemm_kernel<4>), grid, block, 0, st, A0, K0, A1, K1, W, NO, Y0, NO0, Y1, P);
+}
+
+int wgrad_chunks(int P) { return ceil_div(P, WGRAD_CHUNK); }
+
+void launch_wgrad(const float *A0, int M0, const float *A1, int M1, const float *X, int C, int P, float *partial,
+                  hipStream_t st)
+{
+    const dim3 grid(wgrad_chunks(P)), block(64);
+    const int mt = ceil_div(M0 + M1, 32), nt = ceil_div(C, 32);
+#define DG_WG(MT_, NT_) \
+    hipLaunchKernelGGL((wgrad_kernel<MT_, NT_>), grid, block, 0, st, A0, M0, A1, M1, X, C, P, partial)
+    // C <= 64 is enforced by the callers (NT <= 2)
+    if (mt <= 2) {
+        if (nt <= 1) DG_WG(2, 1);
+        else DG_WG(2, 2);
+    } else {
+        if (nt <= 1) DG_WG(4, 1);
+        else DG_WG(4, 2);
+    }
+#undef DG_WG
+}
+
+void launch_finish_dw1(const float *partial, int nchunk, int C, float *gw1, hipStream_t st)
+{
+    hipLaunchKernelGGL(finish_dw1_kernel, dim3(ceil_div(EC * 2 * C, 256)), dim3(256), 0, st, partial, nchunk, C, gw1);
+}
+
+void launch_sum_partials(const float *partial, int nchunk, int n, float *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, partial, nchunk, n, out);
+}
+
+}  // namespace dgcnn

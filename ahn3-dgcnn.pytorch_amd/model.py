@@ -1,0 +1,162 @@
+"""Host-side mirror of the reference's model.py for the EdgeConv path on MI355X.
+
+Same public surface as /root/reference/model.py -- `knn(x, k)` (:25), `get_graph_feature(x, k,
+use_cuda)` (:43), `class DGCNN(nn.Module)` with `__init__(num_classes, num_features, k, dropout,
+emb_dims, cuda)` (:88-91), `forward(x, depth=10)` (:144), attributes k / num_classes / use_cuda /
+num_features (:102-105) and submodule names bn1..bn8, conv1..conv9, dp1 (:107-141), hence the
+same 89 state_dict keys -- but every EdgeConv block runs as hand-written HIP kernels behind the C
+ABI of include/dgcnn_hip.h.  There is no CPU or eager fallback: without the HIP extension and a
+HIP device the compute entry points raise.
+
+Deliberate differences from the reference:
+  D1  get_graph_feature accepts and ignores the stray `dim9=` keyword of model.py:147;
+  D2  DGCNN accepts `ropout=` (train.py:103's typo) as an alias of `dropout=`;
+  D8  the compute device is the HIP device whatever the `cuda` flag says: the flag is kept in
+      the signature, inputs that live on the CPU are copied in and results copied back, so the
+      callers' `data.to(device)` logic (train.py:175, test.py:118) keeps working unchanged;
+  --  neighbour ties are broken by the lower index (the reference's topk order among equal
+      distances is arbitrary), distances follow the fixed fp32 order of oracle/knn_exact.c.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib, ops
+
+NEG_SLOPE = 0.2  # LeakyReLU slope of every stage (model.py:118-139)
+
+
+def _compute_device():
+    if not torch.cuda.is_available():
+        raise _lib.HipExtensionError("no HIP device visible: the MI355X EdgeConv path has no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _to_device(x):
+    """fp32 copy of x on the HIP device (no copy if it is already there)."""
+    dev = x.device if x.is_cuda else _compute_device()
+    return x.to(device=dev, dtype=torch.float32, non_blocking=True)
+
+
+def knn(x, k):
+    """Indices of the k nearest neighbours (in feature space) of every point.
+
+    x: [B, C, N] -> int64 [B, N, k], nearest first, the point itself included (model.py:25-40).
+    The result lives on x's device."""
+    xd = _to_device(x.detach())
+    idx = ops.knn_pm(ops.to_point_major(xd), k)
+    return idx.to(device=x.device, dtype=torch.int64)
+
+
+def get_graph_feature(x, k=20, use_cuda=True, dim9=False, idx=None):
+    """Edge features (x_j - x_i, x_i) of the kNN graph: [B, C, N] -> [B, 2C, N, k], returned, like
+    the reference does (model.py:81), as a permuted view of contiguous [B, N, k, 2C] memory.
+    `use_cuda` and `dim9` are accepted for signature parity and ignored (D1, D8); `idx` (int
+    [B, N, k], local indices) overrides the neighbour search."""
+    B, N = x.size(0), x.size(2)
+    x3 = x.reshape(B, -1, N)
+    xd = _to_device(x3)
+    x_pm = ops.to_point_major_autograd(xd)
+    if idx is None:
+        idx32 = ops.knn_pm(x_pm, k)
+    else:
+        idx32 = idx.to(device=xd.device, dtype=torch.int32)
+    feat = ops.graph_feature_pm(x_pm, idx32)          # [B, N, k, 2C]
+    out = feat.permute(0, 3, 1, 2)
+    return out if out.device == x.device else out.to(x.device)
+
+
+class DGCNN(nn.Module):
+    """Dynamic Graph CNN for point-cloud segmentation; drop-in for the reference class."""
+
+    def __init__(self, num_classes, num_features, k, dropout=0.5, emb_dims=1024, cuda=False, ropout=None):
+        super().__init__()
+        if ropout is not None:  # train.py:103 passes `ropout = dropout` (D2)
+            dropout = ropout
+        self.k = k
+        self.num_classes = num_classes
+        self.use_cuda = cuda
+        self.num_features = num_features
+
+        widths = (64, 64, 64, 64, 64, emb_dims, 512, 256)
+        fan_in = (2 * num_features, 64, 128, 64, 128, 192, 1216, 512)   # 1216 = 1024 + 192, as model.py:134
+        for i, w in enumerate(widths, start=1):
+            setattr(self, "bn%d" % i, (nn.BatchNorm2d if i <= 5 else nn.BatchNorm1d)(w))
+        for i, (cin, w) in enumerate(zip(fan_in, widths), start=1):
+            conv = (nn.Conv2d if i <= 5 else nn.Conv1d)(cin, w, kernel_size=1, bias=False)
+            setattr(self, "conv%d" % i, nn.Sequential(conv, getattr(self, "bn%d" % i),
+                                                      nn.LeakyReLU(negative_slope=NEG_SLOPE)))
+        self.dp1 = nn.Dropout(p=dropout)
+        self.conv9 = nn.Conv1d(256, num_classes, kernel_size=1, bias=False)
+        # the reference never moves the model; here the parameters go to the HIP
+        # device as soon as one exists, whatever `cuda` says (D8)
+        if torch.cuda.is_available():
+            self.to(_compute_device())
+        elif cuda:
+            raise _lib.HipExtensionError("DGCNN(cuda=True) but no HIP device is visible")
+
+    # -- EdgeConv blocks: (first conv, optional second conv) -------------------------------------
+    _BLOCKS = ((1, 2), (3, 4), (5, None))
+
+    def _edge_block(self, x_pm, a, b, idx):
+        conv_a, bn_a = getattr(self, "conv%d" % a)[0], getattr(self, "bn%d" % a)
+        w_b = getattr(self, "conv%d" % b)[0].weight if b is not None else None
+        bn_b = getattr(self, "bn%d" % b) if b is not None else None
+        return ops.edgeconv_pm(x_pm, idx, conv_a.weight, bn_a, w_b, bn_b, training=self.training, slope=NEG_SLOPE)
+
+    def _head_stage(self, z, i):
+        """conv_i (1x1 Conv1d) + bn_i + LeakyReLU on point-major rows z [P, C_in]."""
+        conv = getattr(self, "conv%d" % i)[0]
+        return F.leaky_relu(getattr(self, "bn%d" % i)(F.linear(z, conv.weight.squeeze(-1))), NEG_SLOPE)
+
+    def forward(self, x, depth=10, idx=None, return_idx=False):
+        """x: [B, F, N] (any strides, any device) -> logits [B, num_classes, N]; `depth` < 10 returns
+        the intermediate the reference returns at that depth (model.py:151-189).
+        `idx` (list of three int [B, N, k] tensors) injects the neighbour graphs of the three blocks;
+        `return_idx=True` additionally returns the graphs used (both are test hooks)."""
+        in_dev = x.device
+        xd = _to_device(x)
+        B, _, N = xd.shape
+        feats, used = [], []
+        cur = ops.to_point_major_autograd(xd)                         # [B, N, F]
+        out = None
+        for bi, (a, b) in enumerate(self._BLOCKS):
+            nbr = ops.knn_pm(cur, self.k) if idx is None else idx[bi].to(device=xd.device, dtype=torch.int32)
+            used.append(nbr)
+            cur = self._edge_block(cur, a, b, nbr)                    # [B, N, 64]
+            feats.append(cur)
+            if depth == bi + 1:
+                out = ops.from_point_major_autograd(cur)
+                break
+        if out is None:
+            P = B * N
+            cat = torch.cat(feats, dim=2)                             # [B, N, 192]   (model.py:167)
+            if depth == 4:
+                out = ops.from_point_major_autograd(cat)
+            else:
+                z = self._head_stage(cat.reshape(P, 192), 6)          # [P, emb]      (model.py:172)
+                emb = z.shape[1]
+                if depth == 5:
+                    out = ops.from_point_major_autograd(z.view(B, N, emb))
+                else:
+                    g = z.view(B, N, emb).max(dim=1, keepdim=True)[0]  # [B, 1, emb]  (model.py:175)
+                    if depth == 6:
+                        out = g.transpose(1, 2).contiguous()
+                    else:
+                        z = torch.cat((g.expand(B, N, emb), cat), dim=2)   # (model.py:179-180)
+                        if depth == 7:
+                            out = ops.from_point_major_autograd(z)
+                        else:
+                            z = self._head_stage(z.reshape(P, emb + 192), 7)
+                            if depth == 8:
+                                out = ops.from_point_major_autograd(z.view(B, N, -1))
+                            else:
+                                z = self._head_stage(z, 8)
+                                if depth == 9:
+                                    out = ops.from_point_major_autograd(z.view(B, N, -1))
+                                else:
+                                    z = F.linear(self.dp1(z), self.conv9.weight.squeeze(-1))
+                                    out = ops.from_point_major_autograd(z.view(B, N, -1))
+        if out.device != in_dev:
+            out = out.to(in_dev)
+        return (out, used) if return_idx else out

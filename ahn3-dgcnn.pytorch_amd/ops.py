@@ -4,6 +4,8 @@ with torch and enqueue the HIP kernels of libdgcnn_hip.so on the current stream.
 Internal layout is point-major [B, N, C] fp32 ("pm"); neighbour indices are int32, local to
 the batch element.
 """
+import ctypes
+
 import torch
 
 from . import _lib
@@ -58,3 +60,178 @@ def knn_pm(x_pm, k):
     _lib.check(lib.dgcnn_knn(_lib.ptr(x_pm), B, N, C, k, _lib.ptr(idx), _lib.ptr(ws), ws_bytes,
                              _lib.stream_ptr(x_pm.device)), "dgcnn_knn")
     return idx
+
+
+# ------------------------------------------------------------------------------------------------
+class _GraphFeature(torch.autograd.Function):
+    """Materialised (x_j - x_i, x_i) edge tuples, memory [B, N, k, 2C] (reference model.py:64-81)."""
+
+    @staticmethod
+    def forward(ctx, x_pm, idx):
+        B, N, C = x_pm.shape
+        k = idx.shape[2]
+        out = torch.empty((B, N, k, 2 * C), dtype=torch.float32, device=x_pm.device)
+        lib = _lib.load()
+        _lib.check(lib.dgcnn_graph_feature_fwd(_lib.ptr(x_pm), _lib.ptr(idx), B, N, C, k, _lib.ptr(out),
+                                               _lib.stream_ptr(x_pm.device)), "dgcnn_graph_feature_fwd")
+        ctx.save_for_backward(idx)
+        ctx.shape = (B, N, C, k)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (idx,) = ctx.saved_tensors
+        B, N, C, k = ctx.shape
+        gout = gout.contiguous()
+        gx = torch.zeros((B, N, C), dtype=torch.float32, device=gout.device)
+        lib = _lib.load()
+        _lib.check(lib.dgcnn_graph_feature_bwd(_lib.ptr(gout), _lib.ptr(idx), B, N, C, k, _lib.ptr(gx),
+                                               _lib.stream_ptr(gout.device)), "dgcnn_graph_feature_bwd")
+        return gx, None
+
+
+def graph_feature_pm(x_pm, idx):
+    """x_pm [B, N, C], idx int32 [B, N, k] -> [B, N, k, 2C] (differentiable w.r.t. x_pm)."""
+    x_pm = _f32c(x_pm, "x_pm")
+    _lib.require_device(idx, "idx")
+    if idx.dtype != torch.int32:
+        idx = idx.to(torch.int32)
+    return _GraphFeature.apply(x_pm, idx.contiguous())
+
+
+# ------------------------------------------------------------------------------------------------
+def _bn_struct(weight, bias, rmean, rvar):
+    s = _lib.BnParams()
+    s.weight, s.bias = weight.data_ptr(), bias.data_ptr()
+    s.running_mean = rmean.data_ptr() if rmean is not None else None
+    s.running_var = rvar.data_ptr() if rvar is not None else None
+    return s
+
+
+def _make_desc(B, N, C, k, training, eps, momentum, slope, w1, g1, b1, rm1, rv1, w2, g2, b2, rm2, rv2):
+    d = _lib.EdgeConvDesc()
+    d.B, d.N, d.C, d.k = B, N, C, k
+    d.n_stage = 2 if w2 is not None else 1
+    d.training = 1 if training else 0
+    d.eps, d.momentum, d.slope = eps, momentum, slope
+    d.w1 = w1.data_ptr()
+    d.bn1 = _bn_struct(g1, b1, rm1, rv1)
+    if w2 is not None:
+        d.w2 = w2.data_ptr()
+        d.bn2 = _bn_struct(g2, b2, rm2, rv2)
+    return d
+
+
+class _EdgeConv(torch.autograd.Function):
+    """One EdgeConv block (reference model.py:147-150 / 154-157 / 161-163) through the C ABI."""
+
+    @staticmethod
+    def forward(ctx, x_pm, idx, w1, g1, b1, w2, g2, b2, rm1, rv1, rm2, rv2, training, eps, momentum, slope):
+        B, N, C = x_pm.shape
+        k = idx.shape[2]
+        lib = _lib.load()
+        dev = x_pm.device
+        w1c = w1.detach().reshape(64, 2 * C).contiguous()
+        w2c = w2.detach().reshape(64, 64).contiguous() if w2 is not None else None
+        tens = [t.detach().contiguous() if t is not None else None for t in (g1, b1, g2, b2)]
+        g1c, b1c, g2c, b2c = tens
+        d = _make_desc(B, N, C, k, training, eps, momentum, slope, w1c, g1c, b1c, rm1, rv1, w2c, g2c, b2c, rm2, rv2)
+        y = torch.empty((B, N, 64), dtype=torch.float32, device=dev)
+        saved = torch.empty((lib.dgcnn_edgeconv_saved_bytes(d),), dtype=torch.uint8, device=dev)
+        ws_bytes = lib.dgcnn_edgeconv_fwd_workspace_bytes(d)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        _lib.check(lib.dgcnn_edgeconv_fwd(d, _lib.ptr(x_pm), _lib.ptr(idx), _lib.ptr(y), _lib.ptr(saved), _lib.ptr(ws),
+                                          ws_bytes, _lib.stream_ptr(dev)), "dgcnn_edgeconv_fwd")
+        ctx.save_for_backward(x_pm, idx, y, saved, w1c, g1c, b1c, w2c, g2c, b2c, rm1, rv1, rm2, rv2)
+        ctx.cfg = (training, eps, momentum, slope, tuple(w1.shape), tuple(w2.shape) if w2 is not None else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x_pm, idx, y, saved, w1c, g1c, b1c, w2c, g2c, b2c, rm1, rv1, rm2, rv2 = ctx.saved_tensors
+        training, eps, momentum, slope, w1_shape, w2_shape = ctx.cfg
+        B, N, C = x_pm.shape
+        k = idx.shape[2]
+        lib = _lib.load()
+        dev = x_pm.device
+        gy = gy.contiguous()
+        # training=… only selects the BatchNorm backward form; running statistics are not touched here
+        d = _make_desc(B, N, C, k, training, eps, momentum, slope, w1c, g1c, b1c, rm1, rv1, w2c, g2c, b2c, rm2, rv2)
+        g = _lib.EdgeConvGrads()
+        need_x = ctx.needs_input_grad[0]
+        gx = torch.empty_like(x_pm) if need_x else None
+        gw1 = torch.empty_like(w1c)
+        gg1, gb1 = torch.empty_like(g1c), torch.empty_like(b1c)
+        g.gx = gx.data_ptr() if need_x else None
+        g.gw1, g.gbn1_w, g.gbn1_b = gw1.data_ptr(), gg1.data_ptr(), gb1.data_ptr()
+        gw2 = gg2 = gb2 = None
+        if w2c is not None:
+            gw2, gg2, gb2 = torch.empty_like(w2c), torch.empty_like(g2c), torch.empty_like(b2c)
+            g.gw2, g.gbn2_w, g.gbn2_b = gw2.data_ptr(), gg2.data_ptr(), gb2.data_ptr()
+        ws_bytes = lib.dgcnn_edgeconv_bwd_workspace_bytes(d)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        _lib.check(lib.dgcnn_edgeconv_bwd(d, _lib.ptr(x_pm), _lib.ptr(idx), _lib.ptr(y), _lib.ptr(gy), _lib.ptr(saved),
+                                          ctypes.byref(g), _lib.ptr(ws), ws_bytes, _lib.stream_ptr(dev)),
+                   "dgcnn_edgeconv_bwd")
+        return (gx, None, gw1.reshape(w1_shape), gg1, gb1,
+                gw2.reshape(w2_shape) if gw2 is not None else None, gg2, gb2,
+                None, None, None, None, None, None, None, None)
+
+
+def edgeconv_pm(x_pm, idx, w1, bn1, w2=None, bn2=None, training=False, slope=0.2):
+    """EdgeConv block on point-major features.
+
+    x_pm [B, N, C] fp32, idx int32 [B, N, k]; w1 = Conv2d(2C, 64, 1).weight; bn1 / bn2 = the
+    BatchNorm2d modules (weight, bias, running_mean, running_var, eps, momentum are read; the
+    running statistics are updated in place when training).  Returns y [B, N, 64]."""
+    x_pm = _f32c(x_pm, "x_pm")
+    _lib.require_device(idx, "idx")
+    if idx.dtype != torch.int32:
+        idx = idx.to(torch.int32)
+    idx = idx.contiguous()
+
+    def unpack(bn):
+        if bn is None:
+            return None, None, None, None
+        return bn.weight, bn.bias, bn.running_mean, bn.running_var
+
+    g1, b1, rm1, rv1 = unpack(bn1)
+    g2, b2, rm2, rv2 = unpack(bn2)
+    use_batch_stats = training or rm1 is None
+    momentum = bn1.momentum if bn1.momentum is not None else 0.1
+    y = _EdgeConv.apply(x_pm, idx, w1, g1, b1, w2, g2, b2, rm1, rv1, rm2, rv2, bool(use_batch_stats),
+                        float(bn1.eps), float(momentum), float(slope))
+    if training:
+        for bn in (bn1, bn2):
+            if bn is not None and bn.num_batches_tracked is not None:
+                bn.num_batches_tracked += 1
+    return y
+
+
+# ------------------------------------------------------------------------------------------------
+class _ToPointMajor(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return to_point_major(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return from_point_major(g)
+
+
+class _FromPointMajor(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_pm):
+        return from_point_major(x_pm)
+
+    @staticmethod
+    def backward(ctx, g):
+        return to_point_major(g)
+
+
+def to_point_major_autograd(x):
+    return _ToPointMajor.apply(x) if x.requires_grad else to_point_major(x)
+
+
+def from_point_major_autograd(x_pm):
+    return _FromPointMajor.apply(x_pm) if x_pm.requires_grad else from_point_major(x_pm)

@@ -57,6 +57,75 @@ size_t dgcnn_knn_workspace_bytes(int B, int C, int N, int k);
 int dgcnn_knn(const float *x, int B, int N, int C, int k, int32_t *idx,
               void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- materialised edge features (public get_graph_feature API only) ------------------
+ * Replaces the gather / repeat / sub / cat of get_graph_feature (model.py:64-81):
+ *   out[b][n][j][0..C)  = x[b][idx[b][n][j]][:] - x[b][n][:]
+ *   out[b][n][j][C..2C) = x[b][n][:]
+ * out is [B][N][k][2C] contiguous -- exactly the memory the reference returns through a
+ * permuted [B][2C][N][k] view.  The EdgeConv kernels never materialise this tensor.
+ * The backward adds into gx (caller zero-fills): centre term by a local sum over k,
+ * neighbour term by a scatter-add (autograd's IndexBackward0 of model.py:74). */
+int dgcnn_graph_feature_fwd(const float *x, const int32_t *idx, int B, int N, int C, int k,
+                            float *out, void *stream);
+int dgcnn_graph_feature_bwd(const float *gout, const int32_t *idx, int B, int N, int C, int k,
+                            float *gx, void *stream);
+
+/* ---- EdgeConv block ---------------------------------------------------------------------
+ * One call = one EdgeConv block of DGCNN.forward, i.e. (model.py:147-150 / 154-157 / 161-163)
+ *     e = get_graph_feature(x);  e = convA(e);  [e = convB(e);]  y = e.max(dim=-1)[0]
+ * with convX = Sequential(Conv2d(c_in, 64, 1, bias=False), BatchNorm2d(64), LeakyReLU(slope))
+ * (model.py:116-130).  The kNN indices are an input (dgcnn_knn), so that the graph can be
+ * shared, cached or injected by tests.
+ *
+ * x   : point-major [B][N][C]            idx : [B][N][k] int32
+ * y   : point-major [B][N][64]
+ * saved : opaque buffer of dgcnn_edgeconv_saved_bytes() that the forward fills and the
+ *         backward reads (per-point projections, selected pre-activation extremes, BatchNorm
+ *         batch statistics).
+ * BatchNorm semantics are PyTorch's: training = biased batch variance for normalisation,
+ * running_var updated with the unbiased one, running = (1 - momentum) * running + momentum *
+ * batch; eval = running statistics.  num_batches_tracked is the caller's business. */
+typedef struct dgcnn_bn_params {
+    const float *weight;  /* gamma [64] */
+    const float *bias;    /* beta  [64] */
+    float *running_mean;  /* [64]; read when training == 0, updated when training == 1 */
+    float *running_var;   /* [64] */
+} dgcnn_bn_params;
+
+typedef struct dgcnn_edgeconv_desc {
+    int32_t B, N, C, k;
+    int32_t n_stage;   /* 1: conv(2C->64)+BN+LReLU;  2: followed by conv(64->64)+BN+LReLU */
+    int32_t training;  /* 1: batch statistics (+ running update);  0: running statistics */
+    float eps, momentum, slope;
+    const float *w1;   /* [64][2C]  = Conv2d(2C, 64, 1).weight */
+    dgcnn_bn_params bn1;
+    const float *w2;   /* [64][64]  = Conv2d(64, 64, 1).weight, or NULL when n_stage == 1 */
+    dgcnn_bn_params bn2;
+} dgcnn_edgeconv_desc;
+
+typedef struct dgcnn_edgeconv_grads {
+    float *gx;      /* [B][N][C] point-major, or NULL (block 1: the network input needs no grad) */
+    float *gw1;     /* [64][2C] */
+    float *gbn1_w;  /* [64] */
+    float *gbn1_b;  /* [64] */
+    float *gw2;     /* [64][64] or NULL */
+    float *gbn2_w;  /* [64] or NULL */
+    float *gbn2_b;  /* [64] or NULL */
+} dgcnn_edgeconv_grads;
+
+size_t dgcnn_edgeconv_saved_bytes(const dgcnn_edgeconv_desc *d);
+size_t dgcnn_edgeconv_fwd_workspace_bytes(const dgcnn_edgeconv_desc *d);
+size_t dgcnn_edgeconv_bwd_workspace_bytes(const dgcnn_edgeconv_desc *d);
+
+int dgcnn_edgeconv_fwd(const dgcnn_edgeconv_desc *d, const float *x, const int32_t *idx, float *y,
+                       void *saved, void *workspace, size_t workspace_bytes, void *stream);
+
+/* gy: dL/dy point-major [B][N][64].  Every gradient is OVERWRITTEN (not accumulated). */
+int dgcnn_edgeconv_bwd(const dgcnn_edgeconv_desc *d, const float *x, const int32_t *idx,
+                       const float *y, const float *gy, const void *saved,
+                       const dgcnn_edgeconv_grads *g, void *workspace, size_t workspace_bytes,
+                       void *stream);
+
 #ifdef __cplusplus
 }
 #endif
