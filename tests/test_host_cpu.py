@@ -1,0 +1,103 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every declared symbol (no
+compute calls without a GPU), the module mirrors the reference's surface, and the compute entry
+points refuse to run without the HIP device instead of falling back."""
+import ctypes
+import json
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def test_library_exports_every_declared_symbol():
+    from ahn3_dgcnn_pytorch_amd import _lib
+    header = open(os.path.join(ROOT, "include", "dgcnn_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(dgcnn_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.dgcnn_abi_version() >= 1
+
+
+def test_ctypes_struct_layout_matches_c():
+    from ahn3_dgcnn_pytorch_amd import _lib
+    # natural alignment on x86-64: 6 int32 + 3 float = 36 -> pad to 40, then pointers
+    assert ctypes.sizeof(_lib.BnParams) == 32
+    assert _lib.EdgeConvDesc.w1.offset == 40
+    assert ctypes.sizeof(_lib.EdgeConvDesc) == 40 + 8 + 32 + 8 + 32
+    assert ctypes.sizeof(_lib.EdgeConvGrads) == 56
+
+
+def test_workspace_queries_need_no_gpu():
+    from ahn3_dgcnn_pytorch_amd import _lib
+    lib = _lib.load()
+    assert lib.dgcnn_knn_workspace_bytes(8, 64, 7000, 30) >= 8 * 7040 * 64 * 4
+    d = _lib.EdgeConvDesc()
+    d.B, d.N, d.C, d.k, d.n_stage, d.training = 8, 7000, 64, 30, 2, 1
+    assert lib.dgcnn_edgeconv_saved_bytes(d) >= 3 * 56000 * 64 * 4
+    assert lib.dgcnn_edgeconv_bwd_workspace_bytes(d) >= 56000 * 30 * 64 * 4
+
+
+def test_argument_errors_are_reported_not_crashed():
+    from ahn3_dgcnn_pytorch_amd import _lib
+    lib = _lib.load()
+    rc = lib.dgcnn_knn(None, 1, 10, 4, 3, None, None, 0, None)
+    assert rc != 0 and b"null" in lib.dgcnn_last_error()
+    buf = ctypes.create_string_buffer(64)
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    rc = lib.dgcnn_knn(p, 1, 10, 4, 11, p, p, 1 << 20, None)
+    assert rc != 0 and b"out of range" in lib.dgcnn_last_error()
+
+
+def test_module_surface_matches_reference():
+    from ahn3_dgcnn_pytorch_amd import DGCNN
+    if torch.cuda.is_available():
+        pytest.skip("CPU-only check")
+    with open(os.path.join(GOLD, "state_dict.json")) as f:
+        spec = json.load(f)
+    m = DGCNN(5, 4, 30, dropout=0.5, emb_dims=1024, cuda=False)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(spec["entries"].keys()) and len(sd) == 89
+    for k, (shape, dtype) in spec["entries"].items():
+        assert list(sd[k].shape) == shape and str(sd[k].dtype) == "torch." + dtype
+    assert sum(p.numel() for p in m.parameters()) == spec["n_parameters"]
+    assert len(list(m.parameters())) == spec["n_parameter_tensors"]
+    for attr, val in spec["attributes"].items():
+        assert getattr(m, attr) == val
+    assert [n for n, _ in m.named_children()] == ["bn%d" % i for i in range(1, 9)] + \
+        ["conv%d" % i for i in range(1, 9)] + ["dp1", "conv9"]
+    assert DGCNN(5, 4, 30, ropout=0.25).dp1.p == 0.25  # train.py:103's keyword
+
+
+def test_no_cpu_fallback():
+    from ahn3_dgcnn_pytorch_amd import DGCNN, _lib, get_graph_feature, knn, ops
+    if torch.cuda.is_available():
+        pytest.skip("CPU-only check")
+    x = torch.rand(1, 4, 64)
+    with pytest.raises(_lib.HipExtensionError):
+        DGCNN(5, 4, 8)(x)
+    with pytest.raises(_lib.HipExtensionError):
+        knn(x, 4)
+    with pytest.raises(_lib.HipExtensionError):
+        get_graph_feature(x, k=4)
+    with pytest.raises(_lib.HipExtensionError):
+        ops.knn_pm(x.transpose(1, 2).contiguous(), 4)
+    with pytest.raises(_lib.HipExtensionError):
+        DGCNN(5, 4, 8, cuda=True)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "ahn3-dgcnn.pytorch_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, fn)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), fn
+                assert "torch_ref" not in src and "knn_exact(" not in src, fn

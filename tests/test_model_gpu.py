@@ -1,0 +1,171 @@
+"""GPU parity of the DGCNN host mirror (EdgeConv blocks on HIP kernels, head on torch) against the
+golden vectors captured from the reference (tests/golden/, made by gen_golden.py).
+
+Tolerances: logits / activations 1e-4 absolute (BASELINE.json north_star); gradients 1e-4 of each
+tensor's largest entry.  The 1e-4 gates are asserted with the reference's neighbour graphs injected
+(SURVEY.md 8c gate 3); the end-to-end runs (own kNN) are checked for graph agreement as well."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from param_fill import cotangent, fill_module
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def gold(name):
+    return np.load(os.path.join(GOLD, name))
+
+
+def small_model(train, device):
+    from ahn3_dgcnn_pytorch_amd import DGCNN
+    g = gold("model_small.npz")
+    m = DGCNN(int(g["num_classes"]), 4, int(g["k"]), dropout=0.0, emb_dims=1024, cuda=True)
+    fill_module(m)
+    m.train(train)
+    return g, m, torch.from_numpy(g["x"]).to(device)
+
+
+def idx_list(g, prefix, device):
+    return [torch.from_numpy(g["%s_idx%d" % (prefix, i)].astype(np.int32)).to(device) for i in (1, 2, 3)]
+
+
+@pytest.mark.parametrize("depth", range(1, 11))
+def test_eval_all_depths_with_reference_graph(depth, device):
+    g, m, x = small_model(False, device)
+    with torch.no_grad():
+        y = m(x, depth=depth, idx=idx_list(g, "eval", device))
+    assert y.is_contiguous()
+    step = int(g["eval_d%d_step" % depth])
+    want = g["eval_d%d" % depth]
+    got = y.cpu().numpy()[:, ::step]
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-4)
+
+
+def test_eval_end_to_end_own_knn(device):
+    g, m, x = small_model(False, device)
+    with torch.no_grad():
+        y, used = m(x, return_idx=True)
+    # block 1 searches in the raw coordinates: identical lists; blocks 2/3 search in computed
+    # features (1e-6 apart between implementations): identical neighbour SETS on this tie-free input
+    np.testing.assert_array_equal(used[0].cpu().numpy(), g["eval_idx1"])
+    for i in (1, 2):
+        a = np.sort(used[i].cpu().numpy(), axis=-1)
+        b = np.sort(g["eval_idx%d" % (i + 1)].astype(np.int32), axis=-1)
+        assert (a == b).all(-1).mean() == 1.0
+    np.testing.assert_allclose(y.cpu().numpy(), g["eval_d10"], rtol=0, atol=1e-4)
+
+
+def test_train_step_matches_reference(device):
+    g, m, x = small_model(True, device)
+    idx = idx_list(g, "train", device)
+    y = m(x, idx=idx)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), g["train_d10"], rtol=0, atol=1e-4)
+    R = cotangent(tuple(y.shape)).to(device)
+    (y * R).sum().backward()
+    sd = m.state_dict()
+    for key in g.files:
+        if key.startswith("train_after/"):
+            np.testing.assert_allclose(sd[key.split("/", 1)[1]].cpu().numpy(), g[key], rtol=1e-5, atol=1e-6)
+    for i in range(1, 9):
+        assert int(sd["bn%d.num_batches_tracked" % i]) == 1
+    params = dict(m.named_parameters())
+    checked = 0
+    for key in g.files:
+        if key.startswith("grad/"):
+            want, got = g[key], params[key[5:]].grad.cpu().numpy()
+        elif key.startswith("grad_sample/"):
+            want, got = g[key], params[key[12:]].grad.cpu().numpy().reshape(-1)[::97]
+        else:
+            continue
+        scale = float(np.abs(want).max())
+        err = float(np.abs(got - want).max())
+        # 2e-5 floor: a few head gradients vanish analytically (|g| ~ 1e-6 while their siblings are O(1..100))
+        assert err <= 1e-4 * scale + 2e-5, "%s: err %.3g scale %.3g" % (key, err, scale)
+        checked += 1
+    assert checked == 25
+
+
+@pytest.mark.parametrize("depth", [1, 2, 3])
+def test_train_block_outputs(depth, device):
+    g, m, x = small_model(True, device)
+    y = m(x, depth=depth, idx=idx_list(g, "train", device))
+    np.testing.assert_allclose(y.detach().cpu().numpy(), g["train_d%d" % depth], rtol=0, atol=1e-4)
+
+
+def test_readme_config_logits(device):
+    # BASELINE.json configs[0]: DGCNN(5, 4, 30, emb_dims=1024, cuda=False) on a [1, 4, 1000] tensor
+    from ahn3_dgcnn_pytorch_amd import DGCNN
+    g = gold("model_readme.npz")
+    m = DGCNN(5, 4, 30, dropout=0.5, emb_dims=1024, cuda=False)
+    fill_module(m)
+    m.eval()
+    x_cpu = torch.from_numpy(g["x"])
+    idx = [torch.from_numpy(g["idx%d" % i].astype(np.int32)).to(device) for i in (1, 2, 3)]
+    with torch.no_grad():
+        y = m(x_cpu, idx=idx)
+        y_own, used = m(x_cpu, return_idx=True)
+    assert y.device.type == "cpu" and y.shape == (1, 5, 1000)  # CPU in -> CPU out, like the reference
+    np.testing.assert_allclose(y.numpy(), g["logits"], rtol=0, atol=1e-4)
+    # end to end with the HIP kNN: report/limit the fraction of points off by more than 1e-4
+    # (agreement with PyTorch-CPU's index lists is a RATE: fp32 near-ties order differently, SURVEY.md 8c gate 2)
+    rows_equal = (used[0].cpu().numpy() == g["idx1"]).all(-1)
+    assert rows_equal.mean() >= 0.99
+    frac = float((np.abs(y_own.numpy() - g["logits"]).max(axis=1) > 1e-4).mean())
+    assert frac <= 0.01, "fraction of points whose logits differ by > 1e-4 end-to-end: %.4f" % frac
+    # strided callers: train.py:176 / test.py:119 hand a permuted view of [B, N, F]
+    xs = x_cpu.permute(0, 2, 1).contiguous().permute(0, 2, 1)
+    assert xs.stride() == (4000, 1, 4)
+    with torch.no_grad():
+        ys = m(xs.to(device), idx=idx)
+    assert ys.is_cuda
+    np.testing.assert_allclose(ys.cpu().numpy(), g["logits"], rtol=0, atol=1e-4)
+
+
+def test_predict_style_input_and_ropout_alias(device):
+    # test.py:304-306 builds X[N, F, 1] -> permute(2, 1, 0): fp32 [1, F, N] with strides (1, 1, F)
+    from ahn3_dgcnn_pytorch_amd import DGCNN
+    m = DGCNN(5, 4, 20, ropout=0.3, emb_dims=1024, cuda=True)
+    assert abs(m.dp1.p - 0.3) < 1e-12
+    fill_module(m)
+    m.eval()
+    X = torch.rand(500, 4, 1)
+    v = X.permute(2, 1, 0).float()
+    with torch.no_grad():
+        a = m(v.to(device))
+        b = m(v.contiguous().to(device))
+    assert torch.equal(a, b)
+
+
+def test_state_dict_roundtrip_with_reference_keys(device, tmp_path):
+    from ahn3_dgcnn_pytorch_amd import DGCNN
+    with open(os.path.join(GOLD, "state_dict.json")) as f:
+        spec = json.load(f)
+    m = DGCNN(5, 4, 30, cuda=True)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(spec["entries"].keys())
+    for k, (shape, dtype) in spec["entries"].items():
+        assert list(sd[k].shape) == shape and str(sd[k].dtype) == "torch." + dtype
+    for k in spec["aliased_bn_keys"]:  # bnN.* and convN.1.* are the same storage (model.py:107-139)
+        assert sd[k].data_ptr() == sd["conv" + k[2] + ".1" + k[3:]].data_ptr()
+    # checkpoint interchange in the reference's format (train.py:301-312)
+    path = str(tmp_path / "model.t7")
+    torch.save({"epoch": 3, "model_state_dict": {k: v.cpu() for k, v in sd.items()}}, path)
+    m2 = DGCNN(5, 4, 30, cuda=True)
+    m2.load_state_dict(torch.load(path)["model_state_dict"])
+    for k in sd:
+        assert torch.equal(m2.state_dict()[k], sd[k])
+    assert m.k == 30 and m.num_classes == 5 and m.num_features == 4 and m.use_cuda is True
+
+
+def test_determinism_forward(device):
+    g, m, x = small_model(False, device)
+    with torch.no_grad():
+        a = m(x)
+        b = m(x)
+    assert torch.equal(a, b)
