@@ -8,58 +8,77 @@
 // Arithmetic (must stay bit-identical to oracle/knn_exact.c):
 //   dot  = fp32 FMA chain over channels c = 0..C-1 from +0  -> v_mfma_f32_32x32x2_f32,
 //          which on gfx950 is bitwise a k-ordered fmaf chain (one rounding per product)
-//   xx_l = the same chain with both operands x_l             (knn_prep_kernel)
+//   xx_l = the same chain with both operands x_l             (knn_norm_kernel)
 //   t    = fma(2, dot, -xx_l);  pd = (t - xx_i) + 0
 //   order: pd descending, candidate index ascending among equal pd
 //
-// Structure: one workgroup = 4 waves = 128 query rows of one batch element; every wave
-// owns 32 query rows (the MFMA M dimension) for the whole kernel: its A operand (the
-// query features) stays in registers, its top-k state is wave-private, so the only
-// workgroup-level synchronisation is the hand-over of the shared candidate tile (one
-// barrier per 64 candidates, register-prefetched double buffer).
+// Structure ("wave-autonomous"): one workgroup = ONE wave = 32 query rows (the MFMA M
+// dimension) of one batch element, for the whole candidate stream.  Its A operand (the query
+// features) stays in registers; the candidates arrive as B operands straight from global
+// memory / L2 into registers, one 32-candidate tile ahead, from a copy of x that knn_tile_kernel
+// lays out in MFMA operand order (so every load is a fully coalesced 1 KB wave access; all
+// waves of a batch element walk the same 1.8 MB through one XCD's L2).  No LDS staging and no
+// barrier exists: LDS holds only the top-k state, 16 KB per wave, so 8 waves share a CU and
+// one wave's selection work overlaps the other waves' MFMAs.
 //
 // Streaming top-k per query row: a buffer of CAP 64-bit keys in LDS
 //   key = orderable(pd) << 32 | ~candidate      (u64 max == pd desc, index asc)
 // holds the current best k plus pending candidates; a candidate is appended only if it
-// beats tau = the k-th best pd at the last compaction (ballot + popcount give the slot,
-// no atomics).  When a row's buffer would overflow, the wave sorts it (bitonic network
-// across the 64 lanes via shuffles), keeps the best k and tightens tau.
+// beats tau = the k-th best pd at the last compaction (ballot + popcount give the slot, the
+// per-row counts live in registers: no atomics, no LDS read on the append path).  When a
+// row's buffer would overflow, the wave sorts it (bitonic network across the 64 lanes; DPP
+// row operations for exchange distances 1, 2, 4, 8), keeps the best k and tightens tau.
 #include "common.h"
 
 namespace dgcnn {
 
 constexpr int KNN_ROWPAD = 128;  // query/candidate rows are padded to a multiple of this
-constexpr int KNN_BN = 64;       // candidates per staged tile
 
 typedef unsigned long long u64;
 
 // ------------------------------------------------------------------------------------
-// prep: point-major [B][N][C] -> de-interleaved, padded rows + squared norms.
-//   xs[b][n][h * CH + s] = x[b][n][2 s + h]   (h = channel parity, CH = CP / 2)
-// so that lane-half h of the 32x32x2 MFMA (which supplies k = 2 s + h at step s) reads a
-// contiguous run.  Rows n >= N are zero with xx = +inf, which makes pd = -inf: a padded
-// candidate can never enter a list.
-__global__ void knn_prep_kernel(const float *__restrict__ x, int N, int C, int Npad, int CP,
-                                float *__restrict__ xs, float *__restrict__ xx)
+// prep 1: squared norms with the oracle's chain order; +inf for padding rows, which makes
+// pd = -inf: a padded candidate can never enter a list.
+__global__ void knn_norm_kernel(const float *__restrict__ x, int N, int C, int Npad, float *__restrict__ xx)
 {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     const int b = blockIdx.y;
     if (n >= Npad) return;
-    const int CH = CP >> 1;
-    float *dst = xs + ((size_t)b * Npad + n) * CP;
+    float acc = __builtin_inff();
     if (n < N) {
         const float *src = x + ((size_t)b * N + n) * C;
-        float acc = 0.0f;
-        for (int c = 0; c < CP; ++c) {
-            const float v = (c < C) ? src[c] : 0.0f;
-            acc = __builtin_fmaf(v, v, acc);
-            dst[(c & 1) * CH + (c >> 1)] = v;
-        }
-        xx[(size_t)b * Npad + n] = acc;
-    } else {
-        for (int c = 0; c < CP; ++c) dst[c] = 0.0f;
-        xx[(size_t)b * Npad + n] = __builtin_inff();
+        acc = 0.0f;
+        for (int c = 0; c < C; ++c) acc = __builtin_fmaf(src[c], src[c], acc);
     }
+    xx[(size_t)b * Npad + n] = acc;
+}
+
+// prep 2: point-major [B][N][C] -> MFMA operand order.  For the 32x32x2 MFMA, lane (j, h) of a
+// 32-point tile supplies channel k = 2 s + h of point j at step s.  Per batch element:
+//   xt[tile][g][lane][e] = x[tile * 32 + (lane & 31)][2 * (g * VEC + e) + (lane >> 5)]
+// (VEC = min(4, CP / 2) floats per lane and load; zero beyond N or C).  One thread per vector.
+template <int VEC>
+__global__ void knn_tile_kernel(const float *__restrict__ x, int N, int C, int Npad, int CP,
+                                float *__restrict__ xt)
+{
+    const int G = (CP / 2) / VEC;
+    const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // vector index within the batch element
+    const int b = blockIdx.y;
+    const size_t nvec = (size_t)(Npad / 32) * G * 64;
+    if (v >= nvec) return;
+    const int lane = (int)(v & 63);
+    const int g = (int)((v >> 6) % G);
+    const int tile = (int)((v >> 6) / G);
+    const int n = tile * 32 + (lane & 31), h = lane >> 5;
+    float out[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        const int c = 2 * (g * VEC + e) + h;
+        out[e] = (n < N && c < C) ? x[((size_t)b * N + n) * C + c] : 0.0f;
+    }
+    float *dst = xt + (size_t)b * Npad * CP + v * VEC;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) dst[e] = out[e];
 }
 
 // ------------------------------------------------------------------------------------
@@ -77,37 +96,63 @@ __device__ __forceinline__ u64 make_key(float pd, int cand)
     return ((u64)pd_to_ordered(pd) << 32) | (u64)(0xffffffffu - (unsigned)cand);
 }
 
-// bitonic sort, descending, of CAP = 64 * EPL keys held EPL per lane (element e of lane l
-// has position e * 64 + l).
-template <int EPL>
-__device__ __forceinline__ void bitonic_desc(u64 (&key)[EPL], int lane)
+// value of lane (l ^ J): DPP row operations inside a row of 16 lanes, LDS-crossbar permute beyond
+template <int J>
+__device__ __forceinline__ unsigned xchg32(unsigned v)
 {
+    if constexpr (J == 1)
+        return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
+    else if constexpr (J == 2)
+        return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);  // quad_perm [2,3,0,1]
+    else if constexpr (J == 4) {
+        // banks 0,2 (lanes 0-3, 8-11) take lane + 4 (row_shl:4); banks 1,3 take lane - 4 (row_shr:4)
+        const int t = __builtin_amdgcn_update_dpp(0, (int)v, 0x104, 0xF, 0x5, false);
+        return (unsigned)__builtin_amdgcn_update_dpp(t, (int)v, 0x114, 0xF, 0xA, false);
+    } else if constexpr (J == 8)
+        return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, false);  // row_ror:8
+    else
+        return (unsigned)__shfl_xor((int)v, J);
+}
+template <int J>
+__device__ __forceinline__ u64 xchg64(u64 v)
+{
+    const unsigned lo = xchg32<J>((unsigned)v), hi = xchg32<J>((unsigned)(v >> 32));
+    return ((u64)hi << 32) | lo;
+}
+
+template <int EPL, int K2, int J>
+__device__ __forceinline__ void bitonic_step(u64 (&key)[EPL], int lane)
+{
+    if constexpr (J >= 64) {
+        // EPL == 2, J == 64, K2 == 128: in-lane exchange, descending everywhere
+        const u64 a = key[0], b = key[EPL - 1];
+        key[0] = a > b ? a : b;
+        key[EPL - 1] = a > b ? b : a;
+    } else {
 #pragma unroll
-    for (int k2 = 2; k2 <= 64 * EPL; k2 <<= 1) {
-#pragma unroll
-        for (int j = k2 >> 1; j > 0; j >>= 1) {
-            if (j >= 64) {
-                // EPL == 2, j == 64, k2 == 128: in-lane exchange, descending everywhere
-                const u64 a = key[0], b = key[EPL - 1];
-                key[0] = a > b ? a : b;
-                key[EPL - 1] = a > b ? b : a;
-            } else {
-#pragma unroll
-                for (int e = 0; e < EPL; ++e) {
-                    const int g = e * 64 + lane;
-                    const u64 o = __shfl_xor(key[e], j);
-                    const bool keep_max = ((g & j) == 0) == ((g & k2) == 0);
-                    const u64 mx = key[e] > o ? key[e] : o;
-                    const u64 mn = key[e] > o ? o : key[e];
-                    key[e] = keep_max ? mx : mn;
-                }
-            }
+        for (int e = 0; e < EPL; ++e) {
+            const int g = e * 64 + lane;
+            const u64 o = xchg64<J>(key[e]);
+            const bool keep_max = ((g & J) == 0) == ((g & K2) == 0);
+            key[e] = ((key[e] > o) == keep_max) ? key[e] : o;  // keys are unique
         }
     }
 }
+template <int EPL, int K2, int J>
+__device__ __forceinline__ void bitonic_merge(u64 (&key)[EPL], int lane)
+{
+    bitonic_step<EPL, K2, J>(key, lane);
+    if constexpr (J > 1) bitonic_merge<EPL, K2, J / 2>(key, lane);
+}
+template <int EPL, int K2>
+__device__ __forceinline__ void bitonic_sort(u64 (&key)[EPL], int lane)
+{
+    if constexpr (K2 > 2) bitonic_sort<EPL, K2 / 2>(key, lane);
+    bitonic_merge<EPL, K2, K2 / 2>(key, lane);
+}
 
-// Sort one row's buffer (c valid keys), keep the best k.  Wave-wide call.  Returns the new
-// tau (pd of the k-th best, or -inf while fewer than k candidates are known).
+// Sort one row's buffer (c valid keys) descending, keep the best k.  Wave-wide call.  Returns the
+// new tau (pd of the k-th best, or -inf while fewer than k candidates are known).
 template <int CAP>
 __device__ __forceinline__ float compact_row(u64 *kr, int c, int k, int lane)
 {
@@ -118,7 +163,7 @@ __device__ __forceinline__ float compact_row(u64 *kr, int c, int k, int lane)
         const int g = e * 64 + lane;
         key[e] = (g < c) ? kr[g] : 0ull;
     }
-    bitonic_desc<EPL>(key, lane);
+    bitonic_sort<EPL, CAP>(key, lane);
 #pragma unroll
     for (int e = 0; e < EPL; ++e) kr[e * 64 + lane] = key[e];
     float t = -__builtin_inff();
@@ -130,167 +175,145 @@ __device__ __forceinline__ float compact_row(u64 *kr, int c, int k, int lane)
     return t;
 }
 
-// WAVES waves per workgroup, 32 query rows each (4 for CAP = 64; 2 for CAP = 128 so that
-// the key buffers still fit the 160 KB LDS).
-template <int CP, int CAP, int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void knn_kernel(const float *__restrict__ xs,
-                                                          const float *__restrict__ xx, int N,
-                                                          int Npad, int k,
-                                                          int32_t *__restrict__ idx)
+template <int CP, int CAP>
+__global__ __launch_bounds__(64, 2) void knn_kernel(const float *__restrict__ xt, const float *__restrict__ xx,
+                                                    int B, int N, int Npad, int k, int32_t *__restrict__ idx)
 {
-    constexpr int KNN_WAVES = WAVES, KNN_THREADS = WAVES * 64, KNN_BM = WAVES * 32;
     constexpr int CH = CP / 2;
-    constexpr int STR = CH + (CH >= 4 ? 4 : 0);  // +16 B: conflict-free ds_read_b128 rows
-    constexpr int F4_TILE = KNN_BN * CP / 4;
-    constexpr int F4_THREAD = (F4_TILE + KNN_THREADS - 1) / KNN_THREADS;
+    constexpr int VEC = CH >= 4 ? 4 : CH;
+    constexpr int G = CH / VEC;
+    typedef float vecf __attribute__((ext_vector_type(VEC)));
 
-    __shared__ __attribute__((aligned(16))) float tile[2][2][KNN_BN][STR];
-    __shared__ u64 keys[KNN_WAVES][32][CAP];
-    __shared__ int cnts[KNN_WAVES][32];
-    __shared__ float taus[KNN_WAVES][32];
+    __shared__ u64 keys[32][CAP];
+    __shared__ int cnts[32];
+    __shared__ float taus[32];
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int h = lane >> 5, j32 = lane & 31;
-    const int b = blockIdx.y;
-    const int q0 = blockIdx.x * KNN_BM + wave * 32;
-    const float *xsb = xs + (size_t)b * Npad * CP;
+    const int lane = threadIdx.x, h = lane >> 5, j32 = lane & 31;
+    // blocks are dealt round-robin over the XCDs: with B a multiple of 8 all waves of batch
+    // element b run on one XCD and share its L2 copy of xt[b] (speed only)
+    const int b = blockIdx.x % B, rb = blockIdx.x / B;
+    const int q0 = rb * 32;
+    const float *xtb = xt + (size_t)b * Npad * CP;
     const float *xxb = xx + (size_t)b * Npad;
 
-    if (lane < 32) {
-        cnts[wave][lane] = 0;
-        taus[wave][lane] = -__builtin_inff();
-    }
-
-    // A operand: lane (row j32, half h) supplies A[row][k = 2 s + h] at step s.
-    float a[CH];
-    {
-        const float *src = xsb + (size_t)(q0 + j32) * CP + h * CH;
+    auto load_operand = [&](int tile, float(&dst)[CH]) {
+        const vecf *p = reinterpret_cast<const vecf *>(xtb + (size_t)tile * 32 * CP) + lane;
 #pragma unroll
-        for (int s = 0; s < CH; ++s) a[s] = src[s];
-    }
+        for (int g = 0; g < G; ++g) {
+            const vecf v = p[g * 64];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) dst[g * VEC + e] = v[e];
+        }
+    };
+
+    float a[CH];
+    load_operand(rb, a);  // the query rows are tile rb of the same array
     float xxq[16], taur[16];
+    int cntr[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         xxq[r] = xxb[q0 + mfma32_row(r, h)];
         taur[r] = -__builtin_inff();
+        cntr[r] = 0;
     }
 
-    float4 stage[F4_THREAD];
-    auto load_tile = [&](int t) {
-        const float4 *g = reinterpret_cast<const float4 *>(xsb + (size_t)t * KNN_BN * CP);
+    // one 32 x 32 tile of distances -> selection
+    auto process = [&](const float(&bop)[CH], float xxc, int cand) {
+        f32x16 acc;
 #pragma unroll
-        for (int i = 0; i < F4_THREAD; ++i) {
-            const int q = threadIdx.x + i * KNN_THREADS;
-            if (q < F4_TILE) stage[i] = g[q];
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < CH; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bop[s], acc, 0, 0, 0);
+
+        // pass 1: append where the row's buffer has room, flag the rows that would overflow
+        unsigned retry = 0u;  // bit (r + 16 * half)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float pd = __builtin_fmaf(2.0f, acc[r], -xxc) - xxq[r];
+            const bool pass = pd > taur[r];
+            const u64 m = __ballot(pass);
+            if (m) {
+                const int row = mfma32_row(r, h);
+                const unsigned mh = h ? (unsigned)(m >> 32) : (unsigned)m;
+                const int tot = __popc(mh), c = cntr[r];
+                const bool ovf = c + tot > CAP;
+                const u64 mo = __ballot(ovf);
+                if (!ovf) {
+                    if (pass) {
+                        float pdk = pd;
+                        asm volatile("" : "+v"(pdk));  // keep the key arithmetic on this (rare) path
+                        keys[row][c + __popc(mh & ((1u << j32) - 1u))] = make_key(pdk, cand);
+                    }
+                    cntr[r] = c + tot;
+                }
+                if (mo) {
+                    if (ovf && j32 == 0) cnts[row] = c;
+                    if ((unsigned)mo) retry |= 1u << r;
+                    if (mo >> 32) retry |= 1u << (r + 16);
+                }
+            }
         }
-    };
-    auto store_tile = [&](int buf) {
+        if (retry) {
+            // compact every flagged row (runtime loop: one copy of the sort), then offer the
+            // candidates of those rows again: count <= k and at most 32 newcomers always fit
+            unsigned rr = retry;
+            while (rr) {
+                const int bit = __ffs(rr) - 1;
+                rr &= rr - 1;
+                const int row = mfma32_row(bit & 15, bit >> 4);
+                const int c = cnts[row];
+                const float tnew = compact_row<CAP>(&keys[row][0], c, k, lane);
+                if (lane == 0) {
+                    cnts[row] = c < k ? c : k;
+                    taus[row] = tnew;
+                }
+            }
 #pragma unroll
-        for (int i = 0; i < F4_THREAD; ++i) {
-            const int q = threadIdx.x + i * KNN_THREADS;
-            if (q < F4_TILE) {
-                const int row = q / (CP / 4), w = q % (CP / 4);
-                if constexpr (CH >= 4) {
-                    const int plane = w / (CH / 4), s4 = w % (CH / 4);
-                    *reinterpret_cast<float4 *>(&tile[buf][plane][row][s4 * 4]) = stage[i];
-                } else {  // CP == 4: one float4 = [plane0: s0 s1 | plane1: s0 s1]
-                    tile[buf][0][row][0] = stage[i].x;
-                    tile[buf][0][row][1] = stage[i].y;
-                    tile[buf][1][row][0] = stage[i].z;
-                    tile[buf][1][row][1] = stage[i].w;
+            for (int r = 0; r < 16; ++r) {
+                if (retry & (0x10001u << r)) {
+                    const int row = mfma32_row(r, h);
+                    const bool mine = (retry >> (r + 16 * h)) & 1u;
+                    if (mine) {
+                        taur[r] = taus[row];
+                        cntr[r] = cnts[row];
+                    }
+                    const float pd = __builtin_fmaf(2.0f, acc[r], -xxc) - xxq[r];
+                    const bool pass = mine && (pd > taur[r]);
+                    const u64 m = __ballot(pass);
+                    const unsigned mh = h ? (unsigned)(m >> 32) : (unsigned)m;
+                    if (pass) keys[row][cntr[r] + __popc(mh & ((1u << j32) - 1u))] = make_key(pd, cand);
+                    cntr[r] += __popc(mh);
                 }
             }
         }
     };
 
-    const int ntiles = Npad / KNN_BN;
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-
-    for (int t = 0; t < ntiles; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < ntiles) load_tile(t + 1);
-
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const int cand = t * KNN_BN + nt * 32 + j32;
-            const float xxc = xxb[cand];
-            const float *brow = &tile[buf][h][nt * 32 + j32][0];
-            f32x16 acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-#pragma unroll
-            for (int s = 0; s < CH; ++s)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], brow[s], acc, 0, 0, 0);
-
-            // ---- selection epilogue -------------------------------------------------
-            // todo bit (r + 16 * half): that (register, half) = query row still has to
-            // offer its candidate.  Rows whose buffer would overflow are compacted and
-            // retried; everything in this loop is wave-uniform control flow.
-            unsigned todo = 0xffffffffu;
-            while (todo) {
-                unsigned retry = 0u;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    if (todo & (0x10001u << r)) {
-                        const float tt = __builtin_fmaf(2.0f, acc[r], -xxc);
-                        const float pd = tt - xxq[r];
-                        const bool mine = (todo >> (r + 16 * h)) & 1u;
-                        const bool pass = mine && (pd > taur[r]);
-                        const u64 m = __ballot(pass);
-                        if (m) {
-                            const int row = mfma32_row(r, h);
-                            const unsigned mh = h ? (unsigned)(m >> 32) : (unsigned)m;
-                            const int tot = __popc(mh);
-                            const int c = cnts[wave][row];
-                            const bool ovf = pass && (c + tot > CAP);
-                            const u64 mo = __ballot(ovf);
-                            const bool my_ovf = h ? (mo >> 32) != 0 : ((unsigned)mo) != 0;
-                            if ((unsigned)mo) retry |= 1u << r;
-                            if (mo >> 32) retry |= 1u << (r + 16);
-                            if (pass && !my_ovf) {
-                                const int slot = c + __popc(mh & ((1u << j32) - 1u));
-                                keys[wave][row][slot] = make_key(pd, cand);
-                            }
-                            if (!my_ovf && j32 == 0 && tot) cnts[wave][row] = c + tot;
-                        }
-                    }
-                }
-                if (retry) {
-                    // compact every flagged row (runtime loop: one copy of the sort)
-                    unsigned rr = retry;
-                    while (rr) {
-                        const int bit = __ffs(rr) - 1;
-                        rr &= rr - 1;
-                        const int row = mfma32_row(bit & 15, bit >> 4);
-                        const int c = cnts[wave][row];
-                        const float tnew = compact_row<CAP>(&keys[wave][row][0], c, k, lane);
-                        if (lane == 0) {
-                            cnts[wave][row] = c < k ? c : k;
-                            taus[wave][row] = tnew;
-                        }
-                    }
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        if (retry & (0x10001u << r)) taur[r] = taus[wave][mfma32_row(r, h)];
-                }
-                todo = retry;
-            }
+    const int ntiles = Npad / 32;  // even (Npad is a multiple of 128)
+    float b0[CH], b1[CH];
+    load_operand(0, b0);
+    float x0 = xxb[j32], x1;
+    for (int t = 0; t < ntiles; t += 2) {
+        load_operand(t + 1, b1);
+        x1 = xxb[(t + 1) * 32 + j32];
+        process(b0, x0, t * 32 + j32);
+        if (t + 2 < ntiles) {
+            load_operand(t + 2, b0);
+            x0 = xxb[(t + 2) * 32 + j32];
         }
-
-        if (t + 1 < ntiles) store_tile(buf ^ 1);
-        __syncthreads();
+        process(b1, x1, (t + 1) * 32 + j32);
     }
 
     // ---- final sort and write-out ------------------------------------------------------
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        if (j32 == 0) cnts[mfma32_row(r, h)] = cntr[r];
     for (int row = 0; row < 32; ++row) {
-        const int c = cnts[wave][row];
-        (void)compact_row<CAP>(&keys[wave][row][0], c, k, lane);
+        const int c = cnts[row];
+        (void)compact_row<CAP>(&keys[row][0], c, k, lane);
         const int q = q0 + row;
         if (q < N) {
             for (int g = lane; g < k; g += 64) {
-                const unsigned lo = (unsigned)keys[wave][row][g];
+                const unsigned lo = (unsigned)keys[row][g];
                 idx[((size_t)b * N + q) * k + g] = (int32_t)(0xffffffffu - lo);
             }
         }
@@ -307,13 +330,14 @@ static int knn_cp(int C)
 static int knn_npad(int N) { return ceil_div(N, KNN_ROWPAD) * KNN_ROWPAD; }
 
 template <int CP>
-static void knn_launch_cp(int cap, int B, hipStream_t st, const float *xs, const float *xx,
-                          int N, int Npad, int k, int32_t *idx)
+static void knn_launch_cp(int cap, int B, hipStream_t st, const float *xt, const float *xx, int N, int Npad, int k,
+                          int32_t *idx)
 {
+    const dim3 grid(B * (Npad / 32)), block(64);
     if (cap == 64)
-        hipLaunchKernelGGL((knn_kernel<CP, 64, 4>), dim3(Npad / 128, B), dim3(256), 0, st, xs, xx, N, Npad, k, idx);
+        hipLaunchKernelGGL((knn_kernel<CP, 64>), grid, block, 0, st, xt, xx, B, N, Npad, k, idx);
     else
-        hipLaunchKernelGGL((knn_kernel<CP, 128, 2>), dim3(Npad / 64, B), dim3(128), 0, st, xs, xx, N, Npad, k, idx);
+        hipLaunchKernelGGL((knn_kernel<CP, 128>), grid, block, 0, st, xt, xx, B, N, Npad, k, idx);
 }
 
 }  // namespace dgcnn
@@ -341,20 +365,26 @@ extern "C" int dgcnn_knn(const float *x, int B, int N, int C, int k, int32_t *id
     DG_REQUIRE(workspace_bytes >= dgcnn_knn_workspace_bytes(B, C, N, k), "dgcnn_knn: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     const int Npad = knn_npad(N), CP = knn_cp(C);
-    float *xs = (float *)workspace;
+    float *xt = (float *)workspace;
     float *xx = (float *)((char *)workspace + align_up((size_t)B * Npad * CP * sizeof(float), 256));
 
-    hipLaunchKernelGGL(knn_prep_kernel, dim3(ceil_div(Npad, 256), B), dim3(256), 0, st, x, N, C, Npad, CP, xs, xx);
-    DG_CHECK_LAUNCH("knn_prep_kernel");
+    hipLaunchKernelGGL(knn_norm_kernel, dim3(ceil_div(Npad, 256), B), dim3(256), 0, st, x, N, C, Npad, xx);
+    const size_t nvec = (size_t)Npad * CP / (CP >= 8 ? 4 : 2);
+    const dim3 tgrid((unsigned)((nvec + 255) / 256), B);
+    if (CP >= 8)
+        hipLaunchKernelGGL((knn_tile_kernel<4>), tgrid, dim3(256), 0, st, x, N, C, Npad, CP, xt);
+    else
+        hipLaunchKernelGGL((knn_tile_kernel<2>), tgrid, dim3(256), 0, st, x, N, C, Npad, CP, xt);
+    DG_CHECK_LAUNCH("knn prep kernels");
 
     const int cap = (k <= 32) ? 64 : 128;
     switch (CP) {
-        case 4: knn_launch_cp<4>(cap, B, st, xs, xx, N, Npad, k, idx); break;
-        case 8: knn_launch_cp<8>(cap, B, st, xs, xx, N, Npad, k, idx); break;
-        case 16: knn_launch_cp<16>(cap, B, st, xs, xx, N, Npad, k, idx); break;
-        case 32: knn_launch_cp<32>(cap, B, st, xs, xx, N, Npad, k, idx); break;
-        case 64: knn_launch_cp<64>(cap, B, st, xs, xx, N, Npad, k, idx); break;
-        case 128: knn_launch_cp<128>(cap, B, st, xs, xx, N, Npad, k, idx); break;
+        case 4: knn_launch_cp<4>(cap, B, st, xt, xx, N, Npad, k, idx); break;
+        case 8: knn_launch_cp<8>(cap, B, st, xt, xx, N, Npad, k, idx); break;
+        case 16: knn_launch_cp<16>(cap, B, st, xt, xx, N, Npad, k, idx); break;
+        case 32: knn_launch_cp<32>(cap, B, st, xt, xx, N, Npad, k, idx); break;
+        case 64: knn_launch_cp<64>(cap, B, st, xt, xx, N, Npad, k, idx); break;
+        case 128: knn_launch_cp<128>(cap, B, st, xt, xx, N, Npad, k, idx); break;
         default: DG_FAIL("dgcnn_knn: unsupported padded channel count %d", CP);
     }
     DG_CHECK_LAUNCH("knn_kernel");
