@@ -21,6 +21,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-ffp-contract=off",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-Wall", "-Wno-unused-function"]
+FLAGS += os.environ.get("DGCNN_EXTRA_HIPCC_FLAGS", "").split()  # experiments only (e.g. ablation -D switches)
 
 
 def sources():

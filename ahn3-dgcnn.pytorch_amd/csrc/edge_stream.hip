@@ -81,18 +81,42 @@ __global__ __launch_bounds__(256) void edge_reduce_kernel(const float *__restric
     block_reduce_store<2>(acc, partial);
 }
 
-// one workgroup of 64 threads: thread = channel.  Partials are summed in index order -> deterministic.
-__global__ void bn_finalize_kernel(const double *__restrict__ partial, int nparts, double count, int training,
-                                   dgcnn_bn_params bn, float eps, float momentum, float *__restrict__ stats)
+// Sum of fp64 partial records [nparts][2][64] for channel c.  1024 threads = 16 waves: wave w
+// adds records w, w + 16, ... in order, then the 16 wave sums are added in wave order: a fixed
+// association, so the result is deterministic (and identical for every launch geometry).
+constexpr int FIN_WAVES = 16;
+__device__ __forceinline__ void reduce_records(const double *__restrict__ partial, int nparts, double &s0,
+                                               double &s1)
 {
+    __shared__ double red[FIN_WAVES][2][64];
+    const int c = threadIdx.x & 63, w = threadIdx.x >> 6;
+    double a0 = 0.0, a1 = 0.0;
+    for (int g = w; g < nparts; g += FIN_WAVES) {
+        a0 += partial[((size_t)g * 2 + 0) * 64 + c];
+        a1 += partial[((size_t)g * 2 + 1) * 64 + c];
+    }
+    red[w][0][c] = a0;
+    red[w][1][c] = a1;
+    __syncthreads();
+    s0 = 0.0;
+    s1 = 0.0;
+    for (int i = 0; i < FIN_WAVES; ++i) {
+        s0 += red[i][0][c];
+        s1 += red[i][1][c];
+    }
+}
+
+// one workgroup of 1024 threads; the first wave finishes channel c = lane.
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const double *__restrict__ partial, int nparts,
+                                                           double count, int training, dgcnn_bn_params bn, float eps,
+                                                           float momentum, float *__restrict__ stats)
+{
+    double s = 0.0, ss = 0.0;
+    if (training) reduce_records(partial, nparts, s, ss);
+    if (threadIdx.x >= 64) return;
     const int c = threadIdx.x;
     float mean, var;
     if (training) {
-        double s = 0.0, ss = 0.0;
-        for (int g = 0; g < nparts; ++g) {
-            s += partial[((size_t)g * 2 + 0) * 64 + c];
-            ss += partial[((size_t)g * 2 + 1) * 64 + c];
-        }
         const double m = s / count;
         double v = ss / count - m * m;  // biased variance, as BatchNorm normalises with
         if (v < 0.0) v = 0.0;
@@ -158,15 +182,14 @@ __global__ __launch_bounds__(256) void bwd_point_kernel(const float *__restrict_
 // gbn_b = sum dv, gbn_w = sum dv * uhat;  cc[0..63] = gbn_b / count, cc[64..127] = gbn_w / count
 // (the two mean terms of the BatchNorm input gradient; zero in eval mode, where the statistics
 // are constants).
-__global__ void bn_bwd_finalize_kernel(const double *__restrict__ partial, int nparts, double count, int training,
-                                       float *__restrict__ gbn_w, float *__restrict__ gbn_b, float *__restrict__ cc)
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const double *__restrict__ partial, int nparts,
+                                                               double count, int training, float *__restrict__ gbn_w,
+                                                               float *__restrict__ gbn_b, float *__restrict__ cc)
 {
+    double sb, sg;
+    reduce_records(partial, nparts, sb, sg);
+    if (threadIdx.x >= 64) return;
     const int c = threadIdx.x;
-    double sb = 0.0, sg = 0.0;
-    for (int g = 0; g < nparts; ++g) {
-        sb += partial[((size_t)g * 2 + 0) * 64 + c];
-        sg += partial[((size_t)g * 2 + 1) * 64 + c];
-    }
     gbn_b[c] = (float)sb;
     gbn_w[c] = (float)sg;
     cc[c] = training ? (float)(sb / count) : 0.0f;
@@ -296,7 +319,7 @@ void launch_edge_reduce(const float *TP, const float *TQ, const int32_t *idx, in
 void launch_bn_finalize(const double *partial, int nparts, double count, int training, const dgcnn_bn_params &bn,
                         float eps, float momentum, float *stats, hipStream_t st)
 {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, st, partial, nparts, count, training, bn, eps,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(1024), 0, st, partial, nparts, count, training, bn, eps,
                        momentum, stats);
 }
 
@@ -309,7 +332,7 @@ void launch_edge_out(const float *usel, const float *stats, float slope, int P, 
 void launch_bn_bwd_finalize(const double *partial, int nparts, double count, int training, float *gbn_w, float *gbn_b,
                             float *cc, hipStream_t st)
 {
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(64), 0, st, partial, nparts, count, training, gbn_w,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(1024), 0, st, partial, nparts, count, training, gbn_w,
                        gbn_b, cc);
 }
 

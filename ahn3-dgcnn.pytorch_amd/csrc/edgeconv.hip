@@ -73,7 +73,7 @@ static FwdWs fwd_ws(const dgcnn_edgeconv_desc *d, void *p)
 }
 
 struct BwdWs {
-    float *wcatT, *wcat, *cc1, *cc2, *dR, *dD, *wg_partial, *dv1, *dw2_partial;
+    float *wcatT, *wcat, *cc1, *cc2, *dR, *dD, *wg_partial, *wg_sum, *dv1, *dw2_partial;
     double *partial, *bn1_partial;
     size_t bytes;
 };
@@ -90,6 +90,7 @@ static BwdWs bwd_ws(const dgcnn_edgeconv_desc *d, void *p)
     w.dR = c.take<float>(P * EC);
     w.dD = c.take<float>(P * EC);
     w.wg_partial = c.take<float>((size_t)wgrad_chunks((int)P) * 128 * d->C);
+    w.wg_sum = c.take<float>((size_t)128 * d->C);
     if (d->n_stage == 2) {
         w.dv1 = c.take<float>(P * d->k * EC);
         w.dw2_partial = c.take<float>((size_t)PART_MAX * EC * EC);
@@ -211,7 +212,7 @@ extern "C" int dgcnn_edgeconv_bwd(const dgcnn_edgeconv_desc *d, const float *x, 
         launch_edge_bwd(s.TP, s.TQ, idx, N, k, P, s.stats1, w.cc1, d->slope, d->training, gy, y, w.dv1, w.dR, w.dD, st);
     }
     launch_wgrad(w.dR, EC, w.dD, EC, x, C, P, w.wg_partial, st);
-    launch_finish_dw1(w.wg_partial, wgrad_chunks(P), C, g->gw1, st);
+    launch_finish_dw1(w.wg_partial, wgrad_chunks(P), C, w.wg_sum, g->gw1, st);
     if (g->gx) launch_rowgemm(w.dR, EC, w.dD, EC, w.wcat, C, g->gx, C, nullptr, P, st);
     DG_CHECK_LAUNCH("dgcnn_edgeconv_bwd");
     return 0;

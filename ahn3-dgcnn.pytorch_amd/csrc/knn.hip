@@ -21,6 +21,18 @@
 // barrier exists: LDS holds only the top-k state, 16 KB per wave, so 8 waves share a CU and
 // one wave's selection work overlaps the other waves' MFMAs.
 //
+// Threshold pre-pass (knn_bound_kernel): before the exact stream, a cheap pass computes for every
+// query row a LOWER bound tau0 of its k-th best pd, so that the exact stream starts with a tight
+// threshold instead of -inf (about 40 appends and no compaction per row instead of about 250
+// appends and 8 sorts).  Lane (j, h) keeps the running maximum of its candidate class (candidates
+// with index = j mod 32, even / odd tiles: 64 classes per row); the k-th largest of the 64 class
+// maxima is attained by k distinct candidates, hence is a valid lower bound.  For C >= 16 the
+// pre-pass runs on fp16 MFMA (v_mfma_f32_32x32x16_f16, 1/16 of the fp32 cost) over mean-centred
+// features and tau0 is loosened by an a-priori error bound; for small C it is the exact fp32
+// arithmetic loosened by one ulp.  The bound only affects speed: if a row ends the exact stream
+// with fewer than k candidates (tau0 was not a lower bound), the wave repeats its stream from
+// tau = -inf, so the result never depends on the pre-pass.
+//
 // Streaming top-k per query row: a buffer of CAP 64-bit keys in LDS
 //   key = orderable(pd) << 32 | ~candidate      (u64 max == pd desc, index asc)
 // holds the current best k plus pending candidates; a candidate is appended only if it
@@ -28,9 +40,26 @@
 // per-row counts live in registers: no atomics, no LDS read on the append path).  When a
 // row's buffer would overflow, the wave sorts it (bitonic network across the 64 lanes; DPP
 // row operations for exchange distances 1, 2, 4, 8), keeps the best k and tightens tau.
+#include <stdlib.h>
+
+#include <type_traits>
+#include <utility>
+
 #include "common.h"
 
 namespace dgcnn {
+
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>)
+{
+    (f(std::integral_constant<int, I>{}), ...);
+}
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>), fully unrolled with constant indices
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
 
 constexpr int KNN_ROWPAD = 128;  // query/candidate rows are padded to a multiple of this
 
@@ -110,8 +139,15 @@ __device__ __forceinline__ unsigned xchg32(unsigned v)
         return (unsigned)__builtin_amdgcn_update_dpp(t, (int)v, 0x114, 0xF, 0xA, false);
     } else if constexpr (J == 8)
         return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, false);  // row_ror:8
-    else
-        return (unsigned)__shfl_xor((int)v, J);
+    else if constexpr (J == 16) {
+        // v_permlane16_swap(v, v): first = (r0 r0 r2 r2), second = (r1 r1 r3 r3) in rows of 16 lanes
+        const auto p = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+        return (threadIdx.x & 16) ? p[0] : p[1];
+    } else {
+        // v_permlane32_swap(v, v): first = (lo lo), second = (hi hi) in halves of 32 lanes
+        const auto p = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+        return (threadIdx.x & 32) ? p[0] : p[1];
+    }
 }
 template <int J>
 __device__ __forceinline__ u64 xchg64(u64 v)
@@ -175,9 +211,259 @@ __device__ __forceinline__ float compact_row(u64 *kr, int c, int k, int lane)
     return t;
 }
 
+// ------------------------------------------------------------------------------------
+// pre-pass helpers
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+// approximate centre of one batch element (any vector works: distances are translation invariant;
+// centring only tightens the fp16 error bound): mean of the first <= 256 points.
+__global__ __launch_bounds__(256) void knn_center_kernel(const float *__restrict__ x, int N, int C,
+                                                         float *__restrict__ mu)
+{
+    __shared__ float red[256];
+    const int b = blockIdx.x;
+    const int G = 256 / C > 0 ? 256 / C : 1;  // C <= 128
+    const int c = threadIdx.x % C, g = threadIdx.x / C;
+    const int n1 = N < 256 ? N : 256;
+    float s = 0.0f;
+    if (g < G)
+        for (int n = g; n < n1; n += G) s += x[((size_t)b * N + n) * C + c];
+    red[threadIdx.x] = (g < G) ? s : 0.0f;
+    __syncthreads();
+    if (threadIdx.x < C) {
+        float t = 0.0f;
+        for (int i = 0; i < G; ++i) t += red[i * C + threadIdx.x];
+        mu[(size_t)b * C + threadIdx.x] = t / (float)n1;
+    }
+}
+
+// fp16 operand tiles of the centred features for v_mfma_f32_32x32x16_f16: lane (j, h) of a 32-point
+// tile supplies, at k-step ks, channels 16 ks + 8 h + e (e = 0..7) of point j:
+//   xh[tile][ks][lane][e] = half(x[tile * 32 + (lane & 31)][16 ks + 8 (lane >> 5) + e] - mu)
+// plus the centred squared norms xxc (fp32; +inf for padding rows) and, per batch element, the
+// largest centred and raw norm (bmax[b][0..1], as uint bits of non-negative floats).
+__global__ void knn_half_kernel(const float *__restrict__ x, const float *__restrict__ mu, int N, int C, int Npad,
+                                int CP, half8 *__restrict__ xh)
+{
+    const int KS = CP / 16;
+    const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    const size_t nvec = (size_t)(Npad / 32) * KS * 64;
+    if (v >= nvec) return;
+    const int lane = (int)(v & 63);
+    const int ks = (int)((v >> 6) % KS);
+    const int tile = (int)((v >> 6) / KS);
+    const int n = tile * 32 + (lane & 31), h = lane >> 5;
+    half8 out;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = 16 * ks + 8 * h + e;
+        const float val = (n < N && c < C) ? x[((size_t)b * N + n) * C + c] - mu[(size_t)b * C + c] : 0.0f;
+        out[e] = (_Float16)val;
+    }
+    xh[(size_t)b * (Npad / 32) * KS * 64 + v] = out;
+}
+
+// centred squared norms (any summation order will do: they only feed the pre-pass and its error
+// bound): 16 lanes per point, C <= 128 -> up to two float4 per lane, shuffle reduction.
+__global__ __launch_bounds__(256) void knn_cnorm_kernel(const float *__restrict__ x, const float *__restrict__ mu,
+                                                        int N, int C, int Npad, float *__restrict__ xxc)
+{
+    const int sub = threadIdx.x & 15;
+    const int n = blockIdx.x * 16 + (threadIdx.x >> 4);  // Npad is a multiple of 16
+    const int b = blockIdx.y;
+    float acc = 0.0f;
+    if (n < N) {
+        const float *src = x + ((size_t)b * N + n) * C;
+        const float *m = mu + (size_t)b * C;
+        for (int c = sub; c < C; c += 16) {
+            const float d = src[c] - m[c];
+            acc = __builtin_fmaf(d, d, acc);
+        }
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (n >= N) acc = __builtin_inff();
+    if (sub == 0) xxc[(size_t)b * Npad + n] = acc;
+}
+
+// bmax[b] = (largest centred norm, largest raw norm) of batch element b, as uint bits of non-negative
+// floats; one workgroup per batch element.
+__global__ __launch_bounds__(1024) void knn_bmax_kernel(const float *__restrict__ xxc, const float *__restrict__ xx,
+                                                        int N, int Npad, unsigned *__restrict__ bmax)
+{
+    __shared__ unsigned red[2][16];
+    const int b = blockIdx.x;
+    unsigned mc = 0u, mr = 0u;
+    for (int n = threadIdx.x; n < N; n += 1024) {
+        const unsigned c = __float_as_uint(xxc[(size_t)b * Npad + n]), r = __float_as_uint(xx[(size_t)b * Npad + n]);
+        mc = mc > c ? mc : c;
+        mr = mr > r ? mr : r;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned oc = __shfl_xor(mc, o), orr = __shfl_xor(mr, o);
+        mc = mc > oc ? mc : oc;
+        mr = mr > orr ? mr : orr;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = mc;
+        red[1][threadIdx.x >> 6] = mr;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        unsigned m = 0u;
+        for (int i = 0; i < 16; ++i) m = m > red[threadIdx.x][i] ? m : red[threadIdx.x][i];
+        bmax[2 * b + threadIdx.x] = m;
+    }
+}
+
+__device__ __forceinline__ unsigned f32_to_ordered(float f)
+{
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+template <int K2, int J>
+__device__ __forceinline__ void bitonic32_merge(unsigned &key, int lane)
+{
+    const unsigned o = xchg32<J>(key);
+    const bool keep_max = ((lane & J) == 0) == ((lane & K2) == 0);
+    key = ((key > o) == keep_max) ? key : o;
+    if constexpr (J > 1) bitonic32_merge<K2, J / 2>(key, lane);
+}
+template <int K2>
+__device__ __forceinline__ void bitonic32_sort(unsigned &key, int lane)
+{
+    if constexpr (K2 > 2) bitonic32_sort<K2 / 2>(key, lane);
+    bitonic32_merge<K2, K2 / 2>(key, lane);
+}
+
+// One wave = RT x 32 query rows (RT row tiles share every candidate-operand load: the pre-pass is
+// bound by L2 -> CU traffic, not by arithmetic).  F16 = true: xop are the fp16 centred tiles, xn the
+// centred norms; F16 = false (small C): xop are the fp32 tiles of knn_tile_kernel, xn the raw norms,
+// and the arithmetic is exactly the one of knn_kernel.
+template <int CP, bool F16, int RT>
+__global__ __launch_bounds__(64) void knn_bound_kernel(const void *__restrict__ xop, const float *__restrict__ xn,
+                                                       const float *__restrict__ xx_raw,
+                                                       const unsigned *__restrict__ bmax, int B, int Npad, int k,
+                                                       float *__restrict__ tau0)
+{
+    const int lane = threadIdx.x, h = lane >> 5, j32 = lane & 31;
+    const int b = blockIdx.x % B, rb0 = (blockIdx.x / B) * RT;  // first row tile of this wave
+    const float *xnb = xn + (size_t)b * Npad;
+    const int ntiles = Npad / 32;  // even
+
+    float m0[RT][16], m1[RT][16];  // class maxima of 2 dot - xx_l over even / odd candidate tiles
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m0[rt][r] = m1[rt][r] = -__builtin_inff();
+
+    if constexpr (F16) {
+        constexpr int KS = CP / 16;
+        const half8 *xb = reinterpret_cast<const half8 *>(xop) + (size_t)b * ntiles * KS * 64 + lane;
+        half8 a[RT][KS], b0[KS], b1[KS];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) a[rt][ks] = xb[((size_t)(rb0 + rt) * KS + ks) * 64];
+        auto tile = [&](const half8(&bop)[KS], float xl, float(&m)[RT][16]) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rt][ks], bop[ks], acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) m[rt][r] = fmaxf(m[rt][r], __builtin_fmaf(2.0f, acc[r], -xl));
+            }
+        };
+        for (int t = 0; t < ntiles; t += 2) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                b0[ks] = xb[((size_t)t * KS + ks) * 64];
+                b1[ks] = xb[((size_t)(t + 1) * KS + ks) * 64];
+            }
+            const float x0 = xnb[t * 32 + j32], x1 = xnb[(t + 1) * 32 + j32];
+            tile(b0, x0, m0);
+            tile(b1, x1, m1);
+        }
+    } else {
+        constexpr int CH = CP / 2;
+        constexpr int VEC = CH >= 4 ? 4 : CH;
+        constexpr int G = CH / VEC;
+        typedef float vecf __attribute__((ext_vector_type(VEC)));
+        const vecf *xb = reinterpret_cast<const vecf *>(reinterpret_cast<const float *>(xop) + (size_t)b * Npad * CP) + lane;
+        float a[RT][CH], bop[CH];
+        auto load = [&](int t, float(&dst)[CH]) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const vecf v = xb[((size_t)t * G + g) * 64];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) dst[g * VEC + e] = v[e];
+            }
+        };
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) load(rb0 + rt, a[rt]);
+        for (int t = 0; t < ntiles; ++t) {
+            load(t, bop);
+            const float xl = xnb[t * 32 + j32];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+                for (int s = 0; s < CH; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rt][s], bop[s], acc, 0, 0, 0);
+                if (t & 1) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) m1[rt][r] = fmaxf(m1[rt][r], __builtin_fmaf(2.0f, acc[r], -xl));
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) m0[rt][r] = fmaxf(m0[rt][r], __builtin_fmaf(2.0f, acc[r], -xl));
+                }
+            }
+        }
+    }
+
+    // k-th largest of the 64 class maxima of every row, minus the row's own norm and the error bound
+    const float cmax = __uint_as_float(bmax[2 * b + 0]), rmax = __uint_as_float(bmax[2 * b + 1]);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float other = __uint_as_float(xchg32<32>(__float_as_uint(m1[rt][r])));
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                // row (r, hh): its lanes hold m0 (own half) and the partner half receives that half's m1
+                unsigned key = f32_to_ordered((h == hh) ? m0[rt][r] : other);
+                bitonic32_sort<64>(key, lane);
+                const unsigned kth = __builtin_amdgcn_readlane(key, k - 1);
+                const float vk = __uint_as_float((kth & 0x80000000u) ? (kth & 0x7fffffffu) : ~kth);
+                const int row = (rb0 + rt) * 32 + mfma32_row(r, hh);
+                const float xi = xnb[row], xr = xx_raw[(size_t)b * Npad + row];
+                float t;
+                if constexpr (F16) {
+                    // |pd_fp16 - pd_fp32| <= 2^-9 (1 + 2^-4) sqrt(xxc_i xxc_l) + fp32-level terms
+                    const float eps = 2.1e-3f * __builtin_sqrtf(xi * cmax) + 2.0e-6f * (xr + rmax) + 1e-30f;
+                    t = (vk - xi) - eps;
+                } else {
+                    const float pd = vk - xi;  // same fp32 operations as knn_kernel
+                    t = pd - fmaxf(__builtin_fabsf(pd) * 4.8e-7f, 1e-37f);
+                }
+                if (lane == 0) tau0[(size_t)b * Npad + row] = (t != t) ? -__builtin_inff() : t;  // NaN -> no bound
+            }
+        }
+    }
+}
+
 template <int CP, int CAP>
 __global__ __launch_bounds__(64, 2) void knn_kernel(const float *__restrict__ xt, const float *__restrict__ xx,
-                                                    int B, int N, int Npad, int k, int32_t *__restrict__ idx)
+                                                    const float *__restrict__ tau0, int B, int N, int Npad, int k,
+                                                    int32_t *__restrict__ idx)
 {
     constexpr int CH = CP / 2;
     constexpr int VEC = CH >= 4 ? 4 : CH;
@@ -197,6 +483,9 @@ __global__ __launch_bounds__(64, 2) void knn_kernel(const float *__restrict__ xt
     const float *xxb = xx + (size_t)b * Npad;
 
     auto load_operand = [&](int tile, float(&dst)[CH]) {
+#ifdef KNN_ABLATE_L2  // timing experiment: every operand load hits the same (L1-resident) tile
+        tile = 0;
+#endif
         const vecf *p = reinterpret_cast<const vecf *>(xtb + (size_t)tile * 32 * CP) + lane;
 #pragma unroll
         for (int g = 0; g < G; ++g) {
@@ -209,33 +498,39 @@ __global__ __launch_bounds__(64, 2) void knn_kernel(const float *__restrict__ xt
     float a[CH];
     load_operand(rb, a);  // the query rows are tile rb of the same array
     float xxq[16], taur[16];
-    int cntr[16];
+    unsigned cpk[4] = {0u, 0u, 0u, 0u};  // per-row candidate counts (<= CAP <= 128), one byte per register r
+    auto cnt_get = [&](int r) { return (int)((cpk[r >> 2] >> ((r & 3) * 8)) & 0xffu); };
+    auto cnt_set = [&](int r, int v) {
+        cpk[r >> 2] = (cpk[r >> 2] & ~(0xffu << ((r & 3) * 8))) | ((unsigned)v << ((r & 3) * 8));
+    };
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         xxq[r] = xxb[q0 + mfma32_row(r, h)];
-        taur[r] = -__builtin_inff();
-        cntr[r] = 0;
+        taur[r] = tau0 ? tau0[(size_t)b * Npad + q0 + mfma32_row(r, h)] : -__builtin_inff();
     }
 
-    // one 32 x 32 tile of distances -> selection
-    auto process = [&](const float(&bop)[CH], float xxc, int cand) {
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-#pragma unroll
-        for (int s = 0; s < CH; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bop[s], acc, 0, 0, 0);
-
-        // pass 1: append where the row's buffer has room, flag the rows that would overflow
-        unsigned retry = 0u;  // bit (r + 16 * half)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
+    // Software pipeline: the MFMA chain of the NEXT candidate tile is issued interleaved, in program
+    // order, with the selection epilogue of the CURRENT tile (whose accumulators completed one
+    // step earlier).  A dependent fp32 MFMA occupies the matrix pipe for 64 cycles, so the few
+    // vector/scalar instructions of one register's epilogue between two MFMAs are free, and the
+    // MFMA -> VALU read hazard never stalls.
+    auto fused = [&](auto mf_tag, const float(&bop)[CH], f32x16 &acc_next, const f32x16 &acc, float xxc, int cand) {
+        constexpr bool MF = decltype(mf_tag)::value;
+        unsigned retry = 0u;  // bit (r + 16 * half): row would overflow -> compact, then offer again
+        // pass 1 for accumulator register r: append where the row's buffer has room
+        auto epi = [&](auto rtag) {
+            constexpr int r = decltype(rtag)::value;
+#ifdef KNN_ABLATE_EPILOGUE  // timing experiment: MFMA stream only (results are garbage)
+            asm volatile("" ::"v"(acc[r]));
+            return;
+#endif
             const float pd = __builtin_fmaf(2.0f, acc[r], -xxc) - xxq[r];
             const bool pass = pd > taur[r];
             const u64 m = __ballot(pass);
-            if (m) {
+            if (__builtin_expect(m != 0, 0)) {  // out of line: the common path must not contain taken branches
                 const int row = mfma32_row(r, h);
                 const unsigned mh = h ? (unsigned)(m >> 32) : (unsigned)m;
-                const int tot = __popc(mh), c = cntr[r];
+                const int tot = __popc(mh), c = cnt_get(r);
                 const bool ovf = c + tot > CAP;
                 const u64 mo = __ballot(ovf);
                 if (!ovf) {
@@ -244,7 +539,7 @@ __global__ __launch_bounds__(64, 2) void knn_kernel(const float *__restrict__ xt
                         asm volatile("" : "+v"(pdk));  // keep the key arithmetic on this (rare) path
                         keys[row][c + __popc(mh & ((1u << j32) - 1u))] = make_key(pdk, cand);
                     }
-                    cntr[r] = c + tot;
+                    cpk[r >> 2] += (unsigned)tot << ((r & 3) * 8);
                 }
                 if (mo) {
                     if (ovf && j32 == 0) cnts[row] = c;
@@ -252,7 +547,29 @@ __global__ __launch_bounds__(64, 2) void knn_kernel(const float *__restrict__ xt
                     if (mo >> 32) retry |= 1u << (r + 16);
                 }
             }
+        };
+        if constexpr (MF) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc_next[r] = 0.0f;
         }
+        // 16 epilogue registers spread over the CH MFMAs of the chain
+        constexpr int EPI_PER = CH >= 16 ? 1 : 16 / CH;  // epilogue registers after one MFMA
+        constexpr int MF_PER = CH >= 16 ? CH / 16 : 1;   // MFMAs per epilogue group
+        auto group = [&](auto gtag) {
+            constexpr int g = decltype(gtag)::value;  // 0 .. 16 / EPI_PER - 1
+            if constexpr (MF) {
+#pragma unroll
+                for (int i = 0; i < MF_PER; ++i)
+                    acc_next = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g * MF_PER + i], bop[g * MF_PER + i], acc_next, 0, 0, 0);
+            }
+            if constexpr (EPI_PER == 1) {
+                epi(std::integral_constant<int, g>{});
+            } else {
+                static_for<EPI_PER>([&](auto e) { epi(std::integral_constant<int, g * EPI_PER + decltype(e)::value>{}); });
+            }
+        };
+        static_for<16 / EPI_PER>(group);
+
         if (retry) {
             // compact every flagged row (runtime loop: one copy of the sort), then offer the
             // candidates of those rows again: count <= k and at most 32 newcomers always fit
@@ -273,40 +590,83 @@ __global__ __launch_bounds__(64, 2) void knn_kernel(const float *__restrict__ xt
                 if (retry & (0x10001u << r)) {
                     const int row = mfma32_row(r, h);
                     const bool mine = (retry >> (r + 16 * h)) & 1u;
+                    int c = cnt_get(r);
                     if (mine) {
                         taur[r] = taus[row];
-                        cntr[r] = cnts[row];
+                        c = cnts[row];
                     }
                     const float pd = __builtin_fmaf(2.0f, acc[r], -xxc) - xxq[r];
                     const bool pass = mine && (pd > taur[r]);
                     const u64 m = __ballot(pass);
                     const unsigned mh = h ? (unsigned)(m >> 32) : (unsigned)m;
-                    if (pass) keys[row][cntr[r] + __popc(mh & ((1u << j32) - 1u))] = make_key(pd, cand);
-                    cntr[r] += __popc(mh);
+                    if (pass) keys[row][c + __popc(mh & ((1u << j32) - 1u))] = make_key(pd, cand);
+                    cnt_set(r, c + __popc(mh));
                 }
             }
         }
     };
+    auto chain = [&](const float(&bop)[CH], f32x16 &acc) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+        for (int s2 = 0; s2 < CH; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s2], bop[s2], acc, 0, 0, 0);
+    };
 
     const int ntiles = Npad / 32;  // even (Npad is a multiple of 128)
-    float b0[CH], b1[CH];
-    load_operand(0, b0);
-    float x0 = xxb[j32], x1;
-    for (int t = 0; t < ntiles; t += 2) {
-        load_operand(t + 1, b1);
-        x1 = xxb[(t + 1) * 32 + j32];
-        process(b0, x0, t * 32 + j32);
-        if (t + 2 < ntiles) {
-            load_operand(t + 2, b0);
-            x0 = xxb[(t + 2) * 32 + j32];
+    const int need = k < N ? k : N;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        float bA[CH], bB[CH];
+        f32x16 accA, accB;
+        load_operand(0, bA);
+        load_operand(1, bB);
+        float xA = xxb[j32], xB = xxb[32 + j32];
+        chain(bA, accA);  // tile 0
+        for (int t = 0; t < ntiles; t += 2) {
+            // accA = tile t (complete); bB = operands of tile t + 1
+            // the prefetches are unconditional (tile index clamped) so that no branch separates them
+            // from the MFMA chain: a join would make the compiler wait for vmcnt(0) there
+            const bool more = t + 2 < ntiles;
+            const float xcurA = xA, xcurB = xB;
+            const int tA = more ? t + 2 : t, tB = more ? t + 3 : t + 1;
+#ifdef KNN_ABLATE_LOADS  // timing experiment: no operand traffic in the stream
+            if (t < 0) {
+#endif
+            load_operand(tA, bA);
+            xA = xxb[tA * 32 + j32];
+#ifdef KNN_ABLATE_LOADS
+            }
+#endif
+            fused(std::true_type{}, bB, accB, accA, xcurA, t * 32 + j32);  // MFMA tile t+1 | select tile t
+#ifdef KNN_ABLATE_LOADS
+            if (t < 0) {
+#endif
+            load_operand(tB, bB);
+            xB = xxb[tB * 32 + j32];
+#ifdef KNN_ABLATE_LOADS
+            }
+#endif
+            if (more)
+                fused(std::true_type{}, bA, accA, accB, xcurB, (t + 1) * 32 + j32);  // MFMA tile t+2 | select tile t+1
+            else
+                fused(std::false_type{}, bA, accA, accB, xcurB, (t + 1) * 32 + j32);  // select the last tile
         }
-        process(b1, x1, (t + 1) * 32 + j32);
+        // a row that collected fewer than k candidates started from a threshold that was NOT a lower
+        // bound of its k-th best: start the whole stream again from tau = -inf (never taken when the
+        // pre-pass bound holds; with tau0 == nullptr the first attempt already starts from -inf)
+        bool bad = false;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bad = bad || (q0 + mfma32_row(r, h) < N && cnt_get(r) < need);
+        if (!__ballot(bad)) break;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) taur[r] = -__builtin_inff();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) cpk[i] = 0u;
     }
 
     // ---- final sort and write-out ------------------------------------------------------
 #pragma unroll
     for (int r = 0; r < 16; ++r)
-        if (j32 == 0) cnts[mfma32_row(r, h)] = cntr[r];
+        if (j32 == 0) cnts[mfma32_row(r, h)] = cnt_get(r);
     for (int row = 0; row < 32; ++row) {
         const int c = cnts[row];
         (void)compact_row<CAP>(&keys[row][0], c, k, lane);
@@ -330,14 +690,51 @@ static int knn_cp(int C)
 static int knn_npad(int N) { return ceil_div(N, KNN_ROWPAD) * KNN_ROWPAD; }
 
 template <int CP>
-static void knn_launch_cp(int cap, int B, hipStream_t st, const float *xt, const float *xx, int N, int Npad, int k,
-                          int32_t *idx)
+static void knn_launch_cp(int cap, int B, hipStream_t st, const float *xt, const float *xx, const float *tau0, int N,
+                          int Npad, int k, int32_t *idx)
 {
     const dim3 grid(B * (Npad / 32)), block(64);
     if (cap == 64)
-        hipLaunchKernelGGL((knn_kernel<CP, 64>), grid, block, 0, st, xt, xx, B, N, Npad, k, idx);
+        hipLaunchKernelGGL((knn_kernel<CP, 64>), grid, block, 0, st, xt, xx, tau0, B, N, Npad, k, idx);
     else
-        hipLaunchKernelGGL((knn_kernel<CP, 128>), grid, block, 0, st, xt, xx, B, N, Npad, k, idx);
+        hipLaunchKernelGGL((knn_kernel<CP, 128>), grid, block, 0, st, xt, xx, tau0, B, N, Npad, k, idx);
+}
+
+template <int CP, bool F16>
+static void knn_bound_launch(int B, hipStream_t st, const void *xop, const float *xn, const float *xx,
+                             const unsigned *bmax, int Npad, int k, float *tau0)
+{
+    constexpr int RT = 1;  // (2 row tiles per wave halve the L2 traffic but measured slower: fewer waves)
+    hipLaunchKernelGGL((knn_bound_kernel<CP, F16, RT>), dim3(B * (Npad / (32 * RT))), dim3(64), 0, st, xop, xn, xx, bmax,
+                       B, Npad, k, tau0);
+}
+
+struct KnnWs {
+    float *xt, *xx, *xxc, *tau0, *mu;
+    half8 *xh;
+    unsigned *bmax;
+    size_t bytes;
+};
+static KnnWs knn_ws(int B, int C, int N, void *base)
+{
+    const size_t npad = knn_npad(N), cp = knn_cp(C);
+    char *p = (char *)base;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        void *r = p + off;
+        off += align_up(bytes, 256);
+        return r;
+    };
+    KnnWs w;
+    w.xt = (float *)take((size_t)B * npad * cp * sizeof(float));
+    w.xx = (float *)take((size_t)B * npad * sizeof(float));
+    w.xxc = (float *)take((size_t)B * npad * sizeof(float));
+    w.tau0 = (float *)take((size_t)B * npad * sizeof(float));
+    w.mu = (float *)take((size_t)B * cp * sizeof(float));
+    w.xh = (half8 *)take((size_t)B * npad * cp * sizeof(_Float16));
+    w.bmax = (unsigned *)take((size_t)B * 2 * sizeof(unsigned));
+    w.bytes = off;
+    return w;
 }
 
 }  // namespace dgcnn
@@ -348,9 +745,7 @@ extern "C" size_t dgcnn_knn_workspace_bytes(int B, int C, int N, int k)
 {
     (void)k;
     if (B <= 0 || C <= 0 || N <= 0) return 0;
-    const size_t npad = knn_npad(N), cp = knn_cp(C);
-    return align_up((size_t)B * npad * cp * sizeof(float), 256) +
-           align_up((size_t)B * npad * sizeof(float), 256);
+    return knn_ws(B, C, N, nullptr).bytes;
 }
 
 extern "C" int dgcnn_knn(const float *x, int B, int N, int C, int k, int32_t *idx, void *workspace,
@@ -365,8 +760,8 @@ extern "C" int dgcnn_knn(const float *x, int B, int N, int C, int k, int32_t *id
     DG_REQUIRE(workspace_bytes >= dgcnn_knn_workspace_bytes(B, C, N, k), "dgcnn_knn: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     const int Npad = knn_npad(N), CP = knn_cp(C);
-    float *xt = (float *)workspace;
-    float *xx = (float *)((char *)workspace + align_up((size_t)B * Npad * CP * sizeof(float), 256));
+    const KnnWs w = knn_ws(B, C, N, workspace);
+    float *xt = w.xt, *xx = w.xx;
 
     hipLaunchKernelGGL(knn_norm_kernel, dim3(ceil_div(Npad, 256), B), dim3(256), 0, st, x, N, C, Npad, xx);
     const size_t nvec = (size_t)Npad * CP / (CP >= 8 ? 4 : 2);
@@ -377,14 +772,41 @@ extern "C" int dgcnn_knn(const float *x, int B, int N, int C, int k, int32_t *id
         hipLaunchKernelGGL((knn_tile_kernel<2>), tgrid, dim3(256), 0, st, x, N, C, Npad, CP, xt);
     DG_CHECK_LAUNCH("knn prep kernels");
 
+    // threshold pre-pass (speed only; see the header).  64 candidate classes per row: worth it for k <= 40.
+    const float *tau0 = nullptr;
+    static const bool prepass_off = getenv("DGCNN_KNN_NO_PREPASS") != nullptr;
+    if (k <= 40 && N >= 256 && !prepass_off) {
+        // (knn_bound_kernel writes tau0 for every row, padded rows included)
+        if (CP >= 16) {
+            hipLaunchKernelGGL(knn_center_kernel, dim3(B), dim3(256), 0, st, x, N, C, w.mu);
+            const size_t nvec = (size_t)Npad * CP / 8;
+            hipLaunchKernelGGL(knn_half_kernel, dim3((unsigned)((nvec + 255) / 256), B), dim3(256), 0, st, x, w.mu, N, C,
+                               Npad, CP, w.xh);
+            hipLaunchKernelGGL(knn_cnorm_kernel, dim3(Npad / 16, B), dim3(256), 0, st, x, w.mu, N, C, Npad, w.xxc);
+            hipLaunchKernelGGL(knn_bmax_kernel, dim3(B), dim3(1024), 0, st, w.xxc, xx, N, Npad, w.bmax);
+            switch (CP) {
+                case 16: knn_bound_launch<16, true>(B, st, w.xh, w.xxc, xx, w.bmax, Npad, k, w.tau0); break;
+                case 32: knn_bound_launch<32, true>(B, st, w.xh, w.xxc, xx, w.bmax, Npad, k, w.tau0); break;
+                case 64: knn_bound_launch<64, true>(B, st, w.xh, w.xxc, xx, w.bmax, Npad, k, w.tau0); break;
+                default: knn_bound_launch<128, true>(B, st, w.xh, w.xxc, xx, w.bmax, Npad, k, w.tau0); break;
+            }
+        } else if (CP == 8) {
+            knn_bound_launch<8, false>(B, st, xt, xx, xx, w.bmax, Npad, k, w.tau0);
+        } else {
+            knn_bound_launch<4, false>(B, st, xt, xx, xx, w.bmax, Npad, k, w.tau0);
+        }
+        DG_CHECK_LAUNCH("knn_bound_kernel");
+        tau0 = w.tau0;
+    }
+
     const int cap = (k <= 32) ? 64 : 128;
     switch (CP) {
-        case 4: knn_launch_cp<4>(cap, B, st, xt, xx, N, Npad, k, idx); break;
-        case 8: knn_launch_cp<8>(cap, B, st, xt, xx, N, Npad, k, idx); break;
-        case 16: knn_launch_cp<16>(cap, B, st, xt, xx, N, Npad, k, idx); break;
-        case 32: knn_launch_cp<32>(cap, B, st, xt, xx, N, Npad, k, idx); break;
-        case 64: knn_launch_cp<64>(cap, B, st, xt, xx, N, Npad, k, idx); break;
-        case 128: knn_launch_cp<128>(cap, B, st, xt, xx, N, Npad, k, idx); break;
+        case 4: knn_launch_cp<4>(cap, B, st, xt, xx, tau0, N, Npad, k, idx); break;
+        case 8: knn_launch_cp<8>(cap, B, st, xt, xx, tau0, N, Npad, k, idx); break;
+        case 16: knn_launch_cp<16>(cap, B, st, xt, xx, tau0, N, Npad, k, idx); break;
+        case 32: knn_launch_cp<32>(cap, B, st, xt, xx, tau0, N, Npad, k, idx); break;
+        case 64: knn_launch_cp<64>(cap, B, st, xt, xx, tau0, N, Npad, k, idx); break;
+        case 128: knn_launch_cp<128>(cap, B, st, xt, xx, tau0, N, Npad, k, idx); break;
         default: DG_FAIL("dgcnn_knn: unsupported padded channel count %d", CP);
     }
     DG_CHECK_LAUNCH("knn_kernel");

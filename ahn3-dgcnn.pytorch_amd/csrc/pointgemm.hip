@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(const float *__restrict__ 
     }
 }
 
-constexpr int WGRAD_CHUNK = 256;  // points per wave
+constexpr int WGRAD_CHUNK = 64;  // points per wave (875 waves at P = 56 000)
 
 // partial[chunk][m][n] = sum_p A(p, m) X[p][n]: contraction over the points (MFMA K dimension).
 template <int MT, int NT>
@@ -135,28 +135,32 @@ __global__ __launch_bounds__(64) void wgrad_kernel(const float *__restrict__ A0,
         }
 }
 
-__global__ void finish_dw1_kernel(const float *__restrict__ partial, int nchunk, int C, float *__restrict__ gw1)
+// out[e] = sum_chunk partial[chunk][e] for e < n.  Block = 256 threads = 4 waves x 64 elements: wave w
+// adds its contiguous quarter of the chunks in order, the four sums are then added in wave order
+// (fixed association: deterministic).
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float *__restrict__ partial, int nchunk, int n,
+                                                           float *__restrict__ out)
+{
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;
+    const int q = (nchunk + 3) / 4;
+    const int c0 = w * q, c1 = c0 + q < nchunk ? c0 + q : nchunk;
+    float s = 0.0f;
+    if (e < n)
+        for (int ch = c0; ch < c1; ++ch) s += partial[(size_t)ch * n + e];
+    red[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && e < n) out[e] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
+// gw1 [64][2C] from G = dWcat [128][C]:  c < C: G[o][c] - G[64 + o][c];  c >= C: G[64 + o][c - C]
+__global__ void finish_dw1_kernel(const float *__restrict__ G, int C, float *__restrict__ gw1)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= EC * 2 * C) return;
     const int o = t / (2 * C), c = t % (2 * C);
-    const size_t stride = (size_t)128 * C;
-    float ga = 0.0f, gd = 0.0f;  // G[o][c'] (neighbour part), G[64 + o][c'] (centre part)
-    const int cc = c < C ? c : c - C;
-    for (int ch = 0; ch < nchunk; ++ch) {
-        if (c < C) ga += partial[ch * stride + (size_t)o * C + cc];
-        gd += partial[ch * stride + (size_t)(EC + o) * C + cc];
-    }
-    gw1[t] = c < C ? ga - gd : gd;
-}
-
-__global__ void sum_partials_kernel(const float *__restrict__ partial, int nchunk, int n, float *__restrict__ out)
-{
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    float s = 0.0f;
-    for (int ch = 0; ch < nchunk; ++ch) s += partial[(size_t)ch * n + t];
-    out[t] = s;
+    gw1[t] = c < C ? G[(size_t)o * C + c] - G[(size_t)(EC + o) * C + c] : G[(size_t)(EC + o) * C + (c - C)];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -198,14 +202,15 @@ void launch_wgrad(const float *A0, int M0, const float *A1, int M1, const float 
 #undef DG_WG
 }
 
-void launch_finish_dw1(const float *partial, int nchunk, int C, float *gw1, hipStream_t st)
+void launch_finish_dw1(const float *partial, int nchunk, int C, float *G, float *gw1, hipStream_t st)
 {
-    hipLaunchKernelGGL(finish_dw1_kernel, dim3(ceil_div(EC * 2 * C, 256)), dim3(256), 0, st, partial, nchunk, C, gw1);
+    launch_sum_partials(partial, nchunk, 128 * C, G, st);
+    hipLaunchKernelGGL(finish_dw1_kernel, dim3(ceil_div(EC * 2 * C, 256)), dim3(256), 0, st, G, C, gw1);
 }
 
 void launch_sum_partials(const float *partial, int nchunk, int n, float *out, hipStream_t st)
 {
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, partial, nchunk, n, out);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(ceil_div(n, 64)), dim3(256), 0, st, partial, nchunk, n, out);
 }
 
 }  // namespace dgcnn
