@@ -290,7 +290,8 @@ __global__ __launch_bounds__(256) void knn_cnorm_kernel(const float *__restrict_
 // bmax[b] = (largest centred norm, largest raw norm) of batch element b, as uint bits of non-negative
 // floats; one workgroup per batch element.
 __global__ __launch_bounds__(1024) void knn_bmax_kernel(const float *__restrict__ xxc, const float *__restrict__ xx,
-                                                        int N, int Npad, unsigned *__restrict__ bmax)
+                                                        int N, int Npad, unsigned *__restrict__ bmax,
+                                                        int *__restrict__ f16ok)
 {
     __shared__ unsigned red[2][16];
     const int b = blockIdx.x;
@@ -315,6 +316,8 @@ __global__ __launch_bounds__(1024) void knn_bmax_kernel(const float *__restrict_
         unsigned m = 0u;
         for (int i = 0; i < 16; ++i) m = m > red[threadIdx.x][i] ? m : red[threadIdx.x][i];
         bmax[2 * b + threadIdx.x] = m;
+        // centred features must fit fp16 (|y| <= sqrt(cmax) < 65504) with room; NaN/inf norms fail the test
+        if (threadIdx.x == 0) f16ok[b] = (__uint_as_float(m) < 1.0e9f) ? 1 : 0;
     }
 }
 
@@ -339,6 +342,20 @@ __device__ __forceinline__ void bitonic32_sort(unsigned &key, int lane)
     bitonic32_merge<K2, K2 / 2>(key, lane);
 }
 
+// Bound on |pd16 - pd32| for one query row, where pd16 = 2 d16 - yy_l - yy_i is evaluated from the fp16
+// centred features (d16 = fp32-accumulated fp16 MFMA dot, yy = fp32 centred norms) and pd32 is the oracle's
+// fp32 value on the raw features.  Both approximate the real -||x_i - x_l||^2:
+//   fp16 rounding of both operands (rel. 2^-11 each) + fp32 accumulation: |2 d16 - 2 y_i.y_l| <= 2 * 2^-10 * 1.01 * sqrt(yy_i yy_l)
+//   fp16 subnormals (abs. 2^-25 per element):                              <= 1e-6 (sqrt(yy_i) + sqrt(yy_l))
+//   fp32 evaluation of yy and of the final subtractions:                   <= 1e-5 (yy_i + yy_l)
+//   the oracle's own fp32 chain (gamma_66 = 3.9e-6 on |dot| and on xx):    <= 8e-6 (xx_i + xx_l)
+// with yy_l <= cmax, xx_l <= rmax (per batch element).  Worst-case bounds, not estimates.
+__device__ __forceinline__ float knn_f16_eps(float yy_i, float cmax, float xx_i, float rmax)
+{
+    return 2.1e-3f * __builtin_sqrtf(yy_i * cmax) + 1e-6f * (__builtin_sqrtf(yy_i) + __builtin_sqrtf(cmax)) +
+           1e-5f * (yy_i + cmax) + 8e-6f * (xx_i + rmax) + 1e-30f;
+}
+
 // One wave = RT x 32 query rows (RT row tiles share every candidate-operand load: the pre-pass is
 // bound by L2 -> CU traffic, not by arithmetic).  F16 = true: xop are the fp16 centred tiles, xn the
 // centred norms; F16 = false (small C): xop are the fp32 tiles of knn_tile_kernel, xn the raw norms,
@@ -347,7 +364,7 @@ template <int CP, bool F16, int RT>
 __global__ __launch_bounds__(64) void knn_bound_kernel(const void *__restrict__ xop, const float *__restrict__ xn,
                                                        const float *__restrict__ xx_raw,
                                                        const unsigned *__restrict__ bmax, int B, int Npad, int k,
-                                                       float *__restrict__ tau0)
+                                                       float *__restrict__ tau0, float *__restrict__ epsr)
 {
     const int lane = threadIdx.x, h = lane >> 5, j32 = lane & 31;
     const int b = blockIdx.x % B, rb0 = (blockIdx.x / B) * RT;  // first row tile of this wave
@@ -445,16 +462,18 @@ __global__ __launch_bounds__(64) void knn_bound_kernel(const void *__restrict__ 
                 const float vk = __uint_as_float((kth & 0x80000000u) ? (kth & 0x7fffffffu) : ~kth);
                 const int row = (rb0 + rt) * 32 + mfma32_row(r, hh);
                 const float xi = xnb[row], xr = xx_raw[(size_t)b * Npad + row];
-                float t;
+                float t, eps = 0.0f;
                 if constexpr (F16) {
-                    // |pd_fp16 - pd_fp32| <= 2^-9 (1 + 2^-4) sqrt(xxc_i xxc_l) + fp32-level terms
-                    const float eps = 2.1e-3f * __builtin_sqrtf(xi * cmax) + 2.0e-6f * (xr + rmax) + 1e-30f;
+                    eps = knn_f16_eps(xi, cmax, xr, rmax);
                     t = (vk - xi) - eps;
                 } else {
                     const float pd = vk - xi;  // same fp32 operations as knn_kernel
                     t = pd - fmaxf(__builtin_fabsf(pd) * 4.8e-7f, 1e-37f);
                 }
-                if (lane == 0) tau0[(size_t)b * Npad + row] = (t != t) ? -__builtin_inff() : t;  // NaN -> no bound
+                if (lane == 0) {
+                    tau0[(size_t)b * Npad + row] = (t != t) ? -__builtin_inff() : t;  // NaN -> no bound
+                    if (epsr) epsr[(size_t)b * Npad + row] = eps;
+                }
             }
         }
     }
@@ -462,8 +481,8 @@ __global__ __launch_bounds__(64) void knn_bound_kernel(const void *__restrict__ 
 
 template <int CP, int CAP>
 __global__ __launch_bounds__(64, 2) void knn_kernel(const float *__restrict__ xt, const float *__restrict__ xx,
-                                                    const float *__restrict__ tau0, int B, int N, int Npad, int k,
-                                                    int32_t *__restrict__ idx)
+                                                    const float *__restrict__ tau0, const int *__restrict__ rbflag,
+                                                    int B, int N, int Npad, int k, int32_t *__restrict__ idx)
 {
     constexpr int CH = CP / 2;
     constexpr int VEC = CH >= 4 ? 4 : CH;
@@ -478,6 +497,7 @@ __global__ __launch_bounds__(64, 2) void knn_kernel(const float *__restrict__ xt
     // blocks are dealt round-robin over the XCDs: with B a multiple of 8 all waves of batch
     // element b run on one XCD and share its L2 copy of xt[b] (speed only)
     const int b = blockIdx.x % B, rb = blockIdx.x / B;
+    if (rbflag && !rbflag[b * (Npad / 32) + rb]) return;  // row block already done by the fp16 filter + refine path
     const int q0 = rb * 32;
     const float *xtb = xt + (size_t)b * Npad * CP;
     const float *xxb = xx + (size_t)b * Npad;
@@ -681,6 +701,254 @@ __global__ __launch_bounds__(64, 2) void knn_kernel(const float *__restrict__ xt
 }
 
 // ------------------------------------------------------------------------------------
+// Exact kNN through an fp16 FILTER and an exact fp32 REFINE (C >= 16): knn_filter16_kernel + knn_refine_kernel.
+//
+// fp32 MFMA shares the fp32 FMA lanes with the vector ALU on gfx950 (same 64 FLOP/clk/SIMD; measured here:
+// MFMA-busy and VALU-active cycles add up instead of overlapping), so the exact all-pairs kernel above pays
+// 64 cycles per 32x32x2 MFMA with nothing hidden underneath.  Here the all-pairs stream runs on
+// v_mfma_f32_32x32x16_f16 (1/16 of the cost) over the centred fp16 features and only FILTERS: pair (i, l)
+// survives if   pd16(i, l) > tau0_i - eps_i,   where tau0_i (knn_bound_kernel) is a lower bound of row i's
+// k-th best exact pd and eps_i = knn_f16_eps bounds |pd16 - pd32|.  Every true neighbour survives
+// (pd32 >= k-th best >= tau0_i  =>  pd16 >= tau0_i - eps_i).  The filter kernel is a light streaming kernel
+// (no top-k state, ~70 VGPRs, 1 KB LDS: many waves per SIMD keep the L2 stream busy); it appends the
+// survivors (about 42 per row at N = 7000, k = 30) to a per-wave list in HBM, 64 entries per coalesced store.
+// The refine kernel then computes, one survivor per lane, the exact pd in the oracle's arithmetic (sequential
+// fmaf chain over the raw fp32 features, c = 0..C-1) and selects with the same key / buffer / compaction
+// machinery as knn_kernel.  A row block whose list overflowed, whose features do not fit fp16, or that ends
+// with fewer than k candidates is flagged and recomputed by the exact fp32 kernel (knn_kernel), so the
+// result never depends on the filter.
+constexpr int KNN_QCAP = 256;     // LDS staging ring of the filter kernel (entries: row << 27 | candidate)
+constexpr int KNN_LISTCAP = 4096;  // survivor list per 32-row block in HBM (128 per row on average)
+
+template <int CP>
+__global__ __launch_bounds__(64) void knn_filter16_kernel(const half8 *__restrict__ xh, const float *__restrict__ xxc,
+                                                          const float *__restrict__ tau0,
+                                                          const float *__restrict__ epsr,
+                                                          const int *__restrict__ f16ok, int B, int Npad,
+                                                          unsigned *__restrict__ lists, int *__restrict__ lcount,
+                                                          int *__restrict__ rbflag)
+{
+    constexpr int KS = CP / 16;
+    __shared__ unsigned queue[KNN_QCAP];
+    const int lane = threadIdx.x, h = lane >> 5, j32 = lane & 31;
+    const int b = blockIdx.x % B, rb = blockIdx.x / B;
+    const int ntiles = Npad / 32;
+    const int wid = b * ntiles + rb;  // row block id
+    if (!f16ok[b]) {
+        if (lane == 0) {
+            rbflag[wid] = 1;
+            lcount[wid] = 0;
+        }
+        return;
+    }
+    const int q0 = rb * 32;
+    const half8 *xb = xh + (size_t)b * ntiles * KS * 64 + lane;
+    const float *yb = xxc + (size_t)b * Npad;
+    unsigned *list = lists + (size_t)wid * KNN_LISTCAP;
+
+    half8 a[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) a[ks] = xb[((size_t)rb * KS + ks) * 64];
+    // filter threshold on t = 2 d16 - yy_l:  t > (tau0 - eps) + yy_i, lowered by the rounding of this very sum
+    float thrp[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = q0 + mfma32_row(r, h);
+        const float tau = tau0[(size_t)b * Npad + row], yy = yb[row];
+        const float v = (tau - epsr[(size_t)b * Npad + row]) + yy;
+        thrp[r] = v - (__builtin_fabsf(v) + __builtin_fabsf(tau) + yy) * 2.4e-7f;
+    }
+
+    int qn = 0, lpos = 0;  // staged entries (queue[0 .. qn)), entries already in the HBM list
+    bool overflow = false;
+    auto flush = [&](int n) {  // move the first n (<= 64) staged entries to the list, shift the rest down
+        if (lpos + n > KNN_LISTCAP) {
+            overflow = true;
+        } else if (lane < n) {
+            list[lpos + lane] = queue[lane];
+        }
+        lpos += n;
+        const int rest = qn - n;
+        unsigned keep[KNN_QCAP / 64];
+#pragma unroll
+        for (int i = 0; i < KNN_QCAP / 64; ++i) keep[i] = (i * 64 + lane < rest) ? queue[n + i * 64 + lane] : 0u;
+#pragma unroll
+        for (int i = 0; i < KNN_QCAP / 64; ++i)
+            if (i * 64 + lane < rest) queue[i * 64 + lane] = keep[i];
+        qn = rest;
+    };
+
+    // tiles two ahead are in flight while one is computed: the stream is bound by L2 latency x bandwidth
+    half8 b0[KS], b1[KS], b2[KS];
+    float y0, y1, y2;
+    auto fetch = [&](int t, half8(&dst)[KS], float &y) {
+        const int tc = t < ntiles ? t : ntiles - 1;  // clamped: no branch around the loads
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) dst[ks] = xb[((size_t)tc * KS + ks) * 64];
+        y = yb[tc * 32 + j32];
+    };
+    auto tile = [&](const half8(&bop)[KS], float yl, int cand) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks], bop[ks], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float t = __builtin_fmaf(2.0f, acc[r], -yl);
+            const bool pass = t > thrp[r];
+            const u64 m = __ballot(pass);
+            if (__builtin_expect(m != 0, 0)) {
+                if (qn > KNN_QCAP - 64) {  // room for a full register of survivors (loose thresholds only)
+                    while (qn >= 64) flush(64);
+                }
+                if (pass) {
+                    const int off = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+                    queue[qn + off] = ((unsigned)mfma32_row(r, h) << 27) | (unsigned)cand;
+                }
+                qn += __popcll(m);
+            }
+        }
+        if (qn >= 64) flush(64);
+    };
+    fetch(0, b0, y0);
+    fetch(1, b1, y1);
+    for (int t = 0; t < ntiles; t += 3) {
+        fetch(t + 2, b2, y2);
+        tile(b0, y0, t * 32 + j32);
+        fetch(t + 3, b0, y0);
+        if (t + 1 < ntiles) tile(b1, y1, (t + 1) * 32 + j32);
+        fetch(t + 4, b1, y1);
+        if (t + 2 < ntiles) tile(b2, y2, (t + 2) * 32 + j32);
+    }
+    while (qn > 0) flush(qn < 64 ? qn : 64);
+    if (lane == 0) {
+        lcount[wid] = overflow ? 0 : lpos;
+        rbflag[wid] = overflow ? 1 : 0;
+    }
+}
+
+// One wave = one 32-row block: exact pd of every listed survivor, selection, output.
+template <int CP, int CAP>
+__global__ __launch_bounds__(64) void knn_refine_kernel(const float *__restrict__ x, const float *__restrict__ xx,
+                                                        const unsigned *__restrict__ lists,
+                                                        const int *__restrict__ lcount, int *__restrict__ rbflag,
+                                                        int B, int N, int C, int Npad, int k,
+                                                        int32_t *__restrict__ idx)
+{
+    constexpr int XS = CP + 1;  // LDS row stride of the raw query rows (odd: conflict-free column reads)
+    __shared__ u64 keys[32][CAP];
+    __shared__ int cnts[32];
+    __shared__ float taus[32];
+    __shared__ float xq[32][XS];
+    __shared__ float xxq[32];
+
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x % B, rb = blockIdx.x / B;
+    const int ntiles = Npad / 32;
+    const int wid = b * ntiles + rb;
+    if (rbflag[wid]) return;  // the exact fp32 kernel recomputes this row block
+    const int q0 = rb * 32;
+    const float *xxb = xx + (size_t)b * Npad;
+    const float *xraw = x + (size_t)b * N * C;
+    const unsigned *list = lists + (size_t)wid * KNN_LISTCAP;
+    const int n = lcount[wid];
+
+    for (int e = lane; e < 32 * CP; e += 64) {
+        const int r = e / CP, c = e % CP;
+        xq[r][c] = (q0 + r < N && c < C) ? xraw[(size_t)(q0 + r) * C + c] : 0.0f;
+    }
+    if (lane < 32) {
+        xxq[lane] = xxb[q0 + lane];
+        cnts[lane] = 0;
+        taus[lane] = -__builtin_inff();
+    }
+
+    for (int base = 0; base < n; base += 64) {
+        const bool act = base + lane < n;
+        const unsigned qe = act ? list[base + lane] : 0u;
+        const int row = (int)(qe >> 27), cand = (int)(qe & 0x7ffffffu);
+        const float *xl = xraw + (size_t)cand * C;
+        float dot = 0.0f;
+        if ((C & 3) == 0) {
+            // the candidate row is fetched in two halves, each with all its loads in flight at once;
+            // channels beyond C multiply zeros: fma(0, 0, dot) == dot
+            constexpr int HV = CP / 8 > 0 ? CP / 8 : 1;  // float4 per half
+            float4 v0[HV], v1[HV];
+#pragma unroll
+            for (int i = 0; i < HV; ++i) v0[i] = (4 * i < C) ? *reinterpret_cast<const float4 *>(xl + 4 * i) : float4{0, 0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < HV; ++i)
+                v1[i] = (4 * (HV + i) < C && HV + i < CP / 4) ? *reinterpret_cast<const float4 *>(xl + 4 * (HV + i)) : float4{0, 0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < HV; ++i) {
+                dot = __builtin_fmaf(xq[row][4 * i + 0], v0[i].x, dot);
+                dot = __builtin_fmaf(xq[row][4 * i + 1], v0[i].y, dot);
+                dot = __builtin_fmaf(xq[row][4 * i + 2], v0[i].z, dot);
+                dot = __builtin_fmaf(xq[row][4 * i + 3], v0[i].w, dot);
+            }
+            if constexpr (CP / 4 > HV) {
+#pragma unroll
+                for (int i = 0; i < HV; ++i) {
+                    dot = __builtin_fmaf(xq[row][4 * (HV + i) + 0], v1[i].x, dot);
+                    dot = __builtin_fmaf(xq[row][4 * (HV + i) + 1], v1[i].y, dot);
+                    dot = __builtin_fmaf(xq[row][4 * (HV + i) + 2], v1[i].z, dot);
+                    dot = __builtin_fmaf(xq[row][4 * (HV + i) + 3], v1[i].w, dot);
+                }
+            }
+        } else {
+            for (int c = 0; c < C; ++c) dot = __builtin_fmaf(xq[row][c], xl[c], dot);
+        }
+        const float pd = __builtin_fmaf(2.0f, dot, -xxb[cand]) - xxq[row];  // the oracle's arithmetic
+        const u64 key = make_key(pd, cand);
+        bool pending = act;
+        for (;;) {
+            const bool want = pending && (pd > taus[row]);
+            int slot = -1;
+            if (want) slot = atomicAdd(&cnts[row], 1);
+            if (want && slot < CAP) keys[row][slot] = key;
+            const bool over = want && slot >= CAP;
+            const u64 mo = __ballot(over);
+            if (!mo) break;
+            // rows whose buffer is full: sort, keep the best k, tighten tau; their lanes offer again
+            u64 todo = mo;
+            while (todo) {
+                const int l0 = __ffsll((long long)todo) - 1;
+                const int ru = __builtin_amdgcn_readlane(row, l0);
+                const float tnew = compact_row<CAP>(&keys[ru][0], CAP, k, lane);
+                if (lane == 0) {
+                    cnts[ru] = k;
+                    taus[ru] = tnew;
+                }
+                todo &= ~__ballot(over && row == ru);
+            }
+            pending = over;
+        }
+    }
+
+    // fewer than k candidates in some row: the filter threshold was not a lower bound (cannot happen
+    // while the bounds hold) -> hand the row block to the exact kernel
+    const int need = k < N ? k : N;
+    const bool bad = lane < 32 && q0 + lane < N && cnts[lane] < need;
+    if (__ballot(bad)) {
+        if (lane == 0) rbflag[wid] = 1;
+        return;
+    }
+    for (int row = 0; row < 32; ++row) {
+        int c = cnts[row];
+        c = c < CAP ? c : CAP;
+        (void)compact_row<CAP>(&keys[row][0], c, k, lane);
+        const int q = q0 + row;
+        if (q < N) {
+            for (int g = lane; g < k; g += 64) {
+                const unsigned lo = (unsigned)keys[row][g];
+                idx[((size_t)b * N + q) * k + g] = (int32_t)(0xffffffffu - lo);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
 static int knn_cp(int C)
 {
     int cp = 4;
@@ -690,29 +958,30 @@ static int knn_cp(int C)
 static int knn_npad(int N) { return ceil_div(N, KNN_ROWPAD) * KNN_ROWPAD; }
 
 template <int CP>
-static void knn_launch_cp(int cap, int B, hipStream_t st, const float *xt, const float *xx, const float *tau0, int N,
-                          int Npad, int k, int32_t *idx)
+static void knn_launch_cp(int cap, int B, hipStream_t st, const float *xt, const float *xx, const float *tau0,
+                          const int *rbflag, int N, int Npad, int k, int32_t *idx)
 {
     const dim3 grid(B * (Npad / 32)), block(64);
     if (cap == 64)
-        hipLaunchKernelGGL((knn_kernel<CP, 64>), grid, block, 0, st, xt, xx, tau0, B, N, Npad, k, idx);
+        hipLaunchKernelGGL((knn_kernel<CP, 64>), grid, block, 0, st, xt, xx, tau0, rbflag, B, N, Npad, k, idx);
     else
-        hipLaunchKernelGGL((knn_kernel<CP, 128>), grid, block, 0, st, xt, xx, tau0, B, N, Npad, k, idx);
+        hipLaunchKernelGGL((knn_kernel<CP, 128>), grid, block, 0, st, xt, xx, tau0, rbflag, B, N, Npad, k, idx);
 }
 
 template <int CP, bool F16>
 static void knn_bound_launch(int B, hipStream_t st, const void *xop, const float *xn, const float *xx,
-                             const unsigned *bmax, int Npad, int k, float *tau0)
+                             const unsigned *bmax, int Npad, int k, float *tau0, float *epsr)
 {
     constexpr int RT = 1;  // (2 row tiles per wave halve the L2 traffic but measured slower: fewer waves)
     hipLaunchKernelGGL((knn_bound_kernel<CP, F16, RT>), dim3(B * (Npad / (32 * RT))), dim3(64), 0, st, xop, xn, xx, bmax,
-                       B, Npad, k, tau0);
+                       B, Npad, k, tau0, epsr);
 }
 
 struct KnnWs {
-    float *xt, *xx, *xxc, *tau0, *mu;
+    float *xt, *xx, *xxc, *tau0, *eps, *mu;
     half8 *xh;
-    unsigned *bmax;
+    unsigned *bmax, *lists;
+    int *f16ok, *lcount, *rbflag;
     size_t bytes;
 };
 static KnnWs knn_ws(int B, int C, int N, void *base)
@@ -730,11 +999,31 @@ static KnnWs knn_ws(int B, int C, int N, void *base)
     w.xx = (float *)take((size_t)B * npad * sizeof(float));
     w.xxc = (float *)take((size_t)B * npad * sizeof(float));
     w.tau0 = (float *)take((size_t)B * npad * sizeof(float));
+    w.eps = (float *)take((size_t)B * npad * sizeof(float));
     w.mu = (float *)take((size_t)B * cp * sizeof(float));
     w.xh = (half8 *)take((size_t)B * npad * cp * sizeof(_Float16));
     w.bmax = (unsigned *)take((size_t)B * 2 * sizeof(unsigned));
+    w.f16ok = (int *)take((size_t)B * sizeof(int));
+    w.lcount = (int *)take((size_t)B * (npad / 32) * sizeof(int));
+    w.rbflag = (int *)take((size_t)B * (npad / 32) * sizeof(int));
+    w.lists = (unsigned *)take(cp >= 16 ? (size_t)B * (npad / 32) * KNN_LISTCAP * sizeof(unsigned) : 0);
     w.bytes = off;
     return w;
+}
+
+template <int CP>
+static void knn_f16_launch(int cap, const KnnWs &w, const float *x, int B, int N, int C, int Npad, int k, int32_t *idx,
+                           hipStream_t st)
+{
+    const dim3 grid(B * (Npad / 32)), block(64);
+    hipLaunchKernelGGL((knn_filter16_kernel<CP>), grid, block, 0, st, w.xh, w.xxc, w.tau0, w.eps, w.f16ok, B, Npad, w.lists,
+                       w.lcount, w.rbflag);
+    if (cap == 64)
+        hipLaunchKernelGGL((knn_refine_kernel<CP, 64>), grid, block, 0, st, x, w.xx, w.lists, w.lcount, w.rbflag, B, N, C,
+                           Npad, k, idx);
+    else
+        hipLaunchKernelGGL((knn_refine_kernel<CP, 128>), grid, block, 0, st, x, w.xx, w.lists, w.lcount, w.rbflag, B, N, C,
+                           Npad, k, idx);
 }
 
 }  // namespace dgcnn
@@ -774,8 +1063,13 @@ extern "C" int dgcnn_knn(const float *x, int B, int N, int C, int k, int32_t *id
 
     // threshold pre-pass (speed only; see the header).  64 candidate classes per row: worth it for k <= 40.
     const float *tau0 = nullptr;
+    const int *rbflag = nullptr;
     static const bool prepass_off = getenv("DGCNN_KNN_NO_PREPASS") != nullptr;
-    if (k <= 40 && N >= 256 && !prepass_off) {
+    static const bool f16_off = getenv("DGCNN_KNN_NO_F16") != nullptr;
+    const bool prepass = k <= 40 && N >= 256 && !prepass_off;
+    const bool f16path = prepass && CP >= 16 && !f16_off;
+    const int cap = (k <= 32) ? 64 : 128;
+    if (prepass) {
         // (knn_bound_kernel writes tau0 for every row, padded rows included)
         if (CP >= 16) {
             hipLaunchKernelGGL(knn_center_kernel, dim3(B), dim3(256), 0, st, x, N, C, w.mu);
@@ -783,30 +1077,41 @@ extern "C" int dgcnn_knn(const float *x, int B, int N, int C, int k, int32_t *id
             hipLaunchKernelGGL(knn_half_kernel, dim3((unsigned)((nvec + 255) / 256), B), dim3(256), 0, st, x, w.mu, N, C,
                                Npad, CP, w.xh);
             hipLaunchKernelGGL(knn_cnorm_kernel, dim3(Npad / 16, B), dim3(256), 0, st, x, w.mu, N, C, Npad, w.xxc);
-            hipLaunchKernelGGL(knn_bmax_kernel, dim3(B), dim3(1024), 0, st, w.xxc, xx, N, Npad, w.bmax);
+            hipLaunchKernelGGL(knn_bmax_kernel, dim3(B), dim3(1024), 0, st, w.xxc, xx, N, Npad, w.bmax, w.f16ok);
             switch (CP) {
-                case 16: knn_bound_launch<16, true>(B, st, w.xh, w.xxc, xx, w.bmax, Npad, k, w.tau0); break;
-                case 32: knn_bound_launch<32, true>(B, st, w.xh, w.xxc, xx, w.bmax, Npad, k, w.tau0); break;
-                case 64: knn_bound_launch<64, true>(B, st, w.xh, w.xxc, xx, w.bmax, Npad, k, w.tau0); break;
-                default: knn_bound_launch<128, true>(B, st, w.xh, w.xxc, xx, w.bmax, Npad, k, w.tau0); break;
+                case 16: knn_bound_launch<16, true>(B, st, w.xh, w.xxc, xx, w.bmax, Npad, k, w.tau0, w.eps); break;
+                case 32: knn_bound_launch<32, true>(B, st, w.xh, w.xxc, xx, w.bmax, Npad, k, w.tau0, w.eps); break;
+                case 64: knn_bound_launch<64, true>(B, st, w.xh, w.xxc, xx, w.bmax, Npad, k, w.tau0, w.eps); break;
+                default: knn_bound_launch<128, true>(B, st, w.xh, w.xxc, xx, w.bmax, Npad, k, w.tau0, w.eps); break;
             }
         } else if (CP == 8) {
-            knn_bound_launch<8, false>(B, st, xt, xx, xx, w.bmax, Npad, k, w.tau0);
+            knn_bound_launch<8, false>(B, st, xt, xx, xx, w.bmax, Npad, k, w.tau0, nullptr);
         } else {
-            knn_bound_launch<4, false>(B, st, xt, xx, xx, w.bmax, Npad, k, w.tau0);
+            knn_bound_launch<4, false>(B, st, xt, xx, xx, w.bmax, Npad, k, w.tau0, nullptr);
         }
         DG_CHECK_LAUNCH("knn_bound_kernel");
         tau0 = w.tau0;
     }
+    if (f16path) {
+        // fp16 filter + exact refine; the exact fp32 kernel below then only runs the row blocks these
+        // kernels flagged (it returns at once for the others)
+        rbflag = w.rbflag;
+        switch (CP) {
+            case 16: knn_f16_launch<16>(cap, w, x, B, N, C, Npad, k, idx, st); break;
+            case 32: knn_f16_launch<32>(cap, w, x, B, N, C, Npad, k, idx, st); break;
+            case 64: knn_f16_launch<64>(cap, w, x, B, N, C, Npad, k, idx, st); break;
+            default: knn_f16_launch<128>(cap, w, x, B, N, C, Npad, k, idx, st); break;
+        }
+        DG_CHECK_LAUNCH("knn_filter16_kernel / knn_refine_kernel");
+    }
 
-    const int cap = (k <= 32) ? 64 : 128;
     switch (CP) {
-        case 4: knn_launch_cp<4>(cap, B, st, xt, xx, tau0, N, Npad, k, idx); break;
-        case 8: knn_launch_cp<8>(cap, B, st, xt, xx, tau0, N, Npad, k, idx); break;
-        case 16: knn_launch_cp<16>(cap, B, st, xt, xx, tau0, N, Npad, k, idx); break;
-        case 32: knn_launch_cp<32>(cap, B, st, xt, xx, tau0, N, Npad, k, idx); break;
-        case 64: knn_launch_cp<64>(cap, B, st, xt, xx, tau0, N, Npad, k, idx); break;
-        case 128: knn_launch_cp<128>(cap, B, st, xt, xx, tau0, N, Npad, k, idx); break;
+        case 4: knn_launch_cp<4>(cap, B, st, xt, xx, tau0, rbflag, N, Npad, k, idx); break;
+        case 8: knn_launch_cp<8>(cap, B, st, xt, xx, tau0, rbflag, N, Npad, k, idx); break;
+        case 16: knn_launch_cp<16>(cap, B, st, xt, xx, tau0, rbflag, N, Npad, k, idx); break;
+        case 32: knn_launch_cp<32>(cap, B, st, xt, xx, tau0, rbflag, N, Npad, k, idx); break;
+        case 64: knn_launch_cp<64>(cap, B, st, xt, xx, tau0, rbflag, N, Npad, k, idx); break;
+        case 128: knn_launch_cp<128>(cap, B, st, xt, xx, tau0, rbflag, N, Npad, k, idx); break;
         default: DG_FAIL("dgcnn_knn: unsupported padded channel count %d", CP);
     }
     DG_CHECK_LAUNCH("knn_kernel");
