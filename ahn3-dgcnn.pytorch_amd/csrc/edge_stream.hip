@@ -42,10 +42,13 @@ __device__ __forceinline__ void block_reduce_store(double (&v)[NV], double *__re
 }
 
 // ---------------------------------------------------------------------------------------------
+// Also written for the backward: usum[i] = sum_j u[i][j] (fp32) and, with WANT_EXT, hitn[i] = the neighbour
+// index of the FIRST edge attaining the extreme (PyTorch's max routes the gradient to the first maximum).
 template <bool WANT_EXT>
 __global__ __launch_bounds__(256) void edge_reduce_kernel(const float *__restrict__ TP, const float *__restrict__ TQ,
                                                           const int32_t *__restrict__ idx, int N, int k, int P,
                                                           const float *__restrict__ gamma, float *__restrict__ usel,
+                                                          float *__restrict__ usum, int32_t *__restrict__ hitn,
                                                           double *__restrict__ partial)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -58,25 +61,41 @@ __global__ __launch_bounds__(256) void edge_reduce_kernel(const float *__restric
         const float q = TQ[(size_t)pt * EC + lane];
         const int32_t *ip = idx + (size_t)pt * k;
         float ext = neg ? __builtin_inff() : -__builtin_inff();
+        float us = 0.0f;
+        int hit = 0;
         for (int j0 = 0; j0 < k; j0 += 64) {
             const int kk = k - j0 < 64 ? k - j0 : 64;
             const int nv = lane < kk ? ip[j0 + lane] : 0;
             for (int j = 0; j < kk; j += 8) {
                 float p[8];
+                int n[8];
 #pragma unroll
                 for (int t = 0; t < 8; ++t)
-                    if (j + t < kk) p[t] = Pb[(size_t)__builtin_amdgcn_readlane(nv, j + t) * EC];
+                    if (j + t < kk) {
+                        n[t] = __builtin_amdgcn_readlane(nv, j + t);
+                        p[t] = Pb[(size_t)n[t] * EC];
+                    }
 #pragma unroll
                 for (int t = 0; t < 8; ++t)
                     if (j + t < kk) {
                         const float u = p[t] + q;
                         acc[0] += (double)u;
                         acc[1] = __builtin_fma((double)u, (double)u, acc[1]);
-                        if (WANT_EXT) ext = neg ? fminf(ext, u) : fmaxf(ext, u);
+                        us += u;
+                        if (WANT_EXT) {
+                            if (neg ? (u < ext) : (u > ext)) {  // strict: the first edge attaining the extreme wins
+                                ext = u;
+                                hit = n[t];
+                            }
+                        }
                     }
             }
         }
-        if (WANT_EXT) usel[(size_t)pt * EC + lane] = ext;
+        usum[(size_t)pt * EC + lane] = us;
+        if (WANT_EXT) {
+            usel[(size_t)pt * EC + lane] = ext;
+            hitn[(size_t)pt * EC + lane] = hit;
+        }
     }
     block_reduce_store<2>(acc, partial);
 }
@@ -240,7 +259,11 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(const float *__restrict__
                 for (int t = 0; t < 8; ++t)
                     if (j + t < kk) {
                         n[t] = __builtin_amdgcn_readlane(nv, j + t);
+#ifdef EDGE_BWD_ABLATE_GATHER  // timing experiment: no TP gather (results are garbage)
+                        p[t] = q;
+#else
                         p[t] = Pb[(size_t)n[t] * EC];
+#endif
                         if (DENSE) d[t] = dv[((size_t)pt * k + j0 + j + t) * EC + lane];
                     }
 #pragma unroll
@@ -255,7 +278,11 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(const float *__restrict__
                             const float uhat = (u - mean) * rstd;
                             const float du = sc * ((DENSE ? d[t] : 0.0f) - c1 - c2 * uhat);
                             dsum += du;
+#ifdef EDGE_BWD_ABLATE_ATOMICS  // timing experiment: no scatter (results are garbage)
+                            if (du == 123.456f) Rb[(size_t)n[t] * EC] = du;
+#else
                             atomicAdd(Rb + (size_t)n[t] * EC, du);
+#endif
                         }
                     }
             }
@@ -267,6 +294,119 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(const float *__restrict__
         }
         dD[(size_t)pt * EC + lane] = dsum;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Training-mode stage-1 backward WITHOUT the TP gather.  With alpha = sc c2 rstd and
+//   A[i] = -sc (c1 + c2 rstd (TQ[i] - mean))              (the part of du that is the same for all k edges of i)
+// the edge gradient is  du[i][j] = sc dv[i][j] + A[i] - alpha TP[n(i, j)],  hence
+//   dR[m] = sum_{(i, j) -> m} (sc dv[i][j] + A[i])  -  alpha indeg(m) TP[m]       (scatter, then edge_r_finish)
+//   dD[i] = sum_j sc dv[i][j] + k A[i] - alpha (usum[i] - k TQ[i])                (usum = sum_j u[i][j], forward)
+// so each edge costs one 256-byte wave-atomic and no gather.  Sparse dv (DENSE = false): the whole dL/dy of
+// (i, c) belongs to the edge whose neighbour is hitn[i][c] (recorded by the forward).
+__global__ void indegree_kernel(const int32_t *__restrict__ idx, int N, int k, size_t E, int *__restrict__ indeg)
+{
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const size_t b = e / ((size_t)N * k);
+    atomicAdd(&indeg[b * N + idx[e]], 1);
+}
+
+template <bool DENSE>
+__global__ __launch_bounds__(256) void edge_scatter_kernel(const float *__restrict__ TQ, const int32_t *__restrict__ idx,
+                                                           int N, int k, int P, const float *__restrict__ stats,
+                                                           const float *__restrict__ cc, float slope,
+                                                           const float *__restrict__ gy, const float *__restrict__ y,
+                                                           const int32_t *__restrict__ hitn,
+                                                           const float *__restrict__ usum,
+                                                           const float *__restrict__ dv, float *__restrict__ dR,
+                                                           float *__restrict__ dD)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float mean = stats[ST_MEAN + lane], rstd = stats[ST_RSTD + lane], sc = stats[ST_SC + lane];
+    const float c1 = cc[lane], c2 = cc[64 + lane];
+    const float alpha = sc * c2 * rstd;
+    const PointIter it = point_iter(P, wave, EDGE_WAVES);
+    for (int pt = it.cur; pt < it.end; pt += it.step) {
+        const int b = pt / N;
+        float *Rb = dR + (size_t)b * N * EC + lane;
+        const float q = TQ[(size_t)pt * EC + lane];
+        const int32_t *ip = idx + (size_t)pt * k;
+        const float A = -sc * (c1 + c2 * rstd * (q - mean));
+        float dvs = 0.0f;
+        int hit = -1;
+        if (!DENSE) {
+            const float yv = y[(size_t)pt * EC + lane];
+            dvs = sc * gy[(size_t)pt * EC + lane] * (yv > 0.0f ? 1.0f : slope);
+            hit = hitn[(size_t)pt * EC + lane];
+        }
+        float dsum = DENSE ? 0.0f : dvs;
+        for (int j0 = 0; j0 < k; j0 += 64) {
+            const int kk = k - j0 < 64 ? k - j0 : 64;
+            const int nv = lane < kk ? ip[j0 + lane] : 0;
+            for (int j = 0; j < kk; j += 8) {
+                float d[8];
+                if (DENSE) {
+#pragma unroll
+                    for (int t = 0; t < 8; ++t)
+                        if (j + t < kk) d[t] = dv[((size_t)pt * k + j0 + j + t) * EC + lane];
+                }
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+                    if (j + t < kk) {
+                        const int n = __builtin_amdgcn_readlane(nv, j + t);
+                        float val = A;
+                        if (DENSE) {
+                            const float sd = sc * d[t];
+                            dsum += sd;
+                            val += sd;
+                        } else if (n == hit) {
+                            val += dvs;
+                        }
+                        atomicAdd(Rb + (size_t)n * EC, val);
+                    }
+            }
+        }
+        dD[(size_t)pt * EC + lane] = dsum + (float)k * A - alpha * (usum[(size_t)pt * EC + lane] - (float)k * q);
+    }
+}
+
+// dR[m] -= alpha * indeg(m) * TP[m]
+__global__ void edge_r_finish_kernel(const float *__restrict__ TP, const int *__restrict__ indeg,
+                                     const float *__restrict__ stats, const float *__restrict__ cc, size_t n4,
+                                     float *__restrict__ dR)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n4) return;
+    const int c = (int)(t & 15) * 4;
+    const float deg = (float)indeg[t >> 4];
+    const float4 p = reinterpret_cast<const float4 *>(TP)[t];
+    float4 r = reinterpret_cast<float4 *>(dR)[t];
+    r.x -= stats[ST_SC + c + 0] * cc[64 + c + 0] * stats[ST_RSTD + c + 0] * deg * p.x;
+    r.y -= stats[ST_SC + c + 1] * cc[64 + c + 1] * stats[ST_RSTD + c + 1] * deg * p.y;
+    r.z -= stats[ST_SC + c + 2] * cc[64 + c + 2] * stats[ST_RSTD + c + 2] * deg * p.z;
+    r.w -= stats[ST_SC + c + 3] * cc[64 + c + 3] * stats[ST_RSTD + c + 3] * deg * p.w;
+    reinterpret_cast<float4 *>(dR)[t] = r;
+}
+
+void launch_edge_bwd_nogather(const float *TP, const float *TQ, const int32_t *idx, int B, int N, int k,
+                              const float *stats, const float *cc, float slope, const float *gy, const float *y,
+                              const int32_t *hitn, const float *usum, const float *dv, int *indeg, float *dR,
+                              float *dD, hipStream_t st)
+{
+    const int P = B * N;
+    const size_t E = (size_t)P * k;
+    hipLaunchKernelGGL(indegree_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, idx, N, k, E, indeg);
+    const dim3 grid(edge_grid(P)), block(256);
+    if (dv)
+        hipLaunchKernelGGL((edge_scatter_kernel<true>), grid, block, 0, st, TQ, idx, N, k, P, stats, cc, slope, gy, y,
+                           hitn, usum, dv, dR, dD);
+    else
+        hipLaunchKernelGGL((edge_scatter_kernel<false>), grid, block, 0, st, TQ, idx, N, k, P, stats, cc, slope, gy, y,
+                           hitn, usum, dv, dR, dD);
+    const size_t n4 = (size_t)P * EC / 4;
+    hipLaunchKernelGGL(edge_r_finish_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, TP, indeg, stats, cc,
+                       n4, dR);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -307,13 +447,15 @@ __global__ void graph_feature_bwd_kernel(const float *__restrict__ gout, const i
 
 // ---------------------------------------------------------------------------------------------
 void launch_edge_reduce(const float *TP, const float *TQ, const int32_t *idx, int N, int k, int P, const float *gamma,
-                        float *usel, double *partial, hipStream_t st)
+                        float *usel, float *usum, int32_t *hitn, double *partial, hipStream_t st)
 {
     const dim3 grid(edge_grid(P)), block(256);
     if (usel)
-        hipLaunchKernelGGL((edge_reduce_kernel<true>), grid, block, 0, st, TP, TQ, idx, N, k, P, gamma, usel, partial);
+        hipLaunchKernelGGL((edge_reduce_kernel<true>), grid, block, 0, st, TP, TQ, idx, N, k, P, gamma, usel, usum, hitn,
+                           partial);
     else
-        hipLaunchKernelGGL((edge_reduce_kernel<false>), grid, block, 0, st, TP, TQ, idx, N, k, P, gamma, usel, partial);
+        hipLaunchKernelGGL((edge_reduce_kernel<false>), grid, block, 0, st, TP, TQ, idx, N, k, P, gamma, usel, usum, hitn,
+                           partial);
 }
 
 void launch_bn_finalize(const double *partial, int nparts, double count, int training, const dgcnn_bn_params &bn,

@@ -135,23 +135,29 @@ __global__ __launch_bounds__(64) void wgrad_kernel(const float *__restrict__ A0,
         }
 }
 
-// out[e] = sum_chunk partial[chunk][e] for e < n.  Block = 256 threads = 4 waves x 64 elements: wave w
-// adds its contiguous quarter of the chunks in order, the four sums are then added in wave order
-// (fixed association: deterministic).
-__global__ __launch_bounds__(256) void sum_partials_kernel(const float *__restrict__ partial, int nchunk, int n,
-                                                           float *__restrict__ out)
+// out[e] = sum_chunk partial[chunk][e] for e < n.  Block = 1024 threads = 16 waves x 64 elements: wave w
+// adds its contiguous share of the chunks in order, the 16 sums are then added in wave order (fixed
+// association: deterministic).
+constexpr int SUM_WAVES = 16;
+__global__ __launch_bounds__(1024) void sum_partials_kernel(const float *__restrict__ partial, int nchunk, int n,
+                                                            float *__restrict__ out)
 {
-    __shared__ float red[4][64];
+    __shared__ float red[SUM_WAVES][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + lane;
-    const int q = (nchunk + 3) / 4;
+    const int q = (nchunk + SUM_WAVES - 1) / SUM_WAVES;
     const int c0 = w * q, c1 = c0 + q < nchunk ? c0 + q : nchunk;
     float s = 0.0f;
     if (e < n)
         for (int ch = c0; ch < c1; ++ch) s += partial[(size_t)ch * n + e];
     red[w][lane] = s;
     __syncthreads();
-    if (w == 0 && e < n) out[e] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    if (w == 0 && e < n) {
+        float t = red[0][lane];
+#pragma unroll
+        for (int i = 1; i < SUM_WAVES; ++i) t += red[i][lane];
+        out[e] = t;
+    }
 }
 
 // gw1 [64][2C] from G = dWcat [128][C]:  c < C: G[o][c] - G[64 + o][c];  c >= C: G[64 + o][c - C]
@@ -210,7 +216,7 @@ void launch_finish_dw1(const float *partial, int nchunk, int C, float *G, float 
 
 void launch_sum_partials(const float *partial, int nchunk, int n, float *out, hipStream_t st)
 {
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(ceil_div(n, 64)), dim3(256), 0, st, partial, nchunk, n, out);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(ceil_div(n, 64)), dim3(1024), 0, st, partial, nchunk, n, out);
 }
 
 }  // namespace dgcnn

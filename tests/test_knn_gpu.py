@@ -76,6 +76,43 @@ def test_knn_full_size_bit_exact(device):
     assert (got[:, :, 0] == np.arange(7000)[None]).all()  # self is neighbour 0 on tie-free data
 
 
+# ---- the fp16 filter + exact refine path (C >= 16, k <= 40, N >= 256) must never change the result -------------
+def _feature_cases():
+    rng = np.random.default_rng(99)
+    B, C, N = 2, 64, 900
+    base = rng.standard_normal((B, C, N)).astype(np.float32)
+    cases = {
+        "offset_1000": base + 1000.0,                       # |mean| >> spread: cancellation in the oracle's fp32 pd
+        "tiny_1e-4": base * 1e-4,                           # fp16 subnormal range after centring
+        "huge_1e4": base * 1e4,                             # centred norms near the fp16 limit
+        "overflow_1e6": base * 1e6,                         # does not fit fp16 -> exact fp32 kernel fallback
+        "one_wide_channel": base * np.concatenate([[3000.0], np.ones(C - 1)]).astype(np.float32)[None, :, None],
+        "post_activation_like": np.maximum(base, 0.2 * base) + 3.0,  # LeakyReLU outputs with a common shift
+        "duplicates": np.concatenate([base[:, :, :450], base[:, :, :450]], axis=2),
+        "clustered": (base * 0.01 + rng.integers(0, 4, size=(B, 1, N)).astype(np.float32) * 5.0),
+        "constant": np.full((B, C, N), 2.5, np.float32),
+    }
+    mixed = base.copy()
+    mixed[0] *= 1e-3
+    mixed[1] = mixed[1] * 50.0 - 7.0
+    cases["mixed_scales_per_batch_element"] = mixed
+    return cases
+
+
+@pytest.mark.parametrize("name", sorted(_feature_cases().keys()))
+def test_knn_f16_filter_path_is_exact(name, device):
+    x = _feature_cases()[name]
+    for k in (8, 30, 40):
+        np.testing.assert_array_equal(_run(x, k, device), ke.knn_exact(x, k), err_msg="%s k=%d" % (name, k))
+
+
+def test_knn_f16_path_c16_c32_c128(device):
+    rng = np.random.default_rng(5)
+    for C in (16, 24, 32, 100, 128):
+        x = (rng.standard_normal((2, C, 700)) * rng.uniform(0.1, 10.0, size=(1, C, 1)) + 2.0).astype(np.float32)
+        np.testing.assert_array_equal(_run(x, 20, device), ke.knn_exact(x, 20), err_msg="C=%d" % C)
+
+
 def test_knn_k_out_of_range(device):
     from ahn3_dgcnn_pytorch_amd import ops
     x = torch.zeros((1, 10, 4), device=device)
