@@ -26,13 +26,13 @@ int edge_grid(int P);
 // (point, channel) extreme of u that survives max-over-k (max if gamma >= 0, min otherwise)
 // usum[i] = sum_j u[i][j]; hitn[i] = neighbour of the first edge attaining the extreme (with usel only)
 void launch_edge_reduce(const float *TP, const float *TQ, const int32_t *idx, int N, int k, int P,
-                        const float *gamma, float *usel, float *usum, int32_t *hitn, double *partial,
-                        hipStream_t st);
-// training-mode stage-1 backward without the TP gather (see edge_stream.hip): indeg is a zero-filled [P] int
-// scratch, dR zero-filled; dv == NULL: sparse dv from (gy, y, hitn); else dense dv [E][64]
+                        const float *gamma, float *usel, float *usum, int32_t *hitn, int *indeg,
+                        double *partial, hipStream_t st);  // indeg: zero-filled [P] or NULL
+// training-mode stage-1 backward without the TP gather (see edge_stream.hip): indeg from the forward's
+// edge_reduce, dR zero-filled; dv == NULL: sparse dv from (gy, y, hitn); else dense dv [E][64]
 void launch_edge_bwd_nogather(const float *TP, const float *TQ, const int32_t *idx, int B, int N, int k,
                               const float *stats, const float *cc, float slope, const float *gy, const float *y,
-                              const int32_t *hitn, const float *usum, const float *dv, int *indeg, float *dR,
+                              const int32_t *hitn, const float *usum, const float *dv, const int *indeg, float *dR,
                               float *dD, hipStream_t st);
 // BatchNorm statistics from the partial sums -> stats[ST_*]; running-statistics update
 void launch_bn_finalize(const double *partial, int nparts, double count, int training, const dgcnn_bn_params &bn,

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void edge_reduce_kernel(const float *__restric
                                                           const int32_t *__restrict__ idx, int N, int k, int P,
                                                           const float *__restrict__ gamma, float *__restrict__ usel,
                                                           float *__restrict__ usum, int32_t *__restrict__ hitn,
-                                                          double *__restrict__ partial)
+                                                          int *__restrict__ indeg, double *__restrict__ partial)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool neg = WANT_EXT ? (gamma[lane] < 0.0f) : false;
@@ -66,6 +66,8 @@ __global__ __launch_bounds__(256) void edge_reduce_kernel(const float *__restric
         for (int j0 = 0; j0 < k; j0 += 64) {
             const int kk = k - j0 < 64 ? k - j0 : 64;
             const int nv = lane < kk ? ip[j0 + lane] : 0;
+            // in-degree of the neighbours (training only): scattered int atomics, hidden under the gather
+            if (indeg && lane < kk) atomicAdd(&indeg[(size_t)b * N + nv], 1);
             for (int j = 0; j < kk; j += 8) {
                 float p[8];
                 int n[8];
@@ -304,14 +306,6 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(const float *__restrict__
 //   dD[i] = sum_j sc dv[i][j] + k A[i] - alpha (usum[i] - k TQ[i])                (usum = sum_j u[i][j], forward)
 // so each edge costs one 256-byte wave-atomic and no gather.  Sparse dv (DENSE = false): the whole dL/dy of
 // (i, c) belongs to the edge whose neighbour is hitn[i][c] (recorded by the forward).
-__global__ void indegree_kernel(const int32_t *__restrict__ idx, int N, int k, size_t E, int *__restrict__ indeg)
-{
-    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= E) return;
-    const size_t b = e / ((size_t)N * k);
-    atomicAdd(&indeg[b * N + idx[e]], 1);
-}
-
 template <bool DENSE>
 __global__ __launch_bounds__(256) void edge_scatter_kernel(const float *__restrict__ TQ, const int32_t *__restrict__ idx,
                                                            int N, int k, int P, const float *__restrict__ stats,
@@ -391,12 +385,10 @@ __global__ void edge_r_finish_kernel(const float *__restrict__ TP, const int *__
 
 void launch_edge_bwd_nogather(const float *TP, const float *TQ, const int32_t *idx, int B, int N, int k,
                               const float *stats, const float *cc, float slope, const float *gy, const float *y,
-                              const int32_t *hitn, const float *usum, const float *dv, int *indeg, float *dR,
+                              const int32_t *hitn, const float *usum, const float *dv, const int *indeg, float *dR,
                               float *dD, hipStream_t st)
 {
     const int P = B * N;
-    const size_t E = (size_t)P * k;
-    hipLaunchKernelGGL(indegree_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, idx, N, k, E, indeg);
     const dim3 grid(edge_grid(P)), block(256);
     if (dv)
         hipLaunchKernelGGL((edge_scatter_kernel<true>), grid, block, 0, st, TQ, idx, N, k, P, stats, cc, slope, gy, y,
@@ -447,15 +439,15 @@ __global__ void graph_feature_bwd_kernel(const float *__restrict__ gout, const i
 
 // ---------------------------------------------------------------------------------------------
 void launch_edge_reduce(const float *TP, const float *TQ, const int32_t *idx, int N, int k, int P, const float *gamma,
-                        float *usel, float *usum, int32_t *hitn, double *partial, hipStream_t st)
+                        float *usel, float *usum, int32_t *hitn, int *indeg, double *partial, hipStream_t st)
 {
     const dim3 grid(edge_grid(P)), block(256);
     if (usel)
         hipLaunchKernelGGL((edge_reduce_kernel<true>), grid, block, 0, st, TP, TQ, idx, N, k, P, gamma, usel, usum, hitn,
-                           partial);
+                           indeg, partial);
     else
         hipLaunchKernelGGL((edge_reduce_kernel<false>), grid, block, 0, st, TP, TQ, idx, N, k, P, gamma, usel, usum, hitn,
-                           partial);
+                           indeg, partial);
 }
 
 void launch_bn_finalize(const double *partial, int nparts, double count, int training, const dgcnn_bn_params &bn,

@@ -41,6 +41,7 @@ struct Carver {
 struct SavedLayout {
     float *TP, *TQ, *usel, *usum, *stats1, *stats2;
     int32_t *hitn;
+    int *indeg;
     size_t bytes;
 };
 static SavedLayout saved_layout(const dgcnn_edgeconv_desc *d, void *p)
@@ -53,6 +54,7 @@ static SavedLayout saved_layout(const dgcnn_edgeconv_desc *d, void *p)
     s.usel = c.take<float>(P * EC);
     s.usum = c.take<float>(P * EC);   // sum over k of the stage-1 pre-activation (backward, training mode)
     s.hitn = c.take<int32_t>(P * EC);  // arg-extreme neighbour of a one-stage block
+    s.indeg = c.take<int>(P);          // in-degree of every point in the kNN graph (training mode)
     s.stats1 = c.take<float>(ST_SIZE);
     s.stats2 = c.take<float>(ST_SIZE);
     s.bytes = c.off;
@@ -78,7 +80,6 @@ static FwdWs fwd_ws(const dgcnn_edgeconv_desc *d, void *p)
 struct BwdWs {
     float *wcatT, *wcat, *cc1, *cc2, *dR, *dD, *wg_partial, *wg_sum, *dv1, *dw2_partial;
     double *partial, *bn1_partial;
-    int *indeg;
     size_t bytes;
 };
 static BwdWs bwd_ws(const dgcnn_edgeconv_desc *d, void *p)
@@ -93,7 +94,6 @@ static BwdWs bwd_ws(const dgcnn_edgeconv_desc *d, void *p)
     w.cc2 = c.take<float>(128);
     w.dR = c.take<float>(P * EC);
     w.dD = c.take<float>(P * EC);
-    w.indeg = c.take<int>(P);
     w.wg_partial = c.take<float>((size_t)wgrad_chunks((int)P) * 128 * d->C);
     w.wg_sum = c.take<float>((size_t)128 * d->C);
     if (d->n_stage == 2) {
@@ -164,13 +164,18 @@ extern "C" int dgcnn_edgeconv_fwd(const dgcnn_edgeconv_desc *d, const float *x, 
     launch_rowgemm(x, C, nullptr, 0, w.wcatT, 128, s.TP, EC, s.TQ, P, st);
     if (d->n_stage == 1) {
         if (!d->training) launch_bn_finalize(w.partial, 0, E, 0, d->bn1, d->eps, d->momentum, s.stats1, st);
-        launch_edge_reduce(s.TP, s.TQ, idx, N, k, P, d->bn1.weight, s.usel, s.usum, s.hitn, w.partial, st);
+        int *indeg = d->training ? s.indeg : nullptr;
+        if (indeg && hipMemsetAsync(indeg, 0, (size_t)P * sizeof(int), st) != hipSuccess)
+            DG_FAIL("dgcnn_edgeconv_fwd: hipMemsetAsync failed");
+        launch_edge_reduce(s.TP, s.TQ, idx, N, k, P, d->bn1.weight, s.usel, s.usum, s.hitn, indeg, w.partial, st);
         if (d->training)
             launch_bn_finalize(w.partial, edge_grid(P), E, 1, d->bn1, d->eps, d->momentum, s.stats1, st);
         launch_edge_out(s.usel, s.stats1, d->slope, P, y, st);
     } else {
         if (d->training) {
-            launch_edge_reduce(s.TP, s.TQ, idx, N, k, P, d->bn1.weight, nullptr, s.usum, nullptr, w.partial, st);
+            if (hipMemsetAsync(s.indeg, 0, (size_t)P * sizeof(int), st) != hipSuccess)
+                DG_FAIL("dgcnn_edgeconv_fwd: hipMemsetAsync failed");
+            launch_edge_reduce(s.TP, s.TQ, idx, N, k, P, d->bn1.weight, nullptr, s.usum, nullptr, s.indeg, w.partial, st);
             launch_bn_finalize(w.partial, edge_grid(P), E, 1, d->bn1, d->eps, d->momentum, s.stats1, st);
         } else {
             launch_bn_finalize(w.partial, 0, E, 0, d->bn1, d->eps, d->momentum, s.stats1, st);
@@ -207,10 +212,8 @@ extern "C" int dgcnn_edgeconv_bwd(const dgcnn_edgeconv_desc *d, const float *x, 
     if (d->n_stage == 1) {
         launch_bwd_point(gy, s.usel, s.stats1, d->slope, P, E, d->training, w.partial, g->gbn1_w, g->gbn1_b, w.cc1, st);
         if (d->training) {
-            if (hipMemsetAsync(w.indeg, 0, (size_t)P * sizeof(int), st) != hipSuccess)
-                DG_FAIL("dgcnn_edgeconv_bwd: hipMemsetAsync failed");
             launch_edge_bwd_nogather(s.TP, s.TQ, idx, d->B, N, k, s.stats1, w.cc1, d->slope, gy, y, s.hitn, s.usum, nullptr,
-                                     w.indeg, w.dR, w.dD, st);
+                                     s.indeg, w.dR, w.dD, st);
         } else {
             launch_edge_bwd(s.TP, s.TQ, idx, N, k, P, s.stats1, w.cc1, d->slope, d->training, gy, y, nullptr, w.dR, w.dD,
                             st);
@@ -222,10 +225,8 @@ extern "C" int dgcnn_edgeconv_bwd(const dgcnn_edgeconv_desc *d, const float *x, 
         launch_sum_partials(w.dw2_partial, mlp_grid(P), EC * EC, g->gw2, st);
         launch_bn_bwd_finalize(w.bn1_partial, mlp_grid(P), E, d->training, g->gbn1_w, g->gbn1_b, w.cc1, st);
         if (d->training) {
-            if (hipMemsetAsync(w.indeg, 0, (size_t)P * sizeof(int), st) != hipSuccess)
-                DG_FAIL("dgcnn_edgeconv_bwd: hipMemsetAsync failed");
             launch_edge_bwd_nogather(s.TP, s.TQ, idx, d->B, N, k, s.stats1, w.cc1, d->slope, gy, y, nullptr, s.usum, w.dv1,
-                                     w.indeg, w.dR, w.dD, st);
+                                     s.indeg, w.dR, w.dD, st);
         } else {
             launch_edge_bwd(s.TP, s.TQ, idx, N, k, P, s.stats1, w.cc1, d->slope, d->training, gy, y, w.dv1, w.dR, w.dD, st);
         }
