@@ -383,6 +383,16 @@ __global__ void edge_r_finish_kernel(const float *__restrict__ TP, const int *__
     reinterpret_cast<float4 *>(dR)[t] = r;
 }
 
+// ---- measurement hook: events around the scatter kernel (dgcnn_profile_* in dgcnn_hip.h) ----------------
+namespace {
+constexpr int PROF_MAX = 256;
+struct ProfState {
+    bool on = false, created = false;
+    int n = 0;
+    hipEvent_t e0[PROF_MAX], e1[PROF_MAX];
+} g_prof;
+}  // namespace
+
 void launch_edge_bwd_nogather(const float *TP, const float *TQ, const int32_t *idx, int B, int N, int k,
                               const float *stats, const float *cc, float slope, const float *gy, const float *y,
                               const int32_t *hitn, const float *usum, const float *dv, const int *indeg, float *dR,
@@ -390,12 +400,15 @@ void launch_edge_bwd_nogather(const float *TP, const float *TQ, const int32_t *i
 {
     const int P = B * N;
     const dim3 grid(edge_grid(P)), block(256);
+    const bool prof = g_prof.on && g_prof.n < PROF_MAX;
+    if (prof) (void)hipEventRecord(g_prof.e0[g_prof.n], st);
     if (dv)
         hipLaunchKernelGGL((edge_scatter_kernel<true>), grid, block, 0, st, TQ, idx, N, k, P, stats, cc, slope, gy, y,
                            hitn, usum, dv, dR, dD);
     else
         hipLaunchKernelGGL((edge_scatter_kernel<false>), grid, block, 0, st, TQ, idx, N, k, P, stats, cc, slope, gy, y,
                            hitn, usum, dv, dR, dD);
+    if (prof) (void)hipEventRecord(g_prof.e1[g_prof.n++], st);
     const size_t n4 = (size_t)P * EC / 4;
     hipLaunchKernelGGL(edge_r_finish_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, TP, indeg, stats, cc,
                        n4, dR);
@@ -509,3 +522,32 @@ void launch_graph_feature_bwd(const float *gout, const int32_t *idx, int B, int 
 }
 
 }  // namespace dgcnn
+
+extern "C" int dgcnn_profile_enable(int on)
+{
+    auto &p = dgcnn::g_prof;
+    if (on && !p.created) {
+        for (int i = 0; i < dgcnn::PROF_MAX; ++i) {
+            if (hipEventCreate(&p.e0[i]) != hipSuccess || hipEventCreate(&p.e1[i]) != hipSuccess) return 1;
+        }
+        p.created = true;
+    }
+    p.on = on != 0;
+    p.n = 0;
+    return 0;
+}
+
+extern "C" int dgcnn_profile_samples(void) { return dgcnn::g_prof.n; }
+
+extern "C" float dgcnn_profile_mean_ms(void)
+{
+    auto &p = dgcnn::g_prof;
+    if (p.n == 0) return 0.0f;
+    float sum = 0.0f;
+    for (int i = 0; i < p.n; ++i) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, p.e0[i], p.e1[i]) != hipSuccess) return -1.0f;
+        sum += ms;
+    }
+    return sum / (float)p.n;
+}

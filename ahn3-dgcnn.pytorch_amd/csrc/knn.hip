@@ -214,6 +214,7 @@ __device__ __forceinline__ float compact_row(u64 *kr, int c, int k, int lane)
 // ------------------------------------------------------------------------------------
 // pre-pass helpers
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // approximate centre of one batch element (any vector works: distances are translation invariant;
 // centring only tightens the fp16 error bound): mean of the first <= 256 points.
@@ -479,6 +480,115 @@ __global__ __launch_bounds__(64) void knn_bound_kernel(const void *__restrict__ 
     }
 }
 
+// ---- fp16 streams with operand tiles shared through LDS ------------------------------------------------
+// Both fp16 all-pairs streams (threshold pre-pass and filter) are bound by L2 -> CU operand traffic when every
+// wave fetches every candidate tile itself (1760 waves x 0.9 MB = 1.55 GB per pass at B = 8, N = 7000, C = 64).
+// Here a workgroup = 4 waves = 128 query rows stages each chunk of KNN_ST_TILES candidate tiles once in LDS
+// (already in MFMA operand order, so the ds_read_b128 of a wave is contiguous and conflict-free) and all four
+// waves consume it: a quarter of the traffic, one barrier per chunk, register-prefetched double buffer.
+constexpr int KNN_ST_TILES = 4;  // candidate tiles per staged chunk (Npad / 32 is a multiple of 4)
+
+template <int KS>
+struct Stage16 {
+    static constexpr int VEC_PER_CHUNK = KNN_ST_TILES * KS * 64;  // half8 vectors per chunk
+    static constexpr int VPT = VEC_PER_CHUNK / 256;               // per thread (256 threads)
+    half8 reg[VPT];
+    __device__ __forceinline__ void gload(const half8 *__restrict__ xbatch, int chunk, int tid)
+    {
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) reg[i] = xbatch[(size_t)chunk * VEC_PER_CHUNK + i * 256 + tid];
+    }
+    __device__ __forceinline__ void swrite(half8 *__restrict__ buf, int tid) const
+    {
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) buf[i * 256 + tid] = reg[i];
+    }
+};
+
+template <int CP>
+__global__ __launch_bounds__(256) void knn_bound16s_kernel(const half8 *__restrict__ xh, const float *__restrict__ xxc,
+                                                           const float *__restrict__ xx_raw,
+                                                           const unsigned *__restrict__ bmax, int B, int Npad, int k,
+                                                           float *__restrict__ tau0, float *__restrict__ epsr)
+{
+    constexpr int KS = CP / 16;
+    __shared__ half8 sbuf[2][Stage16<KS>::VEC_PER_CHUNK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, j32 = lane & 31;
+    const int b = blockIdx.x % B, rb = (blockIdx.x / B) * 4 + wave;  // this wave's row tile
+    const int ntiles = Npad / 32, nchunks = ntiles / KNN_ST_TILES;
+    const half8 *xbatch = xh + (size_t)b * ntiles * KS * 64;
+    const float *yb = xxc + (size_t)b * Npad;
+
+    half8 a[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) a[ks] = xbatch[((size_t)rb * KS + ks) * 64 + lane];
+    // class maxima of t = 2 d16 - yy_l: candidate tiles 4g, 4g+1 feed m0, tiles 4g+2, 4g+3 feed m1 (64 classes
+    // per row with the 32 candidate lanes); packed fp32 pairs: 8 v_pk_fma + 8 v_max3 per tile pair
+    f32x2 m0[8], m1[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) m0[i] = m1[i] = f32x2{-__builtin_inff(), -__builtin_inff()};
+
+    Stage16<KS> st;
+    st.gload(xbatch, 0, tid);
+    st.swrite(sbuf[0], tid);
+    float ycur[KNN_ST_TILES], ynext[KNN_ST_TILES];
+#pragma unroll
+    for (int tt = 0; tt < KNN_ST_TILES; ++tt) ycur[tt] = yb[tt * 32 + j32];
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int cn = c + 1 < nchunks ? c + 1 : c;  // clamped prefetch: no branch around the loads
+        st.gload(xbatch, cn, tid);
+#pragma unroll
+        for (int tt = 0; tt < KNN_ST_TILES; ++tt) ynext[tt] = yb[(cn * KNN_ST_TILES + tt) * 32 + j32];
+        const half8 *cur = sbuf[c & 1];
+        f32x16 acc[KNN_ST_TILES];
+#pragma unroll
+        for (int tt = 0; tt < KNN_ST_TILES; ++tt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tt][r] = 0.0f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks], cur[(tt * KS + ks) * 64 + lane], acc[tt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const f32x2 two = f32x2{2.0f, 2.0f};
+            const f32x2 t0 = __builtin_elementwise_fma(f32x2{acc[0][2 * i], acc[0][2 * i + 1]}, two, f32x2{-ycur[0], -ycur[0]});
+            const f32x2 t1 = __builtin_elementwise_fma(f32x2{acc[1][2 * i], acc[1][2 * i + 1]}, two, f32x2{-ycur[1], -ycur[1]});
+            const f32x2 t2 = __builtin_elementwise_fma(f32x2{acc[2][2 * i], acc[2][2 * i + 1]}, two, f32x2{-ycur[2], -ycur[2]});
+            const f32x2 t3 = __builtin_elementwise_fma(f32x2{acc[3][2 * i], acc[3][2 * i + 1]}, two, f32x2{-ycur[3], -ycur[3]});
+            m0[i] = __builtin_elementwise_max(m0[i], __builtin_elementwise_max(t0, t1));
+            m1[i] = __builtin_elementwise_max(m1[i], __builtin_elementwise_max(t2, t3));
+        }
+        st.swrite(sbuf[(c + 1) & 1], tid);
+#pragma unroll
+        for (int tt = 0; tt < KNN_ST_TILES; ++tt) ycur[tt] = ynext[tt];
+        __syncthreads();
+    }
+
+    // k-th largest of the 64 class maxima of every row, minus the row's own norm and the error bound
+    const float cmax = __uint_as_float(bmax[2 * b + 0]), rmax = __uint_as_float(bmax[2 * b + 1]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float other = __uint_as_float(xchg32<32>(__float_as_uint(m1[r >> 1][r & 1])));
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            unsigned key = f32_to_ordered((h == hh) ? m0[r >> 1][r & 1] : other);
+            bitonic32_sort<64>(key, lane);
+            const unsigned kth = __builtin_amdgcn_readlane(key, k - 1);
+            const float vk = __uint_as_float((kth & 0x80000000u) ? (kth & 0x7fffffffu) : ~kth);
+            const int row = rb * 32 + mfma32_row(r, hh);
+            const float xi = yb[row], xr = xx_raw[(size_t)b * Npad + row];
+            const float eps = knn_f16_eps(xi, cmax, xr, rmax);
+            const float t = (vk - xi) - eps;
+            if (lane == 0) {
+                tau0[(size_t)b * Npad + row] = (t != t) ? -__builtin_inff() : t;  // NaN -> no bound
+                epsr[(size_t)b * Npad + row] = eps;
+            }
+        }
+    }
+}
+
 template <int CP, int CAP>
 __global__ __launch_bounds__(64, 2) void knn_kernel(const float *__restrict__ xt, const float *__restrict__ xx,
                                                     const float *__restrict__ tau0, const int *__restrict__ rbflag,
@@ -721,20 +831,21 @@ constexpr int KNN_QCAP = 256;     // LDS staging ring of the filter kernel (entr
 constexpr int KNN_LISTCAP = 4096;  // survivor list per 32-row block in HBM (128 per row on average)
 
 template <int CP>
-__global__ __launch_bounds__(64) void knn_filter16_kernel(const half8 *__restrict__ xh, const float *__restrict__ xxc,
-                                                          const float *__restrict__ tau0,
-                                                          const float *__restrict__ epsr,
-                                                          const int *__restrict__ f16ok, int B, int Npad,
-                                                          unsigned *__restrict__ lists, int *__restrict__ lcount,
-                                                          int *__restrict__ rbflag)
+__global__ __launch_bounds__(256) void knn_filter16_kernel(const half8 *__restrict__ xh, const float *__restrict__ xxc,
+                                                           const float *__restrict__ tau0,
+                                                           const float *__restrict__ epsr,
+                                                           const int *__restrict__ f16ok, int B, int Npad,
+                                                           unsigned *__restrict__ lists, int *__restrict__ lcount,
+                                                           int *__restrict__ rbflag)
 {
     constexpr int KS = CP / 16;
-    __shared__ unsigned queue[KNN_QCAP];
-    const int lane = threadIdx.x, h = lane >> 5, j32 = lane & 31;
-    const int b = blockIdx.x % B, rb = blockIdx.x / B;
-    const int ntiles = Npad / 32;
-    const int wid = b * ntiles + rb;  // row block id
-    if (!f16ok[b]) {
+    __shared__ half8 sbuf[2][Stage16<KS>::VEC_PER_CHUNK];
+    __shared__ unsigned queues[4][KNN_QCAP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, j32 = lane & 31;
+    const int b = blockIdx.x % B, rb = (blockIdx.x / B) * 4 + wave;  // this wave's row block
+    const int ntiles = Npad / 32, nchunks = ntiles / KNN_ST_TILES;
+    const int wid = b * ntiles + rb;
+    if (!f16ok[b]) {  // uniform over the workgroup
         if (lane == 0) {
             rbflag[wid] = 1;
             lcount[wid] = 0;
@@ -742,13 +853,14 @@ __global__ __launch_bounds__(64) void knn_filter16_kernel(const half8 *__restric
         return;
     }
     const int q0 = rb * 32;
-    const half8 *xb = xh + (size_t)b * ntiles * KS * 64 + lane;
+    const half8 *xbatch = xh + (size_t)b * ntiles * KS * 64;
     const float *yb = xxc + (size_t)b * Npad;
     unsigned *list = lists + (size_t)wid * KNN_LISTCAP;
+    unsigned *queue = queues[wave];
 
     half8 a[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) a[ks] = xb[((size_t)rb * KS + ks) * 64];
+    for (int ks = 0; ks < KS; ++ks) a[ks] = xbatch[((size_t)rb * KS + ks) * 64 + lane];
     // filter threshold on t = 2 d16 - yy_l:  t > (tau0 - eps) + yy_i, lowered by the rounding of this very sum
     float thrp[16];
 #pragma unroll
@@ -778,48 +890,55 @@ __global__ __launch_bounds__(64) void knn_filter16_kernel(const half8 *__restric
         qn = rest;
     };
 
-    // tiles two ahead are in flight while one is computed: the stream is bound by L2 latency x bandwidth
-    half8 b0[KS], b1[KS], b2[KS];
-    float y0, y1, y2;
-    auto fetch = [&](int t, half8(&dst)[KS], float &y) {
-        const int tc = t < ntiles ? t : ntiles - 1;  // clamped: no branch around the loads
+    Stage16<KS> st;
+    st.gload(xbatch, 0, tid);
+    st.swrite(sbuf[0], tid);
+    float ycur[KNN_ST_TILES], ynext[KNN_ST_TILES];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) dst[ks] = xb[((size_t)tc * KS + ks) * 64];
-        y = yb[tc * 32 + j32];
-    };
-    auto tile = [&](const half8(&bop)[KS], float yl, int cand) {
-        f32x16 acc;
+    for (int tt = 0; tt < KNN_ST_TILES; ++tt) ycur[tt] = yb[tt * 32 + j32];
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int cn = c + 1 < nchunks ? c + 1 : c;  // clamped prefetch: no branch around the loads
+        st.gload(xbatch, cn, tid);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        for (int tt = 0; tt < KNN_ST_TILES; ++tt) ynext[tt] = yb[(cn * KNN_ST_TILES + tt) * 32 + j32];
+        const half8 *cur = sbuf[c & 1];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks], bop[ks], acc, 0, 0, 0);
+        for (int tt = 0; tt < KNN_ST_TILES; ++tt) {
+            f32x16 acc;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float t = __builtin_fmaf(2.0f, acc[r], -yl);
-            const bool pass = t > thrp[r];
-            const u64 m = __ballot(pass);
-            if (__builtin_expect(m != 0, 0)) {
-                if (qn > KNN_QCAP - 64) {  // room for a full register of survivors (loose thresholds only)
-                    while (qn >= 64) flush(64);
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks], cur[(tt * KS + ks) * 64 + lane], acc, 0, 0, 0);
+            const int cand = (c * KNN_ST_TILES + tt) * 32 + j32;
+            f32x2 tp[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                tp[i] = __builtin_elementwise_fma(f32x2{acc[2 * i], acc[2 * i + 1]}, f32x2{2.0f, 2.0f},
+                                                  f32x2{-ycur[tt], -ycur[tt]});
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float t = tp[r >> 1][r & 1];
+                const bool pass = t > thrp[r];
+                const u64 m = __ballot(pass);
+                if (__builtin_expect(m != 0, 0)) {
+                    if (qn > KNN_QCAP - 64) {  // room for a full register of survivors (loose thresholds only)
+                        while (qn >= 64) flush(64);
+                    }
+                    if (pass) {
+                        const int off = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+                        queue[qn + off] = ((unsigned)mfma32_row(r, h) << 27) | (unsigned)cand;
+                    }
+                    qn += __popcll(m);
                 }
-                if (pass) {
-                    const int off = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-                    queue[qn + off] = ((unsigned)mfma32_row(r, h) << 27) | (unsigned)cand;
-                }
-                qn += __popcll(m);
             }
+            if (qn >= 64) flush(64);
         }
-        if (qn >= 64) flush(64);
-    };
-    fetch(0, b0, y0);
-    fetch(1, b1, y1);
-    for (int t = 0; t < ntiles; t += 3) {
-        fetch(t + 2, b2, y2);
-        tile(b0, y0, t * 32 + j32);
-        fetch(t + 3, b0, y0);
-        if (t + 1 < ntiles) tile(b1, y1, (t + 1) * 32 + j32);
-        fetch(t + 4, b1, y1);
-        if (t + 2 < ntiles) tile(b2, y2, (t + 2) * 32 + j32);
+        st.swrite(sbuf[(c + 1) & 1], tid);
+#pragma unroll
+        for (int tt = 0; tt < KNN_ST_TILES; ++tt) ycur[tt] = ynext[tt];
+        __syncthreads();
     }
     while (qn > 0) flush(qn < 64 ? qn : 64);
     if (lane == 0) {
@@ -1016,8 +1135,8 @@ static void knn_f16_launch(int cap, const KnnWs &w, const float *x, int B, int N
                            hipStream_t st)
 {
     const dim3 grid(B * (Npad / 32)), block(64);
-    hipLaunchKernelGGL((knn_filter16_kernel<CP>), grid, block, 0, st, w.xh, w.xxc, w.tau0, w.eps, w.f16ok, B, Npad, w.lists,
-                       w.lcount, w.rbflag);
+    hipLaunchKernelGGL((knn_filter16_kernel<CP>), dim3(B * (Npad / 128)), dim3(256), 0, st, w.xh, w.xxc, w.tau0, w.eps,
+                       w.f16ok, B, Npad, w.lists, w.lcount, w.rbflag);
     if (cap == 64)
         hipLaunchKernelGGL((knn_refine_kernel<CP, 64>), grid, block, 0, st, x, w.xx, w.lists, w.lcount, w.rbflag, B, N, C,
                            Npad, k, idx);
@@ -1078,12 +1197,16 @@ extern "C" int dgcnn_knn(const float *x, int B, int N, int C, int k, int32_t *id
                                Npad, CP, w.xh);
             hipLaunchKernelGGL(knn_cnorm_kernel, dim3(Npad / 16, B), dim3(256), 0, st, x, w.mu, N, C, Npad, w.xxc);
             hipLaunchKernelGGL(knn_bmax_kernel, dim3(B), dim3(1024), 0, st, w.xxc, xx, N, Npad, w.bmax, w.f16ok);
+            const dim3 bgrid(B * (Npad / 128)), bblock(256);
+#define DG_BOUND16(CP_) \
+    hipLaunchKernelGGL((knn_bound16s_kernel<CP_>), bgrid, bblock, 0, st, w.xh, w.xxc, xx, w.bmax, B, Npad, k, w.tau0, w.eps)
             switch (CP) {
-                case 16: knn_bound_launch<16, true>(B, st, w.xh, w.xxc, xx, w.bmax, Npad, k, w.tau0, w.eps); break;
-                case 32: knn_bound_launch<32, true>(B, st, w.xh, w.xxc, xx, w.bmax, Npad, k, w.tau0, w.eps); break;
-                case 64: knn_bound_launch<64, true>(B, st, w.xh, w.xxc, xx, w.bmax, Npad, k, w.tau0, w.eps); break;
-                default: knn_bound_launch<128, true>(B, st, w.xh, w.xxc, xx, w.bmax, Npad, k, w.tau0, w.eps); break;
+                case 16: DG_BOUND16(16); break;
+                case 32: DG_BOUND16(32); break;
+                case 64: DG_BOUND16(64); break;
+                default: DG_BOUND16(128); break;
             }
+#undef DG_BOUND16
         } else if (CP == 8) {
             knn_bound_launch<8, false>(B, st, xt, xx, xx, w.bmax, Npad, k, w.tau0, nullptr);
         } else {

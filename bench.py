@@ -12,8 +12,10 @@ every rank runs that workload on its own shard (weak scaling: the batch elements
 units) and the step ends with one RCCL all-reduce of the flat parameter-gradient buffer.
 
 Rank 0 prints ONE JSON line (the contract of the build prompt) with two extra objects:
-  roofline     -- the dominant kernel (knn_kernel): algorithmic FLOPs / its HIP-event time, against
-                  the fp32 MFMA peak of MI355X_MICROARCH.md
+  roofline     -- the dominant kernel (edge_scatter_kernel, the scatter-add of the first convolution's
+                  backward): algorithmic bytes / its HIP-event time (events recorded inside the C ABI on
+                  the launch stream), against the HBM peak of MI355X_MICROARCH.md; the kNN graph build
+                  (three kernels) is reported beside it as `knn`
   cpu_baseline -- oracle/torch_ref.py (the reference's own PyTorch-CPU op sequence) timed on the
                   host cores of the same box on a bounded sample of the same workload
 """
@@ -31,6 +33,8 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md, "HBM3E peak BW" (spec; 6.29 TB/s measured by a float4 copy)
+PEAK_F32_ATOMIC_GBS = 1300.0  # MI355X_MICROARCH.md, "Global float atomics": chip-wide rate of added bytes
 
 
 def make_edge_stage(cin, cout=64):
@@ -51,12 +55,16 @@ def make_stages(C, n_stage, device):
     return stages
 
 
-def cpu_baseline(B, N, k, C, n_stage, steps=2):
+def cpu_baseline(B, N, k, C, n_stage, steps=4):
     """The reference's CPU path (restated op-for-op in oracle/torch_ref.py: materialised BxNxN
     distances, topk, gather/repeat/cat, Conv2d, BatchNorm2d, LeakyReLU, max) fwd+bwd on the host."""
     from oracle import torch_ref
     from param_fill import cotangent
-    nthreads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # measured on the MI355X box's host (256 hardware threads): 8 / 16 / 32 / 64 / 128 / 256 threads give
+    # 20.6 / 20.4 / 25.1 / 19.0 / 12.0 / 3.9 k points/s, so the baseline runs at its best setting, 32
+    # (the reference's own default is 8, train.py:36)
+    nthreads = min(avail, 32)
     torch.set_num_threads(nthreads)
     stages = make_stages(C, n_stage, torch.device("cpu"))
     x = torch.randn(B, C, N, generator=torch.Generator().manual_seed(0))
@@ -74,7 +82,8 @@ def cpu_baseline(B, N, k, C, n_stage, steps=2):
     dt = time.perf_counter() - t0
     return {"value": B * N * steps / dt, "unit": "points/s", "cores": nthreads, "kind": "port",
             "sample": "B=%d of the workload's 8 batch elements (same N=%d, k=%d, C=%d, %d-stage block), "
-                      "%d fwd+bwd steps after 1 warm-up, %.1f s" % (B, N, k, C, n_stage, steps, dt)}
+                      "%d fwd+bwd steps after 1 warm-up, %.1f s, torch %s with %d of %d hardware threads" % (
+                          B, N, k, C, n_stage, steps, dt, torch.__version__, nthreads, avail)}
 
 
 def main():
@@ -89,7 +98,7 @@ def main():
     ap.add_argument("--k", type=int, default=30)
     ap.add_argument("--channels", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-batch", type=int, default=4)
+    ap.add_argument("--cpu-sample-batch", type=int, default=8)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -104,7 +113,7 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
 
-    from ahn3_dgcnn_pytorch_amd import ops
+    from ahn3_dgcnn_pytorch_amd import _lib, ops
     from ahn3_dgcnn_pytorch_amd.parallel import FlatGradAllReduce
     from param_fill import cotangent
 
@@ -142,6 +151,8 @@ def main():
     for _ in range(args.warmup):
         step(False)
     fence()
+    lib = _lib.load()
+    lib.dgcnn_profile_enable(1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
@@ -153,11 +164,18 @@ def main():
         dt = float(t.item())
 
     knn_ms = sum(a.elapsed_time(b) for a, b in knn_events) / max(1, len(knn_events))
+    scatter_ms = float(lib.dgcnn_profile_mean_ms())
+    scatter_n = int(lib.dgcnn_profile_samples())
+    lib.dgcnn_profile_enable(0)
     if rank == 0:
-        flops = 2.0 * B * N * N * C  # FLOPs_kNN = 2 B N^2 C per launch
-        achieved = flops / (knn_ms * 1e-3) / 1e12
+        P, E = B * N, B * N * k
+        # algorithmic bytes of one edge_scatter_kernel launch: one fp32 [64] row added per
+        # edge, the neighbour index of every edge, and per point the rows TQ, gy, y, hitn, usum (read) and dD (written)
+        scatter_bytes = 4.0 * E * 64 + 4.0 * E + 6 * 4.0 * P * 64
+        achieved = scatter_bytes / (scatter_ms * 1e-3) / 1e9 if scatter_ms > 0 else 0.0
+        knn_flops = 2.0 * B * N * N * C  # FLOPs_kNN = 2 B N^2 C
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "knn_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "scatter_traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as f:
                 traffic = json.load(f).get("hbm_bytes_per_launch")
@@ -179,10 +197,17 @@ def main():
                                    (" + conv 64->64 + BN + LeakyReLU" if args.stages == 2 else ""),
                        "batch_per_gpu": B, "points": N, "k": k, "channels": C, "stages": args.stages,
                        "parallelism": "dp%d (batch elements sharded, one all-reduce of the flat grad buffer)" % world},
-            "roofline": {"bound": "mfma", "kernel": "knn_kernel (fused fp32-MFMA distances + streaming top-k)",
-                         "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                         "kernel_ms": knn_ms, "algorithmic_flops_per_launch": flops},
+            "roofline": {"bound": "hbm", "kernel": "edge_scatter_kernel (scatter-add of the first conv's backward, "
+                                                    "global_atomic_add_f32, one 256-B row per edge)",
+                         "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
+                         "traffic": traffic, "kernel_ms": scatter_ms, "samples": scatter_n,
+                         "algorithmic_bytes_per_launch": scatter_bytes,
+                         "float_atomic_rate": {"achieved": 4.0 * E * 64 / (scatter_ms * 1e-3) / 1e9 if scatter_ms > 0 else 0.0,
+                                               "peak": PEAK_F32_ATOMIC_GBS, "unit": "GB/s of added bytes"}},
+            "knn": {"ms": knn_ms, "algorithmic_flops": knn_flops, "tflops": knn_flops / (knn_ms * 1e-3) / 1e12,
+                    "frac_of_f32_mfma_peak": knn_flops / (knn_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                    "note": "whole dgcnn_knn call (prep + fp16 threshold pass + fp16 filter + exact fp32 refine); "
+                            "most of the distance arithmetic runs on fp16 MFMA, the result is bit-exact fp32"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(min(args.cpu_sample_batch, B), N, k, C, args.stages)

@@ -126,6 +126,15 @@ int dgcnn_edgeconv_bwd(const dgcnn_edgeconv_desc *d, const float *x, const int32
                        const dgcnn_edgeconv_grads *g, void *workspace, size_t workspace_bytes,
                        void *stream);
 
+/* ---- measurement hook (bench.py) ----------------------------------------------------------------------
+ * HIP events around the DOMINANT kernel of the EdgeConv path (edge_scatter_kernel, the scatter-add of the
+ * first convolution's backward), recorded on the stream the kernel is launched on.  enable(1) resets the
+ * sample ring; mean_ms() returns the mean kernel time of the samples recorded since (call it after the
+ * stream has been synchronised; at most 256 samples are kept).  No effect on results. */
+int dgcnn_profile_enable(int on);
+float dgcnn_profile_mean_ms(void);
+int dgcnn_profile_samples(void);
+
 #ifdef __cplusplus
 }
 #endif
