@@ -29,6 +29,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+# keep rank 0's stdout to the one JSON line: RCCL's version banner is not an error
+if os.environ.get("NCCL_DEBUG", "VERSION").upper() in ("VERSION", "INFO"):
+    os.environ["NCCL_DEBUG"] = "WARN"
+
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -110,8 +114,9 @@ def main():
         raise SystemExit("bench.py needs a HIP device (the EdgeConv path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ  # under torch.distributed.run
+    if world > 1 or launched:
+        dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
 
     from ahn3_dgcnn_pytorch_amd import _lib, ops
     from ahn3_dgcnn_pytorch_amd.parallel import FlatGradAllReduce
@@ -144,7 +149,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -158,7 +163,7 @@ def main():
         step(True)
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -213,7 +218,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(min(args.cpu_sample_batch, B), N, k, C, args.stages)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
