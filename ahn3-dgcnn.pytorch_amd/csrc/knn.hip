@@ -217,7 +217,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // approximate centre of one batch element (any vector works: distances are translation invariant;
-// centring only tightens the fp16 error bound): mean of the first <= 256 points.
+// centring only tightens the fp16 error bound): mean of the first <= 64 points.
 __global__ __launch_bounds__(256) void knn_center_kernel(const float *__restrict__ x, int N, int C,
                                                          float *__restrict__ mu)
 {
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void knn_center_kernel(const float *__restrict
     const int b = blockIdx.x;
     const int G = 256 / C > 0 ? 256 / C : 1;  // C <= 128
     const int c = threadIdx.x % C, g = threadIdx.x / C;
-    const int n1 = N < 256 ? N : 256;
+    const int n1 = N < 64 ? N : 64;
     float s = 0.0f;
     if (g < G)
         for (int n = g; n < n1; n += G) s += x[((size_t)b * N + n) * C + c];

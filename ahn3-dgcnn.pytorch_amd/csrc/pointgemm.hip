@@ -29,8 +29,13 @@ __global__ void prep_wcat_kernel(const float *__restrict__ w1, int C, int Ke, fl
 }
 
 // One wave = one 32-row tile of points x all NO (<= 32 NT) output columns.
-// MFMA operand maps (32x32x2): A lane (i, h) = A[row i][k = 2 s + h];  B lane (n, h) = B[k = 2 s + h][col n];
-// C/D lane (n, h), register r = D[row mfma32_row(r, h)][col n].
+// MFMA operand maps (32x32x2): A lane (i, h) = A[row i][k(s, h)];  B lane (n, h) = B[k(s, h)][col n];
+// C/D lane (n, h), register r = D[row mfma32_row(r, h)][col n].  The contraction order is free here
+// (tolerance-gated, not bit-gated), so lane-half h takes the h-th HALF of the K range:
+// k(s, h) = h * KH + s with KH = ceil(K / 2): every lane reads its row's KH values as one contiguous run
+// (a handful of 16-byte loads per row instead of one strided dword per MFMA step).
+constexpr int RG_KH_MAX = 64;  // K0 + K1 <= 128
+
 template <int NT>
 __global__ __launch_bounds__(256) void rowgemm_kernel(const float *__restrict__ A0, int K0,
                                                       const float *__restrict__ A1, int K1,
@@ -41,7 +46,7 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(const float *__restrict__ 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, i32 = lane & 31;
     const int p0 = (blockIdx.x * 4 + wave) * 32;
     if (p0 >= P) return;
-    const int K = K0 + K1, steps = (K + 1) >> 1;
+    const int K = K0 + K1, KH = (K + 1) >> 1;
     const int row = p0 + i32;
     const bool rv = row < P;
     f32x16 acc[NT];
@@ -50,16 +55,35 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(const float *__restrict__ 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
 
-#pragma unroll 2
-    for (int s = 0; s < steps; ++s) {
-        const int kk = 2 * s + h;
-        float a = 0.0f;
-        if (rv && kk < K) a = (kk < K0) ? A0[(size_t)row * K0 + kk] : A1[(size_t)row * K1 + (kk - K0)];
+    // this lane's K values: k = h * KH + s, s < KH (zero beyond K or beyond P)
+    auto a_at = [&](int kk) -> float {
+        if (!rv || kk >= K) return 0.0f;
+        return (kk < K0) ? A0[(size_t)row * K0 + kk] : A1[(size_t)row * K1 + (kk - K0)];
+    };
+    for (int s0 = 0; s0 < KH; s0 += 8) {
+        float a[8];
+        const int kb = h * KH + s0;
+        // fast path: 8 contiguous, 16-byte aligned values inside one source array
+        const bool in0 = kb + 8 <= K0 && (K0 & 3) == 0 && (kb & 3) == 0;
+        const bool in1 = kb >= K0 && kb + 8 <= K && (K1 & 3) == 0 && ((kb - K0) & 3) == 0;
+        if (s0 + 8 <= KH && rv && (in0 || in1)) {
+            const float *src = in0 ? A0 + (size_t)row * K0 + kb : A1 + (size_t)row * K1 + (kb - K0);
+            const float4 v0 = *reinterpret_cast<const float4 *>(src), v1 = *reinterpret_cast<const float4 *>(src + 4);
+            a[0] = v0.x, a[1] = v0.y, a[2] = v0.z, a[3] = v0.w, a[4] = v1.x, a[5] = v1.y, a[6] = v1.z, a[7] = v1.w;
+        } else {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int n = nt * 32 + i32;
-            const float b = (kk < K && n < NO) ? W[(size_t)kk * NO + n] : 0.0f;
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[nt], 0, 0, 0);
+            for (int e = 0; e < 8; ++e) a[e] = (s0 + e < KH) ? a_at(kb + e) : 0.0f;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int kk = kb + e;
+            const bool kv = s0 + e < KH && kk < K;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int n = nt * 32 + i32;
+                const float b = (kv && n < NO) ? W[(size_t)kk * NO + n] : 0.0f;
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b, acc[nt], 0, 0, 0);
+            }
         }
     }
     const int NO1 = NO - NO0;

@@ -124,22 +124,46 @@ def layer_inputs(m, x):
     return [x, x1, x2]
 
 
+def premax_top2_gap(m, x):
+    """smallest gap between the two largest activations entering any of the three max-over-k (current mode)."""
+    gaps = []
+    with torch.no_grad():
+        cur = x
+        for names in torch_ref.EDGE_BLOCKS:
+            e = torch_ref.edge_features(cur, k=m.k)
+            for nm in names:
+                e = getattr(m, nm)(e)
+            top2 = e.topk(2, dim=-1)[0]
+            gaps.append(float((top2[..., 0] - top2[..., 1]).min()))
+            cur = e.max(dim=-1)[0]
+    return min(gaps)
+
+
 # G3 / G4 / G5: small model, every depth, eval and train, gradients
 def gen_model_small():
-    B, F, N, k, ncls = 2, 4, 256, 8, 5
+    # max-over-k routes the whole gradient of a (point, channel) to ONE edge; where the two best activations
+    # differ by a few ulp the winner depends on rounding (inside the reference too), so the fixture input is
+    # chosen free of such near-ties (and of near-ties at the k-th neighbour) in both modes
+    B, F, N, k, ncls = 2, 4, 128, 8, 5
     best = None
-    for seed in range(64):
+    for seed in range(300):
         x = block_like_input(B, N, 100 + seed)
         r, m = build_pair(ncls, F, k, 0.0)
-        gaps = []
+        crit = []
         for mode in ("eval", "train"):
             getattr(m, mode)()
-            gaps += [boundary_gap(npf(t), k) / max(1e-30, float(t.var()) * t.shape[1]) for t in layer_inputs(m, x)]
-        score = min(gaps)
+            crit += [boundary_gap(npf(t), k) / max(1e-30, float(t.var()) * t.shape[1]) / 1e-5 for t in layer_inputs(m, x)]
+            r2, m2 = build_pair(ncls, F, k, 0.0)
+            getattr(m2, mode)()
+            crit.append(premax_top2_gap(m2, x) / 2e-6)
+        score = min(crit)
         if best is None or score > best[0]:
             best = (score, seed, x)
+        if score >= 1.0:
+            break
     score, seed, x = best
-    print("model_small: seed %d min relative boundary gap %.3g" % (seed, score))
+    print("model_small: seed %d score %.3g (>= 1: boundary gap >= 1e-5 rel, top-2 activation gap >= 2e-6)" % (seed, score))
+    assert score >= 0.5
     out = {"x": npf(x), "rel_boundary_gap": np.array(score), "k": np.array(k), "num_classes": np.array(ncls)}
 
     # ---- eval mode, all depths
