@@ -53,6 +53,11 @@ SIGNATURES = {
     "dgcnn_edgeconv_fwd": (_c_int, [_c_desc_p, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp]),
     "dgcnn_edgeconv_bwd": (_c_int, [_c_desc_p, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp,
                                     ctypes.POINTER(EdgeConvGrads), _c_vp, _c_sz, _c_vp]),
+    "dgcnn_bn_lrelu_workspace_bytes": (_c_sz, [_c_int, _c_int]),
+    "dgcnn_bn_lrelu_fwd": (_c_int, [_c_vp, _c_int, _c_int, ctypes.POINTER(BnParams), _c_int, _c_f, _c_f, _c_f,
+                                    _c_vp, _c_vp, _c_vp, _c_sz, _c_vp]),
+    "dgcnn_bn_lrelu_bwd": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_int, _c_f, _c_vp, _c_vp, _c_vp,
+                                    _c_vp, _c_sz, _c_vp]),
     "dgcnn_profile_enable": (_c_int, [_c_int]),
     "dgcnn_profile_mean_ms": (_c_f, []),
     "dgcnn_profile_samples": (_c_int, []),

@@ -1,0 +1,219 @@
+// head.hip -- BatchNorm1d + LeakyReLU on point-major rows [P][C] for the segmentation head
+// (reference model.py:132-139 applied at :172,:184,:187: Sequential(Conv1d 1x1, BatchNorm1d, LeakyReLU(0.2))).
+// SURVEY.md section 8f row N1 ("next" row after the EdgeConv path): the 1x1 convolutions of the head stay plain
+// library GEMMs on point-major rows; this file replaces the BatchNorm/activation around them, whose stock
+// kernels are slow in this layout (945 + 689 us per layer at P = 56 000, C = 1024).
+//
+// Same statistics discipline as the EdgeConv kernels: fp64 partial sums, fixed reduction order.
+#include "edge_common.h"
+
+namespace dgcnn {
+
+constexpr int HEAD_ROWS_PER_BLOCK = 512;  // rows reduced by one workgroup (4 waves x 128 rows)
+
+// partial[chunk][2][C]: sum and sum of squares (fp64) of x over the chunk's rows; lane = column
+__global__ __launch_bounds__(256) void colstats_kernel(const float *__restrict__ x, int P, int C,
+                                                       double *__restrict__ partial)
+{
+    __shared__ double red[4][2][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int r0 = blockIdx.y * HEAD_ROWS_PER_BLOCK;
+    const int r1 = r0 + HEAD_ROWS_PER_BLOCK < P ? r0 + HEAD_ROWS_PER_BLOCK : P;
+    double s = 0.0, ss = 0.0;
+    if (c < C) {
+        for (int r = r0 + wave; r < r1; r += 4) {
+            const float v = x[(size_t)r * C + c];
+            s += (double)v;
+            ss = __builtin_fma((double)v, (double)v, ss);
+        }
+    }
+    red[wave][0][lane] = s;
+    red[wave][1][lane] = ss;
+    __syncthreads();
+    if (wave == 0 && c < C) {
+        partial[((size_t)blockIdx.y * 2 + 0) * C + c] = (red[0][0][lane] + red[1][0][lane]) + (red[2][0][lane] + red[3][0][lane]);
+        partial[((size_t)blockIdx.y * 2 + 1) * C + c] = (red[0][1][lane] + red[1][1][lane]) + (red[2][1][lane] + red[3][1][lane]);
+    }
+}
+
+// stats[4][C] = mean, rstd, sc = gamma rstd, sh = beta - mean sc; running statistics updated when training.
+// One thread per column; the chunk partials are added in index order (deterministic).
+__global__ void colstats_finalize_kernel(const double *__restrict__ partial, int nchunk, int P, int C, int training,
+                                         const float *__restrict__ gamma, const float *__restrict__ beta,
+                                         float *__restrict__ rmean, float *__restrict__ rvar, float eps,
+                                         float momentum, float *__restrict__ stats)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float mean, var;
+    if (training) {
+        double s = 0.0, ss = 0.0;
+        for (int g = 0; g < nchunk; ++g) {
+            s += partial[((size_t)g * 2 + 0) * C + c];
+            ss += partial[((size_t)g * 2 + 1) * C + c];
+        }
+        const double m = s / P;
+        double v = ss / P - m * m;
+        if (v < 0.0) v = 0.0;
+        mean = (float)m;
+        var = (float)v;
+        if (rmean) {
+            const double unbiased = P > 1 ? v * P / (P - 1.0) : v;
+            rmean[c] = (1.0f - momentum) * rmean[c] + momentum * mean;
+            rvar[c] = (1.0f - momentum) * rvar[c] + momentum * (float)unbiased;
+        }
+    } else {
+        mean = rmean[c];
+        var = rvar[c];
+    }
+    const float rstd = (float)(1.0 / sqrt((double)var + (double)eps));
+    const float sc = gamma[c] * rstd;
+    stats[0 * (size_t)C + c] = mean;
+    stats[1 * (size_t)C + c] = rstd;
+    stats[2 * (size_t)C + c] = sc;
+    stats[3 * (size_t)C + c] = beta[c] - mean * sc;
+}
+
+// y = LeakyReLU(sc x + sh); C is a multiple of 4
+__global__ void bn_lrelu_apply_kernel(const float *__restrict__ x, const float *__restrict__ stats, int C, float slope,
+                                      size_t n4, float *__restrict__ y)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n4) return;
+    const int c = (int)((t * 4) % C);
+    const float4 v = reinterpret_cast<const float4 *>(x)[t];
+    const float4 sc = *reinterpret_cast<const float4 *>(stats + 2 * (size_t)C + c);
+    const float4 sh = *reinterpret_cast<const float4 *>(stats + 3 * (size_t)C + c);
+    float4 o;
+    o.x = lrelu(__builtin_fmaf(v.x, sc.x, sh.x), slope);
+    o.y = lrelu(__builtin_fmaf(v.y, sc.y, sh.y), slope);
+    o.z = lrelu(__builtin_fmaf(v.z, sc.z, sh.z), slope);
+    o.w = lrelu(__builtin_fmaf(v.w, sc.w, sh.w), slope);
+    reinterpret_cast<float4 *>(y)[t] = o;
+}
+
+// backward sums: partial[chunk][2][C] = sum dv, sum dv * xhat  with dv = gy * LeakyReLU'(v), sign(v) = sign(y)
+__global__ __launch_bounds__(256) void bn_lrelu_bwd_reduce_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                                  const float *__restrict__ gy,
+                                                                  const float *__restrict__ stats, int P, int C,
+                                                                  float slope, double *__restrict__ partial)
+{
+    __shared__ double red[4][2][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int r0 = blockIdx.y * HEAD_ROWS_PER_BLOCK;
+    const int r1 = r0 + HEAD_ROWS_PER_BLOCK < P ? r0 + HEAD_ROWS_PER_BLOCK : P;
+    double sb = 0.0, sg = 0.0;
+    if (c < C) {
+        const float mean = stats[c], rstd = stats[(size_t)C + c];
+        for (int r = r0 + wave; r < r1; r += 4) {
+            const size_t o = (size_t)r * C + c;
+            const float dv = gy[o] * (y[o] > 0.0f ? 1.0f : slope);
+            const float xh = (x[o] - mean) * rstd;
+            sb += (double)dv;
+            sg = __builtin_fma((double)dv, (double)xh, sg);
+        }
+    }
+    red[wave][0][lane] = sb;
+    red[wave][1][lane] = sg;
+    __syncthreads();
+    if (wave == 0 && c < C) {
+        partial[((size_t)blockIdx.y * 2 + 0) * C + c] = (red[0][0][lane] + red[1][0][lane]) + (red[2][0][lane] + red[3][0][lane]);
+        partial[((size_t)blockIdx.y * 2 + 1) * C + c] = (red[0][1][lane] + red[1][1][lane]) + (red[2][1][lane] + red[3][1][lane]);
+    }
+}
+
+// gbeta, ggamma and the two mean terms cc[2][C] (zero in eval mode)
+__global__ void bn_bwd_finalize_cols_kernel(const double *__restrict__ partial, int nchunk, int P, int C, int training,
+                                            float *__restrict__ ggamma, float *__restrict__ gbeta, float *__restrict__ cc)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double sb = 0.0, sg = 0.0;
+    for (int g = 0; g < nchunk; ++g) {
+        sb += partial[((size_t)g * 2 + 0) * C + c];
+        sg += partial[((size_t)g * 2 + 1) * C + c];
+    }
+    gbeta[c] = (float)sb;
+    ggamma[c] = (float)sg;
+    cc[c] = training ? (float)(sb / P) : 0.0f;
+    cc[(size_t)C + c] = training ? (float)(sg / P) : 0.0f;
+}
+
+// gx = sc (dv - c1 - c2 xhat)
+__global__ void bn_lrelu_bwd_apply_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                          const float *__restrict__ gy, const float *__restrict__ stats,
+                                          const float *__restrict__ cc, int C, float slope, size_t n4,
+                                          float *__restrict__ gx)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n4) return;
+    const int c = (int)((t * 4) % C);
+    const float4 xv = reinterpret_cast<const float4 *>(x)[t], yv = reinterpret_cast<const float4 *>(y)[t];
+    const float4 g = reinterpret_cast<const float4 *>(gy)[t];
+    const float *mean = stats + c, *rstd = stats + (size_t)C + c, *sc = stats + 2 * (size_t)C + c;
+    const float *c1 = cc + c, *c2 = cc + (size_t)C + c;
+    float4 o;
+    o.x = sc[0] * (g.x * (yv.x > 0.0f ? 1.0f : slope) - c1[0] - c2[0] * ((xv.x - mean[0]) * rstd[0]));
+    o.y = sc[1] * (g.y * (yv.y > 0.0f ? 1.0f : slope) - c1[1] - c2[1] * ((xv.y - mean[1]) * rstd[1]));
+    o.z = sc[2] * (g.z * (yv.z > 0.0f ? 1.0f : slope) - c1[2] - c2[2] * ((xv.z - mean[2]) * rstd[2]));
+    o.w = sc[3] * (g.w * (yv.w > 0.0f ? 1.0f : slope) - c1[3] - c2[3] * ((xv.w - mean[3]) * rstd[3]));
+    reinterpret_cast<float4 *>(gx)[t] = o;
+}
+
+static int head_chunks(int P) { return ceil_div(P, HEAD_ROWS_PER_BLOCK); }
+
+}  // namespace dgcnn
+
+using namespace dgcnn;
+
+extern "C" size_t dgcnn_bn_lrelu_workspace_bytes(int P, int C)
+{
+    if (P <= 0 || C <= 0) return 0;
+    return align_up((size_t)head_chunks(P) * 2 * C * sizeof(double), 256) + align_up((size_t)2 * C * sizeof(float), 256);
+}
+
+extern "C" int dgcnn_bn_lrelu_fwd(const float *x, int P, int C, const dgcnn_bn_params *bn, int training, float eps,
+                                  float momentum, float slope, float *y, float *stats, void *workspace,
+                                  size_t workspace_bytes, void *stream)
+{
+    DG_REQUIRE(x && bn && y && stats && workspace, "dgcnn_bn_lrelu_fwd: null pointer");
+    DG_REQUIRE(P > 0 && C > 0 && (C & 3) == 0, "dgcnn_bn_lrelu_fwd: bad shape P=%d C=%d (C must be a multiple of 4)", P, C);
+    DG_REQUIRE(bn->weight && bn->bias, "dgcnn_bn_lrelu_fwd: BatchNorm parameters missing");
+    DG_REQUIRE(training || (bn->running_mean && bn->running_var), "dgcnn_bn_lrelu_fwd: eval mode needs running statistics");
+    DG_REQUIRE(workspace_bytes >= dgcnn_bn_lrelu_workspace_bytes(P, C), "dgcnn_bn_lrelu_fwd: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    double *partial = (double *)workspace;
+    const int nchunk = head_chunks(P);
+    if (training)
+        hipLaunchKernelGGL(colstats_kernel, dim3(ceil_div(C, 64), nchunk), dim3(256), 0, st, x, P, C, partial);
+    hipLaunchKernelGGL(colstats_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, partial, nchunk, P, C, training,
+                       bn->weight, bn->bias, bn->running_mean, bn->running_var, eps, momentum, stats);
+    const size_t n4 = (size_t)P * C / 4;
+    hipLaunchKernelGGL(bn_lrelu_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, x, stats, C, slope, n4, y);
+    DG_CHECK_LAUNCH("dgcnn_bn_lrelu_fwd");
+    return 0;
+}
+
+extern "C" int dgcnn_bn_lrelu_bwd(const float *x, const float *y, const float *gy, const float *stats, int P, int C,
+                                  int training, float slope, float *gx, float *gweight, float *gbias, void *workspace,
+                                  size_t workspace_bytes, void *stream)
+{
+    DG_REQUIRE(x && y && gy && stats && gx && gweight && gbias && workspace, "dgcnn_bn_lrelu_bwd: null pointer");
+    DG_REQUIRE(P > 0 && C > 0 && (C & 3) == 0, "dgcnn_bn_lrelu_bwd: bad shape P=%d C=%d", P, C);
+    DG_REQUIRE(workspace_bytes >= dgcnn_bn_lrelu_workspace_bytes(P, C), "dgcnn_bn_lrelu_bwd: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int nchunk = head_chunks(P);
+    double *partial = (double *)workspace;
+    float *cc = (float *)((char *)workspace + align_up((size_t)nchunk * 2 * C * sizeof(double), 256));
+    hipLaunchKernelGGL(bn_lrelu_bwd_reduce_kernel, dim3(ceil_div(C, 64), nchunk), dim3(256), 0, st, x, y, gy, stats, P, C,
+                       slope, partial);
+    hipLaunchKernelGGL(bn_bwd_finalize_cols_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, partial, nchunk, P, C,
+                       training, gweight, gbias, cc);
+    const size_t n4 = (size_t)P * C / 4;
+    hipLaunchKernelGGL(bn_lrelu_bwd_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, x, y, gy, stats,
+                       cc, C, slope, n4, gx);
+    DG_CHECK_LAUNCH("dgcnn_bn_lrelu_bwd");
+    return 0;
+}

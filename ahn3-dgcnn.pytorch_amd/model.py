@@ -107,7 +107,8 @@ class DGCNN(nn.Module):
     def _head_stage(self, z, i):
         """conv_i (1x1 Conv1d) + bn_i + LeakyReLU on point-major rows z [P, C_in]."""
         conv = getattr(self, "conv%d" % i)[0]
-        return F.leaky_relu(getattr(self, "bn%d" % i)(F.linear(z, conv.weight.squeeze(-1))), NEG_SLOPE)
+        u = F.linear(z, conv.weight.squeeze(-1))              # plain library GEMM on point-major rows
+        return ops.bn_lrelu_rows(u, getattr(self, "bn%d" % i), self.training, NEG_SLOPE)
 
     def forward(self, x, depth=10, idx=None, return_idx=False):
         """x: [B, F, N] (any strides, any device) -> logits [B, num_classes, N]; `depth` < 10 returns

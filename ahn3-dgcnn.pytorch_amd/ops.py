@@ -209,6 +209,60 @@ def edgeconv_pm(x_pm, idx, w1, bn1, w2=None, bn2=None, training=False, slope=0.2
 
 
 # ------------------------------------------------------------------------------------------------
+class _BNLReLURows(torch.autograd.Function):
+    """BatchNorm1d + LeakyReLU on point-major rows [P, C] (head stages conv6/7/8 of the reference, model.py:132-139)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, rmean, rvar, training, eps, momentum, slope):
+        P, C = x.shape
+        lib = _lib.load()
+        dev = x.device
+        wc, bc = weight.detach().contiguous(), bias.detach().contiguous()
+        bn = _bn_struct(wc, bc, rmean, rvar)
+        y = torch.empty_like(x)
+        stats = torch.empty((4, C), dtype=torch.float32, device=dev)
+        ws_bytes = lib.dgcnn_bn_lrelu_workspace_bytes(P, C)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        _lib.check(lib.dgcnn_bn_lrelu_fwd(_lib.ptr(x), P, C, ctypes.byref(bn), 1 if training else 0, eps, momentum, slope,
+                                          _lib.ptr(y), _lib.ptr(stats), _lib.ptr(ws), ws_bytes, _lib.stream_ptr(dev)),
+                   "dgcnn_bn_lrelu_fwd")
+        ctx.save_for_backward(x, y, stats)
+        ctx.cfg = (training, slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, y, stats = ctx.saved_tensors
+        training, slope = ctx.cfg
+        P, C = x.shape
+        lib = _lib.load()
+        dev = x.device
+        gy = gy.contiguous()
+        gx = torch.empty_like(x)
+        gw = torch.empty((C,), dtype=torch.float32, device=dev)
+        gb = torch.empty((C,), dtype=torch.float32, device=dev)
+        ws_bytes = lib.dgcnn_bn_lrelu_workspace_bytes(P, C)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        _lib.check(lib.dgcnn_bn_lrelu_bwd(_lib.ptr(x), _lib.ptr(y), _lib.ptr(gy), _lib.ptr(stats), P, C,
+                                          1 if training else 0, slope, _lib.ptr(gx), _lib.ptr(gw), _lib.ptr(gb),
+                                          _lib.ptr(ws), ws_bytes, _lib.stream_ptr(dev)), "dgcnn_bn_lrelu_bwd")
+        return gx, gw, gb, None, None, None, None, None, None
+
+
+def bn_lrelu_rows(x, bn, training, slope=0.2):
+    """y = LeakyReLU(BatchNorm1d(x)) for point-major rows x [P, C]; `bn` is the nn.BatchNorm1d module (running
+    statistics updated in place when training)."""
+    x = _f32c(x, "x")
+    use_batch_stats = training or bn.running_mean is None
+    momentum = bn.momentum if bn.momentum is not None else 0.1
+    y = _BNLReLURows.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bool(use_batch_stats),
+                           float(bn.eps), float(momentum), float(slope))
+    if training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    return y
+
+
+# ------------------------------------------------------------------------------------------------
 class _ToPointMajor(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

@@ -126,6 +126,19 @@ int dgcnn_edgeconv_bwd(const dgcnn_edgeconv_desc *d, const float *x, const int32
                        const dgcnn_edgeconv_grads *g, void *workspace, size_t workspace_bytes,
                        void *stream);
 
+/* ---- segmentation head: BatchNorm1d + LeakyReLU on point-major rows ("next") ---------
+ * Replaces the BatchNorm1d + LeakyReLU(slope) of conv6 / conv7 / conv8 (model.py:132-139, applied at :172,:184,
+ * :187) for x = the 1x1 convolution's output as rows [P][C] (C a multiple of 4).  The convolutions themselves stay
+ * plain library GEMMs.  stats [4][C] (mean, rstd, gamma*rstd, beta - mean*gamma*rstd) is written by the forward and
+ * read by the backward.  BatchNorm semantics as in dgcnn_edgeconv_*. */
+size_t dgcnn_bn_lrelu_workspace_bytes(int P, int C);
+int dgcnn_bn_lrelu_fwd(const float *x, int P, int C, const dgcnn_bn_params *bn, int training, float eps,
+                       float momentum, float slope, float *y, float *stats, void *workspace,
+                       size_t workspace_bytes, void *stream);
+int dgcnn_bn_lrelu_bwd(const float *x, const float *y, const float *gy, const float *stats, int P, int C,
+                       int training, float slope, float *gx, float *gweight, float *gbias, void *workspace,
+                       size_t workspace_bytes, void *stream);
+
 /* ---- measurement hook (bench.py) ----------------------------------------------------------------------
  * HIP events around the DOMINANT kernel of the EdgeConv path (edge_scatter_kernel, the scatter-add of the
  * first convolution's backward), recorded on the stream the kernel is launched on.  enable(1) resets the

@@ -1,0 +1,57 @@
+"""Full DGCNN (3 EdgeConv blocks on HIP kernels + head on stock PyTorch-ROCm) timings:
+BASELINE.json configs[2] (eval forward, B=8 N=7000 k=30) and a synthetic training step (configs[3] shape per GPU).
+Not the headline metric (bench.py is); recorded in DESIGN.md."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import torch
+import torch.nn.functional as F
+from ahn3_dgcnn_pytorch_amd import DGCNN
+
+dev = torch.device("cuda:0")
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 7000
+k = int(sys.argv[3]) if len(sys.argv) > 3 else 30
+m = DGCNN(5, 4, k, dropout=0.5, emb_dims=1024, cuda=True)
+g = torch.Generator().manual_seed(0)
+x = (torch.rand(B, N, 4, generator=g) * torch.tensor([30.0, 30.0, 20.0, 20.0])).to(dev).permute(0, 2, 1)  # strided, as train.py:176
+labels = torch.randint(0, 5, (B, N), generator=g).to(dev)
+
+
+def timeit(fn, n=10, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
+m.eval()
+with torch.no_grad():
+    t = timeit(lambda: m(x))
+print("eval forward  B=%d N=%d k=%d: %.2f ms  (%.2f M points/s)" % (B, N, k, t * 1e3, B * N / t / 1e6), flush=True)
+with torch.no_grad():
+    t3 = timeit(lambda: m(x, depth=3))
+print("  of which the three EdgeConv blocks (depth=3 exit): %.2f ms" % (t3 * 1e3), flush=True)
+
+m.train()
+opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=1e-4)  # train.py:118
+
+
+def step():
+    opt.zero_grad(set_to_none=True)
+    logits = m(x)                                  # [B, 5, N]
+    pred = F.softmax(logits, dim=1).permute(0, 2, 1).reshape(-1, 5)   # the reference's softmax-then-cal_loss (train.py:180,197)
+    gold = labels.reshape(-1)
+    one_hot = torch.zeros_like(pred).scatter(1, gold.view(-1, 1), 1)
+    one_hot = one_hot * 0.8 + (1 - one_hot) * 0.2 / 4
+    loss = -(one_hot * F.log_softmax(pred, dim=1)).sum(dim=1).mean()  # util.py:17-34
+    loss.backward()
+    opt.step()
+
+
+t = timeit(step)
+print("train step (fwd + loss + bwd + Adam)  B=%d N=%d k=%d: %.2f ms  (%.2f M points/s)" % (B, N, k, t * 1e3, B * N / t / 1e6))

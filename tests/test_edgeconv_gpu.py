@@ -155,3 +155,31 @@ def test_get_graph_feature_backward(device):
     xd = x.to(device).requires_grad_(True)
     (get_graph_feature(xd, k=5, idx=idx) * R.to(device)).sum().backward()
     np.testing.assert_allclose(xd.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("train", [True, False])
+@pytest.mark.parametrize("P,C", [(1000, 64), (777, 256), (130, 1024)])
+def test_head_bn_lrelu_rows(P, C, train, device):
+    # BatchNorm1d + LeakyReLU(0.2) on point-major rows (head stages) vs PyTorch-CPU
+    from ahn3_dgcnn_pytorch_amd import ops
+    import copy
+    g = torch.Generator().manual_seed(P + C)
+    x = torch.randn(P, C, generator=g) * 2.0 + 5.0   # |mean| > sigma: the fp64 statistics matter
+    R = cotangent((P, C), tag="head")
+    bn = torch.nn.BatchNorm1d(C)
+    bn.load_state_dict({n: fill_tensor("head." + n, v) for n, v in bn.state_dict().items()})
+    bn.train(train)
+    bn_d = copy.deepcopy(bn).to(device)
+    xr = x.clone().requires_grad_(True)
+    yr = torch.nn.functional.leaky_relu(bn(xr), 0.2)
+    (yr * R).sum().backward()
+    xd = x.to(device).requires_grad_(True)
+    yd = ops.bn_lrelu_rows(xd, bn_d, train, 0.2)
+    (yd * R.to(device)).sum().backward()
+    np.testing.assert_allclose(yd.detach().cpu().numpy(), yr.detach().numpy(), rtol=0, atol=1e-4)
+    for got, want, what in ((xd.grad, xr.grad, "gx"), (bn_d.weight.grad, bn.weight.grad, "gweight"), (bn_d.bias.grad, bn.bias.grad, "gbias")):
+        got, want = got.cpu().numpy(), want.numpy()
+        assert np.abs(got - want).max() <= 1e-4 * max(1e-6, np.abs(want).max()), what
+    if train:
+        np.testing.assert_allclose(bn_d.running_mean.cpu().numpy(), bn.running_mean.numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(bn_d.running_var.cpu().numpy(), bn.running_var.numpy(), rtol=1e-5, atol=1e-6)
