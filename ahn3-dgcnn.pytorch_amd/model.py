@@ -144,11 +144,17 @@ class DGCNN(nn.Module):
                     if depth == 6:
                         out = g.transpose(1, 2).contiguous()
                     else:
-                        z = torch.cat((g.expand(B, N, emb), cat), dim=2)   # (model.py:179-180)
                         if depth == 7:
+                            z = torch.cat((g.expand(B, N, emb), cat), dim=2)   # (model.py:179-180)
                             out = ops.from_point_major_autograd(z)
                         else:
-                            z = self._head_stage(z.reshape(P, emb + 192), 7)
+                            # conv7 on cat(repeat(g), x1, x2, x3) (model.py:179-184) without materialising the
+                            # [P, emb + 192] concatenation: W7 = [W7g | W7c],  W7 . [g_b ; c_p] = W7g . g_b + W7c . c_p
+                            # (one [B, emb] x [emb, 512] product per batch element + a 192-wide per-point GEMM:
+                            # 84 % fewer FLOPs than the 1216-wide one)
+                            w7 = self.conv7[0].weight.squeeze(-1)
+                            u7 = F.linear(cat, w7[:, emb:]) + F.linear(g, w7[:, :emb])      # [B, N, 512] + [B, 1, 512]
+                            z = ops.bn_lrelu_rows(u7.reshape(P, -1), self.bn7, self.training, NEG_SLOPE)
                             if depth == 8:
                                 out = ops.from_point_major_autograd(z.view(B, N, -1))
                             else:
