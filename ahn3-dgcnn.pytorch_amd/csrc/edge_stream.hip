@@ -13,13 +13,19 @@
 //              BN-affine + LeakyReLU is monotone per channel (increasing if gamma >= 0, else
 //              decreasing), and every fp32 rounding in it is monotone too, so
 //              max_j LReLU(BN(u_j)) == LReLU(BN(max_j u_j))  (min_j if gamma < 0)  bit for bit.
+#include <stdlib.h>
+
 #include "edge_kernels.h"
 
 namespace dgcnn {
 
 constexpr int EDGE_WAVES = 4;  // waves per workgroup in the streaming passes
 
-int edge_grid(int P) { return point_grid(P, EDGE_WAVES, 128); }
+int edge_grid(int P)
+{
+    static const int slots = getenv("DGCNN_EDGE_SLOTS") ? atoi(getenv("DGCNN_EDGE_SLOTS")) : 128;  // experiments
+    return point_grid(P, EDGE_WAVES, slots);
+}
 
 // sum the per-lane doubles of the workgroup's 4 waves and write partial[blockIdx][which][64]
 template <int NV>
@@ -55,30 +61,45 @@ __global__ __launch_bounds__(256) void edge_reduce_kernel(const float *__restric
     const bool neg = WANT_EXT ? (gamma[lane] < 0.0f) : false;
     double acc[2] = {0.0, 0.0};
     const PointIter it = point_iter(P, wave, EDGE_WAVES);
-    for (int pt = it.cur; pt < it.end; pt += it.step) {
+    // The pass is latency-bound (index row -> neighbour rows -> arithmetic), so every point's loads are issued
+    // as one batch of up to 32 rows, and the next point's index row and TQ row are fetched one point ahead.
+    int pt = it.cur;
+    int nv_next = 0;
+    float q_next = 0.0f;
+    if (pt < it.end) {
+        nv_next = lane < k ? __builtin_nontemporal_load(&idx[(size_t)pt * k + lane]) : 0;
+        q_next = __builtin_nontemporal_load(&TQ[(size_t)pt * EC + lane]);
+    }
+    for (; pt < it.end; pt += it.step) {
         const int b = pt / N;
         const float *Pb = TP + (size_t)b * N * EC + lane;
-        const float q = TQ[(size_t)pt * EC + lane];
+        const float q = q_next;
+        int nv = nv_next;  // neighbours 0..63 of this point (lane j holds idx[pt][j])
         const int32_t *ip = idx + (size_t)pt * k;
+        const int ptn = pt + it.step;
+        if (ptn < it.end) {
+            nv_next = lane < k ? __builtin_nontemporal_load(&idx[(size_t)ptn * k + lane]) : 0;
+            q_next = __builtin_nontemporal_load(&TQ[(size_t)ptn * EC + lane]);
+        }
         float ext = neg ? __builtin_inff() : -__builtin_inff();
         float us = 0.0f;
         int hit = 0;
         for (int j0 = 0; j0 < k; j0 += 64) {
             const int kk = k - j0 < 64 ? k - j0 : 64;
-            const int nv = lane < kk ? ip[j0 + lane] : 0;
+            if (j0 > 0) nv = lane < kk ? ip[j0 + lane] : 0;
             // in-degree of the neighbours (training only): scattered int atomics, hidden under the gather
             if (indeg && lane < kk) atomicAdd(&indeg[(size_t)b * N + nv], 1);
-            for (int j = 0; j < kk; j += 8) {
-                float p[8];
-                int n[8];
+            for (int j = 0; j < kk; j += 32) {
+                float p[32];
+                int n[32];
 #pragma unroll
-                for (int t = 0; t < 8; ++t)
+                for (int t = 0; t < 32; ++t)
                     if (j + t < kk) {
                         n[t] = __builtin_amdgcn_readlane(nv, j + t);
                         p[t] = Pb[(size_t)n[t] * EC];
                     }
 #pragma unroll
-                for (int t = 0; t < 8; ++t)
+                for (int t = 0; t < 32; ++t)
                     if (j + t < kk) {
                         const float u = p[t] + q;
                         acc[0] += (double)u;
@@ -93,10 +114,11 @@ __global__ __launch_bounds__(256) void edge_reduce_kernel(const float *__restric
                     }
             }
         }
-        usum[(size_t)pt * EC + lane] = us;
+        // streaming outputs bypass the cache hierarchy's retention: the gather table must stay in L2
+        __builtin_nontemporal_store(us, &usum[(size_t)pt * EC + lane]);
         if (WANT_EXT) {
-            usel[(size_t)pt * EC + lane] = ext;
-            hitn[(size_t)pt * EC + lane] = hit;
+            __builtin_nontemporal_store(ext, &usel[(size_t)pt * EC + lane]);
+            __builtin_nontemporal_store(hit, &hitn[(size_t)pt * EC + lane]);
         }
     }
     block_reduce_store<2>(acc, partial);

@@ -189,7 +189,9 @@ __device__ __forceinline__ void bitonic_sort(u64 (&key)[EPL], int lane)
 
 // Sort one row's buffer (c valid keys) descending, keep the best k.  Wave-wide call.  Returns the
 // new tau (pd of the k-th best, or -inf while fewer than k candidates are known).
-template <int CAP>
+// STORE (<= CAP) = entries the row's LDS buffer can hold: the sort network always spans CAP lanes x registers,
+// positions beyond the valid count are padded with the smallest key.
+template <int CAP, int STORE = CAP>
 __device__ __forceinline__ float compact_row(u64 *kr, int c, int k, int lane)
 {
     constexpr int EPL = CAP / 64;
@@ -201,7 +203,8 @@ __device__ __forceinline__ float compact_row(u64 *kr, int c, int k, int lane)
     }
     bitonic_sort<EPL, CAP>(key, lane);
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) kr[e * 64 + lane] = key[e];
+    for (int e = 0; e < EPL; ++e)
+        if (STORE == CAP || e * 64 + lane < STORE) kr[e * 64 + lane] = key[e];
     float t = -__builtin_inff();
     if (c >= k) {
         const u64 kk = ((k - 1) >> 6) ? key[EPL - 1] : key[0];
@@ -871,23 +874,18 @@ __global__ __launch_bounds__(256) void knn_filter16_kernel(const half8 *__restri
         thrp[r] = v - (__builtin_fabsf(v) + __builtin_fabsf(tau) + yy) * 2.4e-7f;
     }
 
-    int qn = 0, lpos = 0;  // staged entries (queue[0 .. qn)), entries already in the HBM list
+    // staged survivors: a ring in LDS (no data movement on flush), entries already in the HBM list
+    int qhead = 0, qn = 0, lpos = 0;
     bool overflow = false;
-    auto flush = [&](int n) {  // move the first n (<= 64) staged entries to the list, shift the rest down
+    auto flush = [&](int n) {  // move the oldest n (<= 64) staged entries to the list
         if (lpos + n > KNN_LISTCAP) {
             overflow = true;
         } else if (lane < n) {
-            list[lpos + lane] = queue[lane];
+            list[lpos + lane] = queue[(qhead + lane) & (KNN_QCAP - 1)];
         }
         lpos += n;
-        const int rest = qn - n;
-        unsigned keep[KNN_QCAP / 64];
-#pragma unroll
-        for (int i = 0; i < KNN_QCAP / 64; ++i) keep[i] = (i * 64 + lane < rest) ? queue[n + i * 64 + lane] : 0u;
-#pragma unroll
-        for (int i = 0; i < KNN_QCAP / 64; ++i)
-            if (i * 64 + lane < rest) queue[i * 64 + lane] = keep[i];
-        qn = rest;
+        qhead = (qhead + n) & (KNN_QCAP - 1);
+        qn -= n;
     };
 
     Stage16<KS> st;
@@ -928,7 +926,7 @@ __global__ __launch_bounds__(256) void knn_filter16_kernel(const half8 *__restri
                     }
                     if (pass) {
                         const int off = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-                        queue[qn + off] = ((unsigned)mfma32_row(r, h) << 27) | (unsigned)cand;
+                        queue[(qhead + qn + off) & (KNN_QCAP - 1)] = ((unsigned)mfma32_row(r, h) << 27) | (unsigned)cand;
                     }
                     qn += __popcll(m);
                 }
@@ -956,7 +954,11 @@ __global__ __launch_bounds__(64) void knn_refine_kernel(const float *__restrict_
                                                         int32_t *__restrict__ idx)
 {
     constexpr int XS = CP + 1;  // LDS row stride of the raw query rows (odd: conflict-free column reads)
-    __shared__ u64 keys[32][CAP];
+    // key storage per row: 48 entries for k <= 32 (the filter leaves ~42 survivors per row; a fuller row is
+    // compacted to its best k).  With the query rows that is 20.7 KB per wave at C = 64: 7 row blocks per CU,
+    // so all 1760 row blocks of B = 8, N = 7000 are resident in one round.
+    constexpr int STORE = CAP == 64 ? 48 : CAP;
+    __shared__ u64 keys[32][STORE];
     __shared__ int cnts[32];
     __shared__ float taus[32];
     __shared__ float xq[32][XS];
@@ -1025,8 +1027,8 @@ __global__ __launch_bounds__(64) void knn_refine_kernel(const float *__restrict_
             const bool want = pending && (pd > taus[row]);
             int slot = -1;
             if (want) slot = atomicAdd(&cnts[row], 1);
-            if (want && slot < CAP) keys[row][slot] = key;
-            const bool over = want && slot >= CAP;
+            if (want && slot < STORE) keys[row][slot] = key;
+            const bool over = want && slot >= STORE;
             const u64 mo = __ballot(over);
             if (!mo) break;
             // rows whose buffer is full: sort, keep the best k, tighten tau; their lanes offer again
@@ -1034,7 +1036,7 @@ __global__ __launch_bounds__(64) void knn_refine_kernel(const float *__restrict_
             while (todo) {
                 const int l0 = __ffsll((long long)todo) - 1;
                 const int ru = __builtin_amdgcn_readlane(row, l0);
-                const float tnew = compact_row<CAP>(&keys[ru][0], CAP, k, lane);
+                const float tnew = compact_row<CAP, STORE>(&keys[ru][0], STORE, k, lane);
                 if (lane == 0) {
                     cnts[ru] = k;
                     taus[ru] = tnew;
@@ -1055,8 +1057,8 @@ __global__ __launch_bounds__(64) void knn_refine_kernel(const float *__restrict_
     }
     for (int row = 0; row < 32; ++row) {
         int c = cnts[row];
-        c = c < CAP ? c : CAP;
-        (void)compact_row<CAP>(&keys[row][0], c, k, lane);
+        c = c < STORE ? c : STORE;
+        (void)compact_row<CAP, STORE>(&keys[row][0], c, k, lane);
         const int q = q0 + row;
         if (q < N) {
             for (int g = lane; g < k; g += 64) {

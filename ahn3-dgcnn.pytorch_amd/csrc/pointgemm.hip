@@ -36,6 +36,8 @@ __global__ void prep_wcat_kernel(const float *__restrict__ w1, int C, int Ke, fl
 // (a handful of 16-byte loads per row instead of one strided dword per MFMA step).
 constexpr int RG_KH_MAX = 64;  // K0 + K1 <= 128
 
+constexpr int RG_LDS_FLOATS = 8192;  // W (K x NO <= 128 x 64 or 64 x 128 fp32 = 32 KB) staged once per workgroup
+
 template <int NT>
 __global__ __launch_bounds__(256) void rowgemm_kernel(const float *__restrict__ A0, int K0,
                                                       const float *__restrict__ A1, int K1,
@@ -43,10 +45,17 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(const float *__restrict__ 
                                                       float *__restrict__ Y0, int NO0, float *__restrict__ Y1,
                                                       int P)
 {
+    // the weights are read by every wave at every step: stage them in LDS (the kernel was bound by the
+    // latency of those loads: 73 % of its wave cycles in s_waitcnt)
+    __shared__ float wl[RG_LDS_FLOATS];
+    const int K = K0 + K1, KH = (K + 1) >> 1;
+    const bool staged = K * NO <= RG_LDS_FLOATS;
+    if (staged)
+        for (int e = threadIdx.x; e < K * NO; e += 256) wl[e] = W[e];
+    __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, i32 = lane & 31;
     const int p0 = (blockIdx.x * 4 + wave) * 32;
     if (p0 >= P) return;
-    const int K = K0 + K1, KH = (K + 1) >> 1;
     const int row = p0 + i32;
     const bool rv = row < P;
     f32x16 acc[NT];
@@ -81,7 +90,8 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(const float *__restrict__ 
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int n = nt * 32 + i32;
-                const float b = (kv && n < NO) ? W[(size_t)kk * NO + n] : 0.0f;
+                float b = 0.0f;
+                if (kv && n < NO) b = staged ? wl[kk * NO + n] : W[(size_t)kk * NO + n];
                 acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b, acc[nt], 0, 0, 0);
             }
         }
