@@ -20,7 +20,10 @@ LIB = os.path.join(HERE, "libdgcnn_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-ffp-contract=off",
-         "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-Wall", "-Wno-unused-function"]
+         "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-Wall", "-Wno-unused-function",
+         # MFMA accumulators in VGPRs: the epilogues consume them with VALU instructions, and the default
+         # AGPR form costs one v_accvgpr_read per accumulator register (64 per chunk in the fp16 streams)
+         "-mllvm", "-amdgpu-mfma-vgpr-form"]
 FLAGS += os.environ.get("DGCNN_EXTRA_HIPCC_FLAGS", "").split()  # experiments only (e.g. ablation -D switches)
 
 

@@ -486,38 +486,47 @@ __global__ __launch_bounds__(64) void knn_bound_kernel(const void *__restrict__ 
 // ---- fp16 streams with operand tiles shared through LDS ------------------------------------------------
 // Both fp16 all-pairs streams (threshold pre-pass and filter) are bound by L2 -> CU operand traffic when every
 // wave fetches every candidate tile itself (1760 waves x 0.9 MB = 1.55 GB per pass at B = 8, N = 7000, C = 64).
-// Here a workgroup = 4 waves = 128 query rows stages each chunk of KNN_ST_TILES candidate tiles once in LDS
+// Here a workgroup = KNN_ST_WAVES waves of 32 query rows stages each chunk of KNN_ST_TILES candidate tiles once in LDS
 // (already in MFMA operand order, so the ds_read_b128 of a wave is contiguous and conflict-free) and all four
 // waves consume it: a quarter of the traffic, one barrier per chunk, register-prefetched double buffer.
 constexpr int KNN_ST_TILES = 4;  // candidate tiles per staged chunk (Npad / 32 is a multiple of 4)
 
+constexpr int KNN_ST_WAVES = 4;  // waves (32-row tiles) per workgroup of the fp16 streams (2 measured slower: 105 vs 98 us)
+constexpr int KNN_ST_THREADS = KNN_ST_WAVES * 64;
+
 template <int KS>
 struct Stage16 {
     static constexpr int VEC_PER_CHUNK = KNN_ST_TILES * KS * 64;  // half8 vectors per chunk
-    static constexpr int VPT = VEC_PER_CHUNK / 256;               // per thread (256 threads)
+    static constexpr int VPT = VEC_PER_CHUNK / KNN_ST_THREADS;    // per thread
     half8 reg[VPT];
     __device__ __forceinline__ void gload(const half8 *__restrict__ xbatch, int chunk, int tid)
     {
+#ifdef KNN_ABLATE_STAGE_LOADS  // timing experiment: always the same chunk (L1-resident)
+        chunk = 0;
+#endif
 #pragma unroll
-        for (int i = 0; i < VPT; ++i) reg[i] = xbatch[(size_t)chunk * VEC_PER_CHUNK + i * 256 + tid];
+        for (int i = 0; i < VPT; ++i) reg[i] = xbatch[(size_t)chunk * VEC_PER_CHUNK + i * KNN_ST_THREADS + tid];
     }
     __device__ __forceinline__ void swrite(half8 *__restrict__ buf, int tid) const
     {
 #pragma unroll
-        for (int i = 0; i < VPT; ++i) buf[i * 256 + tid] = reg[i];
+        for (int i = 0; i < VPT; ++i) buf[i * KNN_ST_THREADS + tid] = reg[i];
     }
 };
 
 template <int CP>
-__global__ __launch_bounds__(256) void knn_bound16s_kernel(const half8 *__restrict__ xh, const float *__restrict__ xxc,
+__global__ __launch_bounds__(KNN_ST_THREADS) void knn_bound16s_kernel(const half8 *__restrict__ xh, const float *__restrict__ xxc,
                                                            const float *__restrict__ xx_raw,
                                                            const unsigned *__restrict__ bmax, int B, int Npad, int k,
                                                            float *__restrict__ tau0, float *__restrict__ epsr)
 {
     constexpr int KS = CP / 16;
-    __shared__ half8 sbuf[2][Stage16<KS>::VEC_PER_CHUNK];
+    constexpr int SBUF_BYTES = 2 * Stage16<KS>::VEC_PER_CHUNK * (int)sizeof(half8);
+    constexpr int TR_BYTES = KNN_ST_WAVES * 32 * 65 * (int)sizeof(float);  // epilogue transpose
+    __shared__ __attribute__((aligned(16))) char smem[SBUF_BYTES > TR_BYTES ? SBUF_BYTES : TR_BYTES];
+    half8(*sbuf)[Stage16<KS>::VEC_PER_CHUNK] = reinterpret_cast<half8(*)[Stage16<KS>::VEC_PER_CHUNK]>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, j32 = lane & 31;
-    const int b = blockIdx.x % B, rb = (blockIdx.x / B) * 4 + wave;  // this wave's row tile
+    const int b = blockIdx.x % B, rb = (blockIdx.x / B) * KNN_ST_WAVES + wave;  // this wave's row tile
     const int ntiles = Npad / 32, nchunks = ntiles / KNN_ST_TILES;
     const half8 *xbatch = xh + (size_t)b * ntiles * KS * 64;
     const float *yb = xxc + (size_t)b * Npad;
@@ -569,26 +578,66 @@ __global__ __launch_bounds__(256) void knn_bound16s_kernel(const half8 *__restri
         __syncthreads();
     }
 
-    // k-th largest of the 64 class maxima of every row, minus the row's own norm and the error bound
-    const float cmax = __uint_as_float(bmax[2 * b + 0]), rmax = __uint_as_float(bmax[2 * b + 1]);
+    // k-th largest of the 64 class maxima of every row, minus the row's own norm and the error bound.
+    // The maxima are transposed through LDS (row stride 65 words: conflict-free both ways) so that lane
+    // (h, j) holds classes 32h .. 32h+31 of row j in registers; each lane sorts its 32 keys with a register
+    // bitonic network (all 32 rows of the tile at once, no cross-lane traffic), the two halves of a row are
+    // merged with one half-cleaner across lanes j and j + 32, and a 5-stage merge finishes the half that
+    // holds rank k (the upper 32 in lanes h = 0, the lower 32 in lanes h = 1).
+    float *tr = reinterpret_cast<float *>(smem) + wave * (32 * 65);  // all waves are past the last barrier
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const float other = __uint_as_float(xchg32<32>(__float_as_uint(m1[r >> 1][r & 1])));
+        const int row = mfma32_row(r, h);
+        tr[row * 65 + j32] = m0[r >> 1][r & 1];
+        tr[row * 65 + 32 + j32] = m1[r >> 1][r & 1];
+    }
+    unsigned v[32];
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            unsigned key = f32_to_ordered((h == hh) ? m0[r >> 1][r & 1] : other);
-            bitonic32_sort<64>(key, lane);
-            const unsigned kth = __builtin_amdgcn_readlane(key, k - 1);
-            const float vk = __uint_as_float((kth & 0x80000000u) ? (kth & 0x7fffffffu) : ~kth);
-            const int row = rb * 32 + mfma32_row(r, hh);
-            const float xi = yb[row], xr = xx_raw[(size_t)b * Npad + row];
-            const float eps = knn_f16_eps(xi, cmax, xr, rmax);
-            const float t = (vk - xi) - eps;
-            if (lane == 0) {
-                tau0[(size_t)b * Npad + row] = (t != t) ? -__builtin_inff() : t;  // NaN -> no bound
-                epsr[(size_t)b * Npad + row] = eps;
+    for (int i = 0; i < 32; ++i) v[i] = f32_to_ordered(tr[j32 * 65 + h * 32 + i]);
+    auto cex = [](unsigned &hi, unsigned &lo) {  // compare-exchange: hi >= lo afterwards
+        const unsigned a = hi, c = lo;
+        hi = a > c ? a : c;
+        lo = a > c ? c : a;
+    };
+#pragma unroll
+    for (int size = 2; size <= 32; size <<= 1) {
+#pragma unroll
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const int p = i ^ stride;
+                if (p > i) {
+                    if ((i & size) == 0 || size == 32) cex(v[i], v[p]);  // descending run
+                    else cex(v[p], v[i]);
+                }
             }
         }
+    }
+    unsigned w[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const unsigned o = xchg32<32>(v[31 - i]);  // partner lane's i-th smallest
+        w[i] = h == 0 ? (v[i] > o ? v[i] : o) : (v[i] < o ? v[i] : o);
+    }
+#pragma unroll
+    for (int stride = 16; stride > 0; stride >>= 1) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i)
+            if ((i ^ stride) > i) cex(w[i], w[i ^ stride]);
+    }
+    const int sel = (k - 1) & 31;
+    unsigned kth = w[0];
+#pragma unroll
+    for (int i = 1; i < 32; ++i) kth = sel == i ? w[i] : kth;
+    if (h == ((k - 1) >> 5)) {
+        const float cmax = __uint_as_float(bmax[2 * b + 0]), rmax = __uint_as_float(bmax[2 * b + 1]);
+        const float vk = __uint_as_float((kth & 0x80000000u) ? (kth & 0x7fffffffu) : ~kth);
+        const int row = rb * 32 + j32;
+        const float xi = yb[row], xr = xx_raw[(size_t)b * Npad + row];
+        const float eps = knn_f16_eps(xi, cmax, xr, rmax);
+        const float t = (vk - xi) - eps;
+        tau0[(size_t)b * Npad + row] = (t != t) ? -__builtin_inff() : t;  // NaN -> no bound
+        epsr[(size_t)b * Npad + row] = eps;
     }
 }
 
@@ -834,7 +883,7 @@ constexpr int KNN_QCAP = 256;     // LDS staging ring of the filter kernel (entr
 constexpr int KNN_LISTCAP = 4096;  // survivor list per 32-row block in HBM (128 per row on average)
 
 template <int CP>
-__global__ __launch_bounds__(256) void knn_filter16_kernel(const half8 *__restrict__ xh, const float *__restrict__ xxc,
+__global__ __launch_bounds__(KNN_ST_THREADS) void knn_filter16_kernel(const half8 *__restrict__ xh, const float *__restrict__ xxc,
                                                            const float *__restrict__ tau0,
                                                            const float *__restrict__ epsr,
                                                            const int *__restrict__ f16ok, int B, int Npad,
@@ -843,9 +892,9 @@ __global__ __launch_bounds__(256) void knn_filter16_kernel(const half8 *__restri
 {
     constexpr int KS = CP / 16;
     __shared__ half8 sbuf[2][Stage16<KS>::VEC_PER_CHUNK];
-    __shared__ unsigned queues[4][KNN_QCAP];
+    __shared__ unsigned queues[KNN_ST_WAVES][KNN_QCAP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, j32 = lane & 31;
-    const int b = blockIdx.x % B, rb = (blockIdx.x / B) * 4 + wave;  // this wave's row block
+    const int b = blockIdx.x % B, rb = (blockIdx.x / B) * KNN_ST_WAVES + wave;  // this wave's row block
     const int ntiles = Npad / 32, nchunks = ntiles / KNN_ST_TILES;
     const int wid = b * ntiles + rb;
     if (!f16ok[b]) {  // uniform over the workgroup
@@ -865,13 +914,15 @@ __global__ __launch_bounds__(256) void knn_filter16_kernel(const half8 *__restri
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) a[ks] = xbatch[((size_t)rb * KS + ks) * 64 + lane];
     // filter threshold on t = 2 d16 - yy_l:  t > (tau0 - eps) + yy_i, lowered by the rounding of this very sum
-    float thrp[16];
+    f32x2 thrp[8];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = q0 + mfma32_row(r, h);
         const float tau = tau0[(size_t)b * Npad + row], yy = yb[row];
         const float v = (tau - epsr[(size_t)b * Npad + row]) + yy;
-        thrp[r] = v - (__builtin_fabsf(v) + __builtin_fabsf(tau) + yy) * 2.4e-7f;
+        const float thr = v - (__builtin_fabsf(v) + __builtin_fabsf(tau) + yy) * 2.4e-7f;
+        // padding rows (yy = +inf) give NaN: nothing may pass there, and the sign test below needs a real number
+        thrp[r >> 1][r & 1] = thr != thr ? __builtin_inff() : thr;
     }
 
     // staged survivors: a ring in LDS (no data movement on flush), entries already in the HBM list
@@ -910,26 +961,32 @@ __global__ __launch_bounds__(256) void knn_filter16_kernel(const half8 *__restri
             for (int ks = 0; ks < KS; ++ks)
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks], cur[(tt * KS + ks) * 64 + lane], acc, 0, 0, 0);
             const int cand = (c * KNN_ST_TILES + tt) * 32 + j32;
-            f32x2 tp[8];
+            // t > thr  <=>  sign(thr - t): the 16 sign bits of a lane are packed with one v_alignbit each
+            // (bit r = accumulator register r), so the common path is 8 v_pk_fma + 8 v_pk_add + 16 v_alignbit
+            // per tile and no per-register ballot/branch.  ~6 of the 1024 pairs of a tile survive.
+            unsigned bits = 0u;
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
-                tp[i] = __builtin_elementwise_fma(f32x2{acc[2 * i], acc[2 * i + 1]}, f32x2{2.0f, 2.0f},
-                                                  f32x2{-ycur[tt], -ycur[tt]});
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float t = tp[r >> 1][r & 1];
-                const bool pass = t > thrp[r];
-                const u64 m = __ballot(pass);
-                if (__builtin_expect(m != 0, 0)) {
-                    if (qn > KNN_QCAP - 64) {  // room for a full register of survivors (loose thresholds only)
-                        while (qn >= 64) flush(64);
-                    }
-                    if (pass) {
-                        const int off = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-                        queue[(qhead + qn + off) & (KNN_QCAP - 1)] = ((unsigned)mfma32_row(r, h) << 27) | (unsigned)cand;
-                    }
-                    qn += __popcll(m);
+            for (int i = 7; i >= 0; --i) {
+                const f32x2 t = __builtin_elementwise_fma(f32x2{acc[2 * i], acc[2 * i + 1]}, f32x2{2.0f, 2.0f},
+                                                          f32x2{-ycur[tt], -ycur[tt]});
+                const f32x2 d = thrp[i] - t;
+                bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(d[1]), 31);
+                bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(d[0]), 31);
+            }
+            // rounds: every lane that still holds survivors appends its lowest one (uniform loop, 1-3 rounds)
+            u64 m = __ballot(bits != 0u);
+            while (m != 0) {
+                if (qn > KNN_QCAP - 64) {  // room for a full round of survivors (loose thresholds only)
+                    while (qn >= 64) flush(64);
                 }
+                if (bits != 0u) {
+                    const int r = __builtin_ctz(bits);
+                    const int off = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+                    queue[(qhead + qn + off) & (KNN_QCAP - 1)] = ((unsigned)((r & 3) + 8 * (r >> 2) + 4 * h) << 27) | (unsigned)cand;
+                    bits &= bits - 1u;
+                }
+                qn += __popcll(m);
+                m = __ballot(bits != 0u);
             }
             if (qn >= 64) flush(64);
         }
@@ -1137,7 +1194,7 @@ static void knn_f16_launch(int cap, const KnnWs &w, const float *x, int B, int N
                            hipStream_t st)
 {
     const dim3 grid(B * (Npad / 32)), block(64);
-    hipLaunchKernelGGL((knn_filter16_kernel<CP>), dim3(B * (Npad / 128)), dim3(256), 0, st, w.xh, w.xxc, w.tau0, w.eps,
+    hipLaunchKernelGGL((knn_filter16_kernel<CP>), dim3(B * (Npad / (32 * KNN_ST_WAVES))), dim3(KNN_ST_THREADS), 0, st, w.xh, w.xxc, w.tau0, w.eps,
                        w.f16ok, B, Npad, w.lists, w.lcount, w.rbflag);
     if (cap == 64)
         hipLaunchKernelGGL((knn_refine_kernel<CP, 64>), grid, block, 0, st, x, w.xx, w.lists, w.lcount, w.rbflag, B, N, C,
@@ -1199,7 +1256,7 @@ extern "C" int dgcnn_knn(const float *x, int B, int N, int C, int k, int32_t *id
                                Npad, CP, w.xh);
             hipLaunchKernelGGL(knn_cnorm_kernel, dim3(Npad / 16, B), dim3(256), 0, st, x, w.mu, N, C, Npad, w.xxc);
             hipLaunchKernelGGL(knn_bmax_kernel, dim3(B), dim3(1024), 0, st, w.xxc, xx, N, Npad, w.bmax, w.f16ok);
-            const dim3 bgrid(B * (Npad / 128)), bblock(256);
+            const dim3 bgrid(B * (Npad / (32 * KNN_ST_WAVES))), bblock(KNN_ST_THREADS);
 #define DG_BOUND16(CP_) \
     hipLaunchKernelGGL((knn_bound16s_kernel<CP_>), bgrid, bblock, 0, st, w.xh, w.xxc, xx, w.bmax, B, Npad, k, w.tau0, w.eps)
             switch (CP) {
