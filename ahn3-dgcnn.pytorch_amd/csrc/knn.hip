@@ -518,6 +518,7 @@ template <int CP>
 __global__ __launch_bounds__(KNN_ST_THREADS) void knn_bound16s_kernel(const half8 *__restrict__ xh, const float *__restrict__ xxc,
                                                            const float *__restrict__ xx_raw,
                                                            const unsigned *__restrict__ bmax, int B, int Npad, int k,
+                                                           int parts, unsigned *__restrict__ exch,
                                                            float *__restrict__ tau0, float *__restrict__ epsr)
 {
     constexpr int KS = CP / 16;
@@ -526,8 +527,12 @@ __global__ __launch_bounds__(KNN_ST_THREADS) void knn_bound16s_kernel(const half
     __shared__ __attribute__((aligned(16))) char smem[SBUF_BYTES > TR_BYTES ? SBUF_BYTES : TR_BYTES];
     half8(*sbuf)[Stage16<KS>::VEC_PER_CHUNK] = reinterpret_cast<half8(*)[Stage16<KS>::VEC_PER_CHUNK]>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, j32 = lane & 31;
-    const int b = blockIdx.x % B, rb = (blockIdx.x / B) * KNN_ST_WAVES + wave;  // this wave's row tile
+    // workgroup = (batch element, candidate part, group of KNN_ST_WAVES row tiles); with B a multiple of 8 both
+    // parts of a row group run on the same XCD (blockIdx % 8)
+    const int b = blockIdx.x % B, part = (blockIdx.x / B) % parts;
+    const int rb = (blockIdx.x / B / parts) * KNN_ST_WAVES + wave;  // this wave's row tile
     const int ntiles = Npad / 32, nchunks = ntiles / KNN_ST_TILES;
+    const int c0 = part * nchunks / parts, c1 = (part + 1) * nchunks / parts;  // this part's candidate chunks
     const half8 *xbatch = xh + (size_t)b * ntiles * KS * 64;
     const float *yb = xxc + (size_t)b * Npad;
 
@@ -541,18 +546,18 @@ __global__ __launch_bounds__(KNN_ST_THREADS) void knn_bound16s_kernel(const half
     for (int i = 0; i < 8; ++i) m0[i] = m1[i] = f32x2{-__builtin_inff(), -__builtin_inff()};
 
     Stage16<KS> st;
-    st.gload(xbatch, 0, tid);
+    st.gload(xbatch, c0, tid);
     st.swrite(sbuf[0], tid);
     float ycur[KNN_ST_TILES], ynext[KNN_ST_TILES];
 #pragma unroll
-    for (int tt = 0; tt < KNN_ST_TILES; ++tt) ycur[tt] = yb[tt * 32 + j32];
+    for (int tt = 0; tt < KNN_ST_TILES; ++tt) ycur[tt] = yb[(c0 * KNN_ST_TILES + tt) * 32 + j32];
     __syncthreads();
-    for (int c = 0; c < nchunks; ++c) {
-        const int cn = c + 1 < nchunks ? c + 1 : c;  // clamped prefetch: no branch around the loads
+    for (int c = c0; c < c1; ++c) {
+        const int cn = c + 1 < c1 ? c + 1 : c;  // clamped prefetch: no branch around the loads
         st.gload(xbatch, cn, tid);
 #pragma unroll
         for (int tt = 0; tt < KNN_ST_TILES; ++tt) ynext[tt] = yb[(cn * KNN_ST_TILES + tt) * 32 + j32];
-        const half8 *cur = sbuf[c & 1];
+        const half8 *cur = sbuf[(c - c0) & 1];
         f32x16 acc[KNN_ST_TILES];
 #pragma unroll
         for (int tt = 0; tt < KNN_ST_TILES; ++tt) {
@@ -572,7 +577,7 @@ __global__ __launch_bounds__(KNN_ST_THREADS) void knn_bound16s_kernel(const half
             m0[i] = __builtin_elementwise_max(m0[i], __builtin_elementwise_max(t0, t1));
             m1[i] = __builtin_elementwise_max(m1[i], __builtin_elementwise_max(t2, t3));
         }
-        st.swrite(sbuf[(c + 1) & 1], tid);
+        st.swrite(sbuf[(c - c0 + 1) & 1], tid);
 #pragma unroll
         for (int tt = 0; tt < KNN_ST_TILES; ++tt) ycur[tt] = ynext[tt];
         __syncthreads();
@@ -625,6 +630,15 @@ __global__ __launch_bounds__(KNN_ST_THREADS) void knn_bound16s_kernel(const half
         for (int i = 0; i < 32; ++i)
             if ((i ^ stride) > i) cex(w[i], w[i ^ stride]);
     }
+    if (parts == 2) {
+        // Candidate halves: each part publishes its 64 sorted class maxima per row (lanes h = 0 the upper 32,
+        // h = 1 the lower 32) and knn_bound_merge_kernel finishes the row from both lists.
+        unsigned *mine = exch + (((size_t)b * Npad + rb * 32 + j32) * 2 + part) * 64 + h * 32;
+#pragma unroll
+        for (int i = 0; i < 32; i += 4)
+            *reinterpret_cast<uint4 *>(mine + i) = uint4{w[i], w[i + 1], w[i + 2], w[i + 3]};
+        return;
+    }
     const int sel = (k - 1) & 31;
     unsigned kth = w[0];
 #pragma unroll
@@ -638,6 +652,61 @@ __global__ __launch_bounds__(KNN_ST_THREADS) void knn_bound16s_kernel(const half
         const float t = (vk - xi) - eps;
         tau0[(size_t)b * Npad + row] = (t != t) ? -__builtin_inff() : t;  // NaN -> no bound
         epsr[(size_t)b * Npad + row] = eps;
+    }
+}
+
+// Threshold of a row from the two parts' sorted class maxima A, B (64 each, descending): the top 64 of the
+// union is the bitonic sequence max(A[i], B[63 - i]); one cross-lane half-cleaner and the in-lane merge sort
+// it.  128 classes per row instead of 64 also tighten the threshold.  One wave = 32 rows, lane (h, j) = half h
+// of row j as in the epilogue of knn_bound16s_kernel.
+__global__ __launch_bounds__(64) void knn_bound_merge_kernel(const unsigned *__restrict__ exch,
+                                                             const float *__restrict__ xxc,
+                                                             const float *__restrict__ xx_raw,
+                                                             const unsigned *__restrict__ bmax, int B, int Npad, int k,
+                                                             float *__restrict__ tau0, float *__restrict__ epsr)
+{
+    const int lane = threadIdx.x, h = lane >> 5, j32 = lane & 31;
+    const int b = blockIdx.x % B, rb = blockIdx.x / B;
+    const size_t row = (size_t)b * Npad + rb * 32 + j32;
+    const uint4 *pa = reinterpret_cast<const uint4 *>(exch + (row * 2 + 0) * 64 + h * 32);
+    const uint4 *pb = reinterpret_cast<const uint4 *>(exch + (row * 2 + 1) * 64 + (1 - h) * 32);
+    unsigned w[32];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint4 va = pa[i], vb = pb[7 - i];  // B reversed: element 31 - (4 i + e) is vb[3 - e]
+        w[4 * i + 0] = va.x > vb.w ? va.x : vb.w;
+        w[4 * i + 1] = va.y > vb.z ? va.y : vb.z;
+        w[4 * i + 2] = va.z > vb.y ? va.z : vb.y;
+        w[4 * i + 3] = va.w > vb.x ? va.w : vb.x;
+    }
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const unsigned o = xchg32<32>(w[i]);
+        w[i] = h == 0 ? (w[i] > o ? w[i] : o) : (w[i] < o ? w[i] : o);
+    }
+#pragma unroll
+    for (int stride = 16; stride > 0; stride >>= 1) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            if ((i ^ stride) > i) {
+                const unsigned x = w[i], y = w[i ^ stride];
+                w[i] = x > y ? x : y;
+                w[i ^ stride] = x > y ? y : x;
+            }
+        }
+    }
+    const int sel = (k - 1) & 31;
+    unsigned kth = w[0];
+#pragma unroll
+    for (int i = 1; i < 32; ++i) kth = sel == i ? w[i] : kth;
+    if (h == ((k - 1) >> 5)) {
+        const float cmax = __uint_as_float(bmax[2 * b + 0]), rmax = __uint_as_float(bmax[2 * b + 1]);
+        const float vk = __uint_as_float((kth & 0x80000000u) ? (kth & 0x7fffffffu) : ~kth);
+        const float xi = xxc[row], xr = xx_raw[row];
+        const float eps = knn_f16_eps(xi, cmax, xr, rmax);
+        const float t = (vk - xi) - eps;
+        tau0[row] = (t != t) ? -__builtin_inff() : t;  // NaN -> no bound
+        epsr[row] = eps;
     }
 }
 
@@ -887,27 +956,32 @@ __global__ __launch_bounds__(KNN_ST_THREADS) void knn_filter16_kernel(const half
                                                            const float *__restrict__ tau0,
                                                            const float *__restrict__ epsr,
                                                            const int *__restrict__ f16ok, int B, int Npad,
-                                                           unsigned *__restrict__ lists, int *__restrict__ lcount,
-                                                           int *__restrict__ rbflag)
+                                                           int parts, unsigned *__restrict__ lists,
+                                                           int *__restrict__ lcount, int *__restrict__ rbflag)
 {
     constexpr int KS = CP / 16;
     __shared__ half8 sbuf[2][Stage16<KS>::VEC_PER_CHUNK];
     __shared__ unsigned queues[KNN_ST_WAVES][KNN_QCAP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, j32 = lane & 31;
-    const int b = blockIdx.x % B, rb = (blockIdx.x / B) * KNN_ST_WAVES + wave;  // this wave's row block
+    // workgroup = (batch element, candidate part, group of row blocks) as in knn_bound16s_kernel; every
+    // (row block, part) owns 1 / parts of the row block's list.  rbflag is zero-filled by the launcher.
+    const int b = blockIdx.x % B, part = (blockIdx.x / B) % parts;
+    const int rb = (blockIdx.x / B / parts) * KNN_ST_WAVES + wave;  // this wave's row block
     const int ntiles = Npad / 32, nchunks = ntiles / KNN_ST_TILES;
+    const int c0 = part * nchunks / parts, c1 = (part + 1) * nchunks / parts;
     const int wid = b * ntiles + rb;
+    const int listcap = KNN_LISTCAP / parts;
     if (!f16ok[b]) {  // uniform over the workgroup
         if (lane == 0) {
             rbflag[wid] = 1;
-            lcount[wid] = 0;
+            lcount[2 * wid + part] = 0;
         }
         return;
     }
     const int q0 = rb * 32;
     const half8 *xbatch = xh + (size_t)b * ntiles * KS * 64;
     const float *yb = xxc + (size_t)b * Npad;
-    unsigned *list = lists + (size_t)wid * KNN_LISTCAP;
+    unsigned *list = lists + (size_t)wid * KNN_LISTCAP + part * listcap;
     unsigned *queue = queues[wave];
 
     half8 a[KS];
@@ -929,7 +1003,7 @@ __global__ __launch_bounds__(KNN_ST_THREADS) void knn_filter16_kernel(const half
     int qhead = 0, qn = 0, lpos = 0;
     bool overflow = false;
     auto flush = [&](int n) {  // move the oldest n (<= 64) staged entries to the list
-        if (lpos + n > KNN_LISTCAP) {
+        if (lpos + n > listcap) {
             overflow = true;
         } else if (lane < n) {
             list[lpos + lane] = queue[(qhead + lane) & (KNN_QCAP - 1)];
@@ -939,66 +1013,122 @@ __global__ __launch_bounds__(KNN_ST_THREADS) void knn_filter16_kernel(const half
         qn -= n;
     };
 
+    // MFMA chains of two candidate tiles, interleaved (the matrix pipe stays busy although each chain is serial)
+    auto mfma_pair = [&](const half8 *buf, int t0, f32x16 &c0, f32x16 &c1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c0[r] = c1[r] = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#if defined(KNN_ABLATE_LDSREAD)  // timing experiment
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks], a[(ks + 1) % KS], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks], a[(ks + 2) % KS], c1, 0, 0, 0);
+#elif defined(KNN_ABLATE_MFMA)  // timing experiment
+            {
+                const half8 v0 = buf[(t0 * KS + ks) * 64 + lane], v1 = buf[((t0 + 1) * KS + ks) * 64 + lane];
+                c0[ks] += (float)v0[0];
+                c1[ks] += (float)v1[0];
+            }
+#else
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks], buf[(t0 * KS + ks) * 64 + lane], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks], buf[((t0 + 1) * KS + ks) * 64 + lane], c1, 0, 0, 0);
+#endif
+        }
+    };
+    // t > thr  <=>  sign(thr - t): the 16 sign bits of a lane are packed with one v_alignbit each (bit r =
+    // accumulator register r): 8 v_pk_fma + 8 v_pk_add + 16 v_alignbit per tile, no per-register ballot/branch
+    auto signs = [&](const f32x16 &acc, float y) {
+        unsigned bits = 0u;
+#ifdef KNN_ABLATE_SIGNS  // timing experiment
+        asm volatile("" : "+v"(bits) : "v"(acc));
+        return bits;
+#endif
+#pragma unroll
+        for (int i = 7; i >= 0; --i) {
+            const f32x2 t = __builtin_elementwise_fma(f32x2{acc[2 * i], acc[2 * i + 1]}, f32x2{2.0f, 2.0f}, f32x2{-y, -y});
+            const f32x2 d = thrp[i] - t;
+            bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(d[1]), 31);
+            bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(d[0]), 31);
+        }
+        return bits;
+    };
+    // rounds: every lane that still holds survivors appends its lowest one (uniform loop; ~6 of the 1024
+    // pairs of a tile survive, so 1-3 rounds)
+    auto rounds = [&](unsigned bits, int cand) {
+#ifdef KNN_ABLATE_ROUNDS  // timing experiment: no survivor extraction (results are garbage)
+        asm volatile("" ::"v"(bits));
+        return;
+#endif
+        u64 m = __ballot(bits != 0u);
+        while (m != 0) {
+            if (qn > KNN_QCAP - 64) {  // room for a full round of survivors (loose thresholds only)
+                while (qn >= 64) flush(64);
+            }
+            if (bits != 0u) {
+                const int r = __builtin_ctz(bits);
+                const int off = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+                queue[(qhead + qn + off) & (KNN_QCAP - 1)] = ((unsigned)((r & 3) + 8 * (r >> 2) + 4 * h) << 27) | (unsigned)cand;
+                bits &= bits - 1u;
+            }
+            qn += __popcll(m);
+            m = __ballot(bits != 0u);
+        }
+        if (qn >= 64) flush(64);
+    };
+
+    // Software pipeline over pairs of tiles: the MFMA chains of one pair are issued in the same basic block as
+    // the sign packing of the pair before it, so the matrix pipe works under the vector epilogue.  The pair
+    // pending across the chunk barrier is tiles 2, 3 of the previous chunk.
     Stage16<KS> st;
-    st.gload(xbatch, 0, tid);
+    st.gload(xbatch, c0, tid);
     st.swrite(sbuf[0], tid);
     float ycur[KNN_ST_TILES], ynext[KNN_ST_TILES];
 #pragma unroll
-    for (int tt = 0; tt < KNN_ST_TILES; ++tt) ycur[tt] = yb[tt * 32 + j32];
+    for (int tt = 0; tt < KNN_ST_TILES; ++tt) ycur[tt] = yb[(c0 * KNN_ST_TILES + tt) * 32 + j32];
+    f32x16 pa0, pa1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pa0[r] = pa1[r] = 0.0f;
+    float py0 = 0.0f, py1 = 0.0f;
     __syncthreads();
-    for (int c = 0; c < nchunks; ++c) {
-        const int cn = c + 1 < nchunks ? c + 1 : c;  // clamped prefetch: no branch around the loads
+    for (int c = c0; c < c1; ++c) {
+        const int cn = c + 1 < c1 ? c + 1 : c;  // clamped prefetch: no branch around the loads
         st.gload(xbatch, cn, tid);
 #pragma unroll
         for (int tt = 0; tt < KNN_ST_TILES; ++tt) ynext[tt] = yb[(cn * KNN_ST_TILES + tt) * 32 + j32];
-        const half8 *cur = sbuf[c & 1];
-#pragma unroll
-        for (int tt = 0; tt < KNN_ST_TILES; ++tt) {
-            f32x16 acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks], cur[(tt * KS + ks) * 64 + lane], acc, 0, 0, 0);
-            const int cand = (c * KNN_ST_TILES + tt) * 32 + j32;
-            // t > thr  <=>  sign(thr - t): the 16 sign bits of a lane are packed with one v_alignbit each
-            // (bit r = accumulator register r), so the common path is 8 v_pk_fma + 8 v_pk_add + 16 v_alignbit
-            // per tile and no per-register ballot/branch.  ~6 of the 1024 pairs of a tile survive.
-            unsigned bits = 0u;
-#pragma unroll
-            for (int i = 7; i >= 0; --i) {
-                const f32x2 t = __builtin_elementwise_fma(f32x2{acc[2 * i], acc[2 * i + 1]}, f32x2{2.0f, 2.0f},
-                                                          f32x2{-ycur[tt], -ycur[tt]});
-                const f32x2 d = thrp[i] - t;
-                bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(d[1]), 31);
-                bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(d[0]), 31);
-            }
-            // rounds: every lane that still holds survivors appends its lowest one (uniform loop, 1-3 rounds)
-            u64 m = __ballot(bits != 0u);
-            while (m != 0) {
-                if (qn > KNN_QCAP - 64) {  // room for a full round of survivors (loose thresholds only)
-                    while (qn >= 64) flush(64);
-                }
-                if (bits != 0u) {
-                    const int r = __builtin_ctz(bits);
-                    const int off = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-                    queue[(qhead + qn + off) & (KNN_QCAP - 1)] = ((unsigned)((r & 3) + 8 * (r >> 2) + 4 * h) << 27) | (unsigned)cand;
-                    bits &= bits - 1u;
-                }
-                qn += __popcll(m);
-                m = __ballot(bits != 0u);
-            }
-            if (qn >= 64) flush(64);
+        const half8 *cur = sbuf[(c - c0) & 1];
+        const int cand0 = c * KNN_ST_TILES * 32 + j32;
+        f32x16 a0, a1;
+        mfma_pair(cur, 0, a0, a1);
+        {
+            const unsigned keep = c > c0 ? ~0u : 0u;  // nothing is pending in the first iteration
+            const unsigned b0 = signs(pa0, py0) & keep, b1 = signs(pa1, py1) & keep;
+            rounds(b0, cand0 - 64);
+            rounds(b1, cand0 - 32);
         }
-        st.swrite(sbuf[(c + 1) & 1], tid);
+        mfma_pair(cur, 2, pa0, pa1);
+        {
+            const unsigned b0 = signs(a0, ycur[0]), b1 = signs(a1, ycur[1]);
+            rounds(b0, cand0);
+            rounds(b1, cand0 + 32);
+        }
+        py0 = ycur[2];
+        py1 = ycur[3];
+        st.swrite(sbuf[(c - c0 + 1) & 1], tid);
 #pragma unroll
         for (int tt = 0; tt < KNN_ST_TILES; ++tt) ycur[tt] = ynext[tt];
+#ifndef KNN_ABLATE_BARRIER  // timing experiment: racy staging
         __syncthreads();
+#endif
+    }
+    {
+        const int cand0 = c1 * KNN_ST_TILES * 32 + j32;
+        const unsigned b0 = signs(pa0, py0), b1 = signs(pa1, py1);
+        rounds(b0, cand0 - 64);
+        rounds(b1, cand0 - 32);
     }
     while (qn > 0) flush(qn < 64 ? qn : 64);
     if (lane == 0) {
-        lcount[wid] = overflow ? 0 : lpos;
-        rbflag[wid] = overflow ? 1 : 0;
+        lcount[2 * wid + part] = overflow ? 0 : lpos;
+        if (overflow) rbflag[wid] = 1;
     }
 }
 
@@ -1007,7 +1137,7 @@ template <int CP, int CAP>
 __global__ __launch_bounds__(64) void knn_refine_kernel(const float *__restrict__ x, const float *__restrict__ xx,
                                                         const unsigned *__restrict__ lists,
                                                         const int *__restrict__ lcount, int *__restrict__ rbflag,
-                                                        int B, int N, int C, int Npad, int k,
+                                                        int B, int N, int C, int Npad, int k, int parts,
                                                         int32_t *__restrict__ idx)
 {
     constexpr int XS = CP + 1;  // LDS row stride of the raw query rows (odd: conflict-free column reads)
@@ -1029,8 +1159,10 @@ __global__ __launch_bounds__(64) void knn_refine_kernel(const float *__restrict_
     const int q0 = rb * 32;
     const float *xxb = xx + (size_t)b * Npad;
     const float *xraw = x + (size_t)b * N * C;
+    // the survivor list comes in `parts` segments (one per candidate part of the filter)
     const unsigned *list = lists + (size_t)wid * KNN_LISTCAP;
-    const int n = lcount[wid];
+    const int n0 = lcount[2 * wid], n = n0 + (parts == 2 ? lcount[2 * wid + 1] : 0);
+    const int seg1 = KNN_LISTCAP / 2 - n0;  // entry e >= n0 lives at list[seg1 + e]
 
     for (int e = lane; e < 32 * CP; e += 64) {
         const int r = e / CP, c = e % CP;
@@ -1044,7 +1176,8 @@ __global__ __launch_bounds__(64) void knn_refine_kernel(const float *__restrict_
 
     for (int base = 0; base < n; base += 64) {
         const bool act = base + lane < n;
-        const unsigned qe = act ? list[base + lane] : 0u;
+        const int e = base + lane;
+        const unsigned qe = act ? list[e < n0 ? e : seg1 + e] : 0u;
         const int row = (int)(qe >> 27), cand = (int)(qe & 0x7ffffffu);
         const float *xl = xraw + (size_t)cand * C;
         float dot = 0.0f;
@@ -1158,7 +1291,7 @@ static void knn_bound_launch(int B, hipStream_t st, const void *xop, const float
 struct KnnWs {
     float *xt, *xx, *xxc, *tau0, *eps, *mu;
     half8 *xh;
-    unsigned *bmax, *lists;
+    unsigned *bmax, *lists, *exch;
     int *f16ok, *lcount, *rbflag;
     size_t bytes;
 };
@@ -1182,26 +1315,27 @@ static KnnWs knn_ws(int B, int C, int N, void *base)
     w.xh = (half8 *)take((size_t)B * npad * cp * sizeof(_Float16));
     w.bmax = (unsigned *)take((size_t)B * 2 * sizeof(unsigned));
     w.f16ok = (int *)take((size_t)B * sizeof(int));
-    w.lcount = (int *)take((size_t)B * (npad / 32) * sizeof(int));
+    w.lcount = (int *)take((size_t)B * (npad / 32) * 2 * sizeof(int));
     w.rbflag = (int *)take((size_t)B * (npad / 32) * sizeof(int));
+    w.exch = (unsigned *)take(cp >= 16 ? (size_t)B * npad * 2 * 64 * sizeof(unsigned) : 0);
     w.lists = (unsigned *)take(cp >= 16 ? (size_t)B * (npad / 32) * KNN_LISTCAP * sizeof(unsigned) : 0);
     w.bytes = off;
     return w;
 }
 
 template <int CP>
-static void knn_f16_launch(int cap, const KnnWs &w, const float *x, int B, int N, int C, int Npad, int k, int32_t *idx,
-                           hipStream_t st)
+static void knn_f16_launch(int cap, int parts, const KnnWs &w, const float *x, int B, int N, int C, int Npad, int k,
+                           int32_t *idx, hipStream_t st)
 {
     const dim3 grid(B * (Npad / 32)), block(64);
-    hipLaunchKernelGGL((knn_filter16_kernel<CP>), dim3(B * (Npad / (32 * KNN_ST_WAVES))), dim3(KNN_ST_THREADS), 0, st, w.xh, w.xxc, w.tau0, w.eps,
-                       w.f16ok, B, Npad, w.lists, w.lcount, w.rbflag);
+    hipLaunchKernelGGL((knn_filter16_kernel<CP>), dim3(B * parts * (Npad / (32 * KNN_ST_WAVES))), dim3(KNN_ST_THREADS), 0,
+                       st, w.xh, w.xxc, w.tau0, w.eps, w.f16ok, B, Npad, parts, w.lists, w.lcount, w.rbflag);
     if (cap == 64)
         hipLaunchKernelGGL((knn_refine_kernel<CP, 64>), grid, block, 0, st, x, w.xx, w.lists, w.lcount, w.rbflag, B, N, C,
-                           Npad, k, idx);
+                           Npad, k, parts, idx);
     else
         hipLaunchKernelGGL((knn_refine_kernel<CP, 128>), grid, block, 0, st, x, w.xx, w.lists, w.lcount, w.rbflag, B, N, C,
-                           Npad, k, idx);
+                           Npad, k, parts, idx);
 }
 
 }  // namespace dgcnn
@@ -1247,6 +1381,9 @@ extern "C" int dgcnn_knn(const float *x, int B, int N, int C, int k, int32_t *id
     const bool prepass = k <= 40 && N >= 256 && !prepass_off;
     const bool f16path = prepass && CP >= 16 && !f16_off;
     const int cap = (k <= 32) ? 64 : 128;
+    // the fp16 streams split the candidates of a row group over two workgroups when there are enough chunks:
+    // twice the waves per SIMD (the streams are latency-bound at 1.7) and 128 instead of 64 threshold classes
+    const int parts = Npad / (32 * KNN_ST_TILES) >= 8 ? 2 : 1;
     if (prepass) {
         // (knn_bound_kernel writes tau0 for every row, padded rows included)
         if (CP >= 16) {
@@ -1256,9 +1393,12 @@ extern "C" int dgcnn_knn(const float *x, int B, int N, int C, int k, int32_t *id
                                Npad, CP, w.xh);
             hipLaunchKernelGGL(knn_cnorm_kernel, dim3(Npad / 16, B), dim3(256), 0, st, x, w.mu, N, C, Npad, w.xxc);
             hipLaunchKernelGGL(knn_bmax_kernel, dim3(B), dim3(1024), 0, st, w.xxc, xx, N, Npad, w.bmax, w.f16ok);
-            const dim3 bgrid(B * (Npad / (32 * KNN_ST_WAVES))), bblock(KNN_ST_THREADS);
-#define DG_BOUND16(CP_) \
-    hipLaunchKernelGGL((knn_bound16s_kernel<CP_>), bgrid, bblock, 0, st, w.xh, w.xxc, xx, w.bmax, B, Npad, k, w.tau0, w.eps)
+            if (hipMemsetAsync(w.rbflag, 0, (size_t)B * (Npad / 32) * sizeof(int), st) != hipSuccess)
+                DG_FAIL("dgcnn_knn: memset failed");
+            const dim3 bgrid(B * parts * (Npad / (32 * KNN_ST_WAVES))), bblock(KNN_ST_THREADS);
+#define DG_BOUND16(CP_)                                                                                              \
+    hipLaunchKernelGGL((knn_bound16s_kernel<CP_>), bgrid, bblock, 0, st, w.xh, w.xxc, xx, w.bmax, B, Npad, k, parts, \
+                       w.exch, w.tau0, w.eps)
             switch (CP) {
                 case 16: DG_BOUND16(16); break;
                 case 32: DG_BOUND16(32); break;
@@ -1266,6 +1406,9 @@ extern "C" int dgcnn_knn(const float *x, int B, int N, int C, int k, int32_t *id
                 default: DG_BOUND16(128); break;
             }
 #undef DG_BOUND16
+            if (parts == 2)
+                hipLaunchKernelGGL(knn_bound_merge_kernel, dim3(B * (Npad / 32)), dim3(64), 0, st, w.exch, w.xxc, xx, w.bmax, B,
+                                   Npad, k, w.tau0, w.eps);
         } else if (CP == 8) {
             knn_bound_launch<8, false>(B, st, xt, xx, xx, w.bmax, Npad, k, w.tau0, nullptr);
         } else {
@@ -1279,10 +1422,10 @@ extern "C" int dgcnn_knn(const float *x, int B, int N, int C, int k, int32_t *id
         // kernels flagged (it returns at once for the others)
         rbflag = w.rbflag;
         switch (CP) {
-            case 16: knn_f16_launch<16>(cap, w, x, B, N, C, Npad, k, idx, st); break;
-            case 32: knn_f16_launch<32>(cap, w, x, B, N, C, Npad, k, idx, st); break;
-            case 64: knn_f16_launch<64>(cap, w, x, B, N, C, Npad, k, idx, st); break;
-            default: knn_f16_launch<128>(cap, w, x, B, N, C, Npad, k, idx, st); break;
+            case 16: knn_f16_launch<16>(cap, parts, w, x, B, N, C, Npad, k, idx, st); break;
+            case 32: knn_f16_launch<32>(cap, parts, w, x, B, N, C, Npad, k, idx, st); break;
+            case 64: knn_f16_launch<64>(cap, parts, w, x, B, N, C, Npad, k, idx, st); break;
+            default: knn_f16_launch<128>(cap, parts, w, x, B, N, C, Npad, k, idx, st); break;
         }
         DG_CHECK_LAUNCH("knn_filter16_kernel / knn_refine_kernel");
     }
