@@ -4,6 +4,8 @@
 
 namespace dgcnn {
 
+typedef unsigned long long u64;
+
 constexpr int EC = 64;  // output channels of every edge convolution (model.py:116-130)
 
 // XCD-aware distribution of points over workgroups.  Blocks are dealt round-robin over the 8

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void edge_reduce_kernel(const float *__restric
                                                           const int32_t *__restrict__ idx, int N, int k, int P,
                                                           const float *__restrict__ gamma, float *__restrict__ usel,
                                                           float *__restrict__ usum, int32_t *__restrict__ hitn,
-                                                          int *__restrict__ indeg, double *__restrict__ partial)
+                                                          double *__restrict__ partial)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool neg = WANT_EXT ? (gamma[lane] < 0.0f) : false;
@@ -87,8 +87,6 @@ __global__ __launch_bounds__(256) void edge_reduce_kernel(const float *__restric
         for (int j0 = 0; j0 < k; j0 += 64) {
             const int kk = k - j0 < 64 ? k - j0 : 64;
             if (j0 > 0) nv = lane < kk ? ip[j0 + lane] : 0;
-            // in-degree of the neighbours (training only): scattered int atomics, hidden under the gather
-            if (indeg && lane < kk) atomicAdd(&indeg[(size_t)b * N + nv], 1);
             for (int j = 0; j < kk; j += 32) {
                 float p[32];
                 int n[32];
@@ -415,25 +413,275 @@ struct ProfState {
 } g_prof;
 }  // namespace
 
-void launch_edge_bwd_nogather(const float *TP, const float *TQ, const int32_t *idx, int B, int N, int k,
-                              const float *stats, const float *cc, float slope, const float *gy, const float *y,
-                              const int32_t *hitn, const float *usum, const float *dv, const int *indeg, float *dR,
-                              float *dD, hipStream_t st)
+// ---------------------------------------------------------------------------------------------
+// Reverse adjacency (CSR by destination) of the kNN graph, and the training-mode stage-1 backward as a GATHER
+// over it.  The scatter form above costs one 256-byte wave-atomic per edge (1.68 M of them at B = 8, N = 7000,
+// k = 30: ~0.33 ms at the float-atomic rate); but A[i] = a0 - alpha TQ[i] is affine in the centre's TQ row, so
+//   dR[m] = indeg(m) a0 - alpha (sum_{i in in(m)} TQ[i] + indeg(m) TP[m]) + sum_{e in in(m)} sc dv[e]
+// needs, per in-edge, one coalesced 256-byte row load and no atomic.  Building the lists costs one integer
+// atomic per edge (cursor bump), 64 times fewer than the float atomics it replaces.  Sparse dv (single-stage
+// block): the P x 64 hit gradients are added to dR with atomics by edge_point_bwd_kernel afterwards.
+// The order of a point's in-edges follows the cursor atomics, so the fp32 sum order can differ between runs
+// (as it did with float atomics).
+// Build, per batch element b (its in-edges occupy [b N k, (b + 1) N k) of `rev`): the sources of a batch element
+// are cut into `chunks` contiguous ranges, one workgroup each, and all counting happens with LDS atomics on an
+// N-entry table (scattered global atomics run at ~20 G/s on MI355X whatever their width: 1.68 M of them cost
+// as much as the whole gather).
+//   rev_count: cnt[b][chunk][m] = edges of the chunk that point at m
+//   rev_degree / rev_scan / rev_slots: indeg[m] = sum over chunks; rowptr = exclusive scan of indeg;
+//              cnt[b][chunk][m] <- first slot of that chunk's edges into m
+//   rev_place: rev[slot++] = edge id, slot from the LDS copy of cnt[b][chunk][.]
+constexpr int REV_THREADS = 1024;
+constexpr int REV_MAX_N = 40000;  // N ints of LDS per workgroup (160 KB per CU)
+
+__global__ __launch_bounds__(REV_THREADS) void rev_count_kernel(const int32_t *__restrict__ idx, int N, int k,
+                                                               int chunks, int *__restrict__ cnt)
 {
-    const int P = B * N;
+    extern __shared__ int table[];
+    const int b = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
+    for (int m = threadIdx.x; m < N; m += REV_THREADS) table[m] = 0;
+    __syncthreads();
+    const int ne = N * k, per = (ne + chunks - 1) / chunks;
+    const int beg = chunk * per, end = beg + per < ne ? beg + per : ne;
+    const int32_t *ib = idx + (size_t)b * ne;
+    for (int e = beg + threadIdx.x; e < end; e += REV_THREADS) atomicAdd(&table[ib[e]], 1);
+    __syncthreads();
+    int *out = cnt + (size_t)blockIdx.x * N;
+    for (int m = threadIdx.x; m < N; m += REV_THREADS) out[m] = table[m];
+}
+
+// indeg[b][m] = sum over chunks of cnt[b][chunk][m]
+__global__ __launch_bounds__(256) void rev_degree_kernel(const int *__restrict__ cnt, int N, int chunks, int P,
+                                                         int *__restrict__ indeg)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= P) return;
+    const int b = g / N, m = g - b * N;
+    const int *cb = cnt + (size_t)b * chunks * N + m;
+    int s = 0;
+    for (int c = 0; c < chunks; ++c) s += cb[(size_t)c * N];
+    indeg[g] = s;
+}
+
+// rowptr = exclusive scan of indeg; one workgroup = one batch element
+__global__ __launch_bounds__(REV_THREADS) void rev_scan_kernel(const int *__restrict__ indeg, int N, int k,
+                                                              int *__restrict__ rowptr)
+{
+    __shared__ int part[REV_THREADS];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int *deg = indeg + (size_t)b * N;
+    const int per = (N + REV_THREADS - 1) / REV_THREADS;
+    const int beg = tid * per < N ? tid * per : N, end = beg + per < N ? beg + per : N;
+    int s = 0;
+    for (int i = beg; i < end; ++i) s += deg[i];
+    part[tid] = s;
+    __syncthreads();
+    for (int off = 1; off < REV_THREADS; off <<= 1) {  // inclusive Hillis-Steele scan
+        const int v = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = b * N * k + part[tid] - s;
+    for (int i = beg; i < end; ++i) {
+        rowptr[(size_t)b * N + i] = run;
+        run += deg[i];
+    }
+    if (b == (int)gridDim.x - 1 && tid == REV_THREADS - 1) rowptr[(size_t)gridDim.x * N] = (int)gridDim.x * N * k;
+}
+
+// cnt[b][chunk][m] <- first slot of chunk's edges into m
+__global__ __launch_bounds__(256) void rev_slots_kernel(const int *__restrict__ rowptr, int N, int chunks, int P,
+                                                        int *__restrict__ cnt)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= P) return;
+    const int b = g / N, m = g - b * N;
+    int *cb = cnt + (size_t)b * chunks * N + m;
+    int slot = rowptr[g];
+    for (int c = 0; c < chunks; ++c) {
+        const int n = cb[(size_t)c * N];
+        cb[(size_t)c * N] = slot;
+        slot += n;
+    }
+}
+
+__global__ __launch_bounds__(REV_THREADS) void rev_place_kernel(const int32_t *__restrict__ idx, int N, int k,
+                                                               int chunks, const int *__restrict__ cnt,
+                                                               int32_t *__restrict__ rev)
+{
+    extern __shared__ int table[];
+    const int b = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
+    const int *first = cnt + (size_t)blockIdx.x * N;
+    for (int m = threadIdx.x; m < N; m += REV_THREADS) table[m] = first[m];
+    __syncthreads();
+    const int ne = N * k, per = (ne + chunks - 1) / chunks;
+    const int beg = chunk * per, end = beg + per < ne ? beg + per : ne;
+    const int32_t *ib = idx + (size_t)b * ne;
+    for (int e = beg + threadIdx.x; e < end; e += REV_THREADS) rev[atomicAdd(&table[ib[e]], 1)] = b * ne + e;
+}
+
+template <bool DENSE>
+__global__ __launch_bounds__(256) void edge_rgather_kernel(const float *__restrict__ TP, const float *__restrict__ TQ,
+                                                           const int *__restrict__ rowptr,
+                                                           const int32_t *__restrict__ rev, int k, int P,
+                                                           const float *__restrict__ stats,
+                                                           const float *__restrict__ cc, const float *__restrict__ dv,
+                                                           const u64 *__restrict__ hmask,
+                                                           const float2 *__restrict__ TG, float *__restrict__ dR)
+{
+    // DENSE: dv [E][64] rows by edge id.  Sparse: hmask[e] = channels whose max-over-k picked edge e, and
+    // TG [P][64] = {TQ, G} pairs, G = sc dL/dv of the centre's surviving edge per channel (both written by
+    // edge_point_bwd_kernel): one 512-byte record per in-edge instead of two row gathers.
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float mean = stats[ST_MEAN + lane], rstd = stats[ST_RSTD + lane], sc = stats[ST_SC + lane];
+    const float c1 = cc[lane], c2 = cc[64 + lane];
+    const float alpha = sc * c2 * rstd, a0 = -sc * (c1 - c2 * rstd * mean);
+    const PointIter it = point_iter(P, wave, EDGE_WAVES);
+    for (int pt = it.cur; pt < it.end; pt += it.step) {
+        const int beg = rowptr[pt], end = rowptr[pt + 1];
+        float s0 = 0.0f, s1 = 0.0f, d0 = 0.0f, d1 = 0.0f;
+        for (int e0 = beg; e0 < end; e0 += 64) {
+            const int cnt = end - e0 < 64 ? end - e0 : 64;
+            const int ev = lane < cnt ? rev[e0 + lane] : 0;
+            const int src = (int)((unsigned)ev / (unsigned)k);
+            u64 hm = 0;
+            if (!DENSE) hm = lane < cnt ? hmask[ev] : 0;
+            const unsigned hlo = (unsigned)hm, hhi = (unsigned)(hm >> 32);
+            for (int t = 0; t < cnt; t += 8) {
+                float q[8], d[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int tt = t + u < cnt ? t + u : t;  // clamped: no branch around the loads
+                    const int i = __builtin_amdgcn_readlane(src, tt);
+                    if (DENSE) {
+                        q[u] = TQ[(size_t)i * EC + lane];
+                        d[u] = dv[(size_t)__builtin_amdgcn_readlane(ev, tt) * EC + lane];
+                    } else {
+                        const float2 tg = TG[(size_t)i * EC + lane];
+                        const unsigned w = lane < 32 ? __builtin_amdgcn_readlane(hlo, tt) : __builtin_amdgcn_readlane(hhi, tt);
+                        q[u] = tg.x;
+                        d[u] = ((w >> (lane & 31)) & 1u) ? tg.y : 0.0f;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const bool on = t + u < cnt;
+                    if (u & 1) {
+                        s1 += on ? q[u] : 0.0f;
+                        d1 += on ? d[u] : 0.0f;
+                    } else {
+                        s0 += on ? q[u] : 0.0f;
+                        d0 += on ? d[u] : 0.0f;
+                    }
+                }
+            }
+        }
+        const float deg = (float)(end - beg);
+        float r = deg * a0 - alpha * ((s0 + s1) + deg * TP[(size_t)pt * EC + lane]);
+        r += DENSE ? sc * (d0 + d1) : (d0 + d1);
+        dR[(size_t)pt * EC + lane] = r;
+    }
+}
+
+// dD[i] = sum_j sc dv[i][j] + k A[i] - alpha (usum[i] - k TQ[i]).  Sparse dv has one non-zero per (i, c), on the
+// edge whose neighbour is hitn[i][c]: the kernel also writes TG[i][c] = {TQ, G = sc dv of that edge} and, per edge, the
+// 64-bit channel mask hmask[e] that edge_rgather_kernel uses to route G into dR.
+template <bool DENSE>
+__global__ __launch_bounds__(256) void edge_point_bwd_kernel(const float *__restrict__ TQ, const int32_t *__restrict__ idx,
+                                                             int N, int k, int P, const float *__restrict__ stats,
+                                                             const float *__restrict__ cc, float slope,
+                                                             const float *__restrict__ gy, const float *__restrict__ y,
+                                                             const int32_t *__restrict__ hitn,
+                                                             const float *__restrict__ usum,
+                                                             const float *__restrict__ dv, u64 *__restrict__ hmask,
+                                                             float2 *__restrict__ TG, float *__restrict__ dD)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float mean = stats[ST_MEAN + lane], rstd = stats[ST_RSTD + lane], sc = stats[ST_SC + lane];
+    const float c1 = cc[lane], c2 = cc[64 + lane];
+    const float alpha = sc * c2 * rstd;
+    const PointIter it = point_iter(P, wave, EDGE_WAVES);
+    for (int pt = it.cur; pt < it.end; pt += it.step) {
+        const size_t o = (size_t)pt * EC + lane;
+        const float q = TQ[o];
+        const float A = -sc * (c1 + c2 * rstd * (q - mean));
+        float dsum;
+        if (DENSE) {
+            float t0 = 0.0f, t1 = 0.0f;
+            const float *dp = dv + (size_t)pt * k * EC + lane;
+            int j = 0;
+            for (; j + 1 < k; j += 2) {
+                t0 += dp[(size_t)j * EC];
+                t1 += dp[(size_t)(j + 1) * EC];
+            }
+            if (j < k) t0 += dp[(size_t)j * EC];
+            dsum = sc * (t0 + t1);
+        } else {
+            const float yv = y[o];
+            dsum = sc * gy[o] * (yv > 0.0f ? 1.0f : slope);
+            TG[o] = float2{q, dsum};
+            const int hit = hitn[o];
+            for (int j0 = 0; j0 < k; j0 += 64) {
+                const int kk = k - j0 < 64 ? k - j0 : 64;
+                const int nv = lane < kk ? idx[(size_t)pt * k + j0 + lane] : -1;
+                u64 mine = 0;
+                for (int j = 0; j < kk; ++j) {
+                    const u64 m = __ballot(hit == __builtin_amdgcn_readlane(nv, j));
+                    if (lane == j) mine = m;
+                }
+                if (lane < kk) hmask[(size_t)pt * k + j0 + lane] = mine;
+            }
+        }
+        dD[o] = dsum + (float)k * A - alpha * (usum[o] - (float)k * q);
+    }
+}
+
+int rev_chunks(int B, int N, int k)
+{
+    // about one workgroup per CU, at least ~4 edges per thread
+    int c = ceil_div(128, B);
+    const int cap = ceil_div(N * k, 4 * REV_THREADS);
+    if (c > cap) c = cap;
+    return c < 1 ? 1 : c;
+}
+
+int launch_edge_bwd_nogather(const float *TP, const float *TQ, const int32_t *idx, int B, int N, int k,
+                             const float *stats, const float *cc, float slope, const float *gy, const float *y,
+                             const int32_t *hitn, const float *usum, const float *dv, int *cnt, int *indeg, int *rowptr,
+                             int32_t *rev, u64 *hmask, float2 *TG, float *dR, float *dD, hipStream_t st)
+{
+    DG_REQUIRE(N <= REV_MAX_N, "dgcnn_edgeconv_bwd: N=%d > %d unsupported in training mode", N, REV_MAX_N);
+    const int P = B * N, chunks = rev_chunks(B, N, k);
+    const size_t lds = (size_t)N * sizeof(int);
+    static bool attr_done = false;
+    if (!attr_done) {  // more than the default 64 KB of dynamic LDS for large N
+        (void)hipFuncSetAttribute((const void *)rev_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, REV_MAX_N * 4);
+        (void)hipFuncSetAttribute((const void *)rev_place_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, REV_MAX_N * 4);
+        attr_done = true;
+    }
     const dim3 grid(edge_grid(P)), block(256);
+    hipLaunchKernelGGL(rev_count_kernel, dim3(B * chunks), dim3(REV_THREADS), lds, st, idx, N, k, chunks, cnt);
+    hipLaunchKernelGGL(rev_degree_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, st, cnt, N, chunks, P, indeg);
+    hipLaunchKernelGGL(rev_scan_kernel, dim3(B), dim3(REV_THREADS), 0, st, indeg, N, k, rowptr);
+    hipLaunchKernelGGL(rev_slots_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, st, rowptr, N, chunks, P, cnt);
+    hipLaunchKernelGGL(rev_place_kernel, dim3(B * chunks), dim3(REV_THREADS), lds, st, idx, N, k, chunks, cnt, rev);
+    if (dv)
+        hipLaunchKernelGGL((edge_point_bwd_kernel<true>), grid, block, 0, st, TQ, idx, N, k, P, stats, cc, slope, gy, y, hitn,
+                           usum, dv, hmask, TG, dD);
+    else
+        hipLaunchKernelGGL((edge_point_bwd_kernel<false>), grid, block, 0, st, TQ, idx, N, k, P, stats, cc, slope, gy, y,
+                           hitn, usum, dv, hmask, TG, dD);
     const bool prof = g_prof.on && g_prof.n < PROF_MAX;
     if (prof) (void)hipEventRecord(g_prof.e0[g_prof.n], st);
     if (dv)
-        hipLaunchKernelGGL((edge_scatter_kernel<true>), grid, block, 0, st, TQ, idx, N, k, P, stats, cc, slope, gy, y,
-                           hitn, usum, dv, dR, dD);
+        hipLaunchKernelGGL((edge_rgather_kernel<true>), grid, block, 0, st, TP, TQ, rowptr, rev, k, P, stats, cc, dv, hmask,
+                           TG, dR);
     else
-        hipLaunchKernelGGL((edge_scatter_kernel<false>), grid, block, 0, st, TQ, idx, N, k, P, stats, cc, slope, gy, y,
-                           hitn, usum, dv, dR, dD);
+        hipLaunchKernelGGL((edge_rgather_kernel<false>), grid, block, 0, st, TP, TQ, rowptr, rev, k, P, stats, cc, dv, hmask,
+                           TG, dR);
     if (prof) (void)hipEventRecord(g_prof.e1[g_prof.n++], st);
-    const size_t n4 = (size_t)P * EC / 4;
-    hipLaunchKernelGGL(edge_r_finish_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, TP, indeg, stats, cc,
-                       n4, dR);
+    return 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -474,15 +722,15 @@ __global__ void graph_feature_bwd_kernel(const float *__restrict__ gout, const i
 
 // ---------------------------------------------------------------------------------------------
 void launch_edge_reduce(const float *TP, const float *TQ, const int32_t *idx, int N, int k, int P, const float *gamma,
-                        float *usel, float *usum, int32_t *hitn, int *indeg, double *partial, hipStream_t st)
+                        float *usel, float *usum, int32_t *hitn, double *partial, hipStream_t st)
 {
     const dim3 grid(edge_grid(P)), block(256);
     if (usel)
         hipLaunchKernelGGL((edge_reduce_kernel<true>), grid, block, 0, st, TP, TQ, idx, N, k, P, gamma, usel, usum, hitn,
-                           indeg, partial);
+                           partial);
     else
         hipLaunchKernelGGL((edge_reduce_kernel<false>), grid, block, 0, st, TP, TQ, idx, N, k, P, gamma, usel, usum, hitn,
-                           indeg, partial);
+                           partial);
 }
 
 void launch_bn_finalize(const double *partial, int nparts, double count, int training, const dgcnn_bn_params &bn,

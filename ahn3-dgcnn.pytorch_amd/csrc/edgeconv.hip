@@ -41,7 +41,6 @@ struct Carver {
 struct SavedLayout {
     float *TP, *TQ, *usel, *usum, *stats1, *stats2;
     int32_t *hitn;
-    int *indeg;
     size_t bytes;
 };
 static SavedLayout saved_layout(const dgcnn_edgeconv_desc *d, void *p)
@@ -54,7 +53,6 @@ static SavedLayout saved_layout(const dgcnn_edgeconv_desc *d, void *p)
     s.usel = c.take<float>(P * EC);
     s.usum = c.take<float>(P * EC);   // sum over k of the stage-1 pre-activation (backward, training mode)
     s.hitn = c.take<int32_t>(P * EC);  // arg-extreme neighbour of a one-stage block
-    s.indeg = c.take<int>(P);          // in-degree of every point in the kNN graph (training mode)
     s.stats1 = c.take<float>(ST_SIZE);
     s.stats2 = c.take<float>(ST_SIZE);
     s.bytes = c.off;
@@ -80,6 +78,9 @@ static FwdWs fwd_ws(const dgcnn_edgeconv_desc *d, void *p)
 struct BwdWs {
     float *wcatT, *wcat, *cc1, *cc2, *dR, *dD, *wg_partial, *wg_sum, *dv1, *dw2_partial;
     double *partial, *bn1_partial;
+    int *cnt, *indeg, *rowptr, *rev;  // reverse adjacency of the kNN graph (training mode)
+    u64 *hmask;
+    float2 *TG;
     size_t bytes;
 };
 static BwdWs bwd_ws(const dgcnn_edgeconv_desc *d, void *p)
@@ -96,6 +97,12 @@ static BwdWs bwd_ws(const dgcnn_edgeconv_desc *d, void *p)
     w.dD = c.take<float>(P * EC);
     w.wg_partial = c.take<float>((size_t)wgrad_chunks((int)P) * 128 * d->C);
     w.wg_sum = c.take<float>((size_t)128 * d->C);
+    w.cnt = c.take<int>((size_t)d->B * rev_chunks(d->B, d->N, d->k) * d->N);
+    w.indeg = c.take<int>(P);
+    w.rowptr = c.take<int>(P + 1);
+    w.rev = c.take<int>(P * d->k);
+    w.hmask = d->n_stage == 1 ? c.take<u64>(P * d->k) : nullptr;
+    w.TG = d->n_stage == 1 ? c.take<float2>(P * EC) : nullptr;
     if (d->n_stage == 2) {
         w.dv1 = c.take<float>(P * d->k * EC);
         w.dw2_partial = c.take<float>((size_t)PART_MAX * EC * EC);
@@ -164,18 +171,13 @@ extern "C" int dgcnn_edgeconv_fwd(const dgcnn_edgeconv_desc *d, const float *x, 
     launch_rowgemm(x, C, nullptr, 0, w.wcatT, 128, s.TP, EC, s.TQ, P, st);
     if (d->n_stage == 1) {
         if (!d->training) launch_bn_finalize(w.partial, 0, E, 0, d->bn1, d->eps, d->momentum, s.stats1, st);
-        int *indeg = d->training ? s.indeg : nullptr;
-        if (indeg && hipMemsetAsync(indeg, 0, (size_t)P * sizeof(int), st) != hipSuccess)
-            DG_FAIL("dgcnn_edgeconv_fwd: hipMemsetAsync failed");
-        launch_edge_reduce(s.TP, s.TQ, idx, N, k, P, d->bn1.weight, s.usel, s.usum, s.hitn, indeg, w.partial, st);
+        launch_edge_reduce(s.TP, s.TQ, idx, N, k, P, d->bn1.weight, s.usel, s.usum, s.hitn, w.partial, st);
         if (d->training)
             launch_bn_finalize(w.partial, edge_grid(P), E, 1, d->bn1, d->eps, d->momentum, s.stats1, st);
         launch_edge_out(s.usel, s.stats1, d->slope, P, y, st);
     } else {
         if (d->training) {
-            if (hipMemsetAsync(s.indeg, 0, (size_t)P * sizeof(int), st) != hipSuccess)
-                DG_FAIL("dgcnn_edgeconv_fwd: hipMemsetAsync failed");
-            launch_edge_reduce(s.TP, s.TQ, idx, N, k, P, d->bn1.weight, nullptr, s.usum, nullptr, s.indeg, w.partial, st);
+            launch_edge_reduce(s.TP, s.TQ, idx, N, k, P, d->bn1.weight, nullptr, s.usum, nullptr, w.partial, st);
             launch_bn_finalize(w.partial, edge_grid(P), E, 1, d->bn1, d->eps, d->momentum, s.stats1, st);
         } else {
             launch_bn_finalize(w.partial, 0, E, 0, d->bn1, d->eps, d->momentum, s.stats1, st);
@@ -207,13 +209,14 @@ extern "C" int dgcnn_edgeconv_bwd(const dgcnn_edgeconv_desc *d, const float *x, 
     const double E = (double)P * k;
 
     launch_prep_wcat(d->w1, C, C, w.wcatT, w.wcat, st);
-    if (hipMemsetAsync(w.dR, 0, (size_t)P * EC * sizeof(float), st) != hipSuccess)
-        DG_FAIL("dgcnn_edgeconv_bwd: hipMemsetAsync failed");
+    if (!d->training && hipMemsetAsync(w.dR, 0, (size_t)P * EC * sizeof(float), st) != hipSuccess)
+        DG_FAIL("dgcnn_edgeconv_bwd: hipMemsetAsync failed");  // eval mode scatters into dR
     if (d->n_stage == 1) {
         launch_bwd_point(gy, s.usel, s.stats1, d->slope, P, E, d->training, w.partial, g->gbn1_w, g->gbn1_b, w.cc1, st);
         if (d->training) {
-            launch_edge_bwd_nogather(s.TP, s.TQ, idx, d->B, N, k, s.stats1, w.cc1, d->slope, gy, y, s.hitn, s.usum, nullptr,
-                                     s.indeg, w.dR, w.dD, st);
+            if (launch_edge_bwd_nogather(s.TP, s.TQ, idx, d->B, N, k, s.stats1, w.cc1, d->slope, gy, y, s.hitn, s.usum,
+                                         nullptr, w.cnt, w.indeg, w.rowptr, w.rev, w.hmask, w.TG, w.dR, w.dD, st))
+                return 1;
         } else {
             launch_edge_bwd(s.TP, s.TQ, idx, N, k, P, s.stats1, w.cc1, d->slope, d->training, gy, y, nullptr, w.dR, w.dD,
                             st);
@@ -225,8 +228,9 @@ extern "C" int dgcnn_edgeconv_bwd(const dgcnn_edgeconv_desc *d, const float *x, 
         launch_sum_partials(w.dw2_partial, mlp_grid(P), EC * EC, g->gw2, st);
         launch_bn_bwd_finalize(w.bn1_partial, mlp_grid(P), E, d->training, g->gbn1_w, g->gbn1_b, w.cc1, st);
         if (d->training) {
-            launch_edge_bwd_nogather(s.TP, s.TQ, idx, d->B, N, k, s.stats1, w.cc1, d->slope, gy, y, nullptr, s.usum, w.dv1,
-                                     s.indeg, w.dR, w.dD, st);
+            if (launch_edge_bwd_nogather(s.TP, s.TQ, idx, d->B, N, k, s.stats1, w.cc1, d->slope, gy, y, nullptr, s.usum,
+                                         w.dv1, w.cnt, w.indeg, w.rowptr, w.rev, nullptr, nullptr, w.dR, w.dD, st))
+                return 1;
         } else {
             launch_edge_bwd(s.TP, s.TQ, idx, N, k, P, s.stats1, w.cc1, d->slope, d->training, gy, y, w.dv1, w.dR, w.dD, st);
         }
