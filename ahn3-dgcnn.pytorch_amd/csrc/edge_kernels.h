@@ -24,17 +24,17 @@ void launch_sum_partials(const float *partial, int nchunk, int n, float *out, hi
 int edge_grid(int P);
 // stats of u = TP[n(i,j)] + TQ[i] over all edges (fp64 partials) and, if usel != NULL, the per
 // (point, channel) extreme of u that survives max-over-k (max if gamma >= 0, min otherwise)
-// usum[i] = sum_j u[i][j]; hitn[i] = neighbour of the first edge attaining the extreme (with usel only)
+// usum[i] = sum_j u[i][j]; hitj[i] = slot j of the first edge attaining the extreme (with usel only)
 void launch_edge_reduce(const float *TP, const float *TQ, const int32_t *idx, int N, int k, int P,
-                        const float *gamma, float *usel, float *usum, int32_t *hitn, double *partial, hipStream_t st);
+                        const float *gamma, float *usel, float *usum, uint8_t *hitj, double *partial, hipStream_t st);
 // training-mode stage-1 backward as a gather over the reverse adjacency of the kNN graph (see edge_stream.hip).
-// Scratch: cnt [B * rev_chunks][N], indeg [P], rowptr [P + 1], rev [E]; sparse dv only: hmask [E], TG [P][64] pairs.
-// dR is overwritten (no zero fill).  dv == NULL: sparse dv from (gy, y, hitn); else dense dv [E][64].
+// Scratch: cnt [B * rev_chunks][N], indeg [P], rowptr [P + 1], rev [E]; sparse dv only: hmask [E], hrec [E][4], G [P][64].
+// dR is overwritten (no zero fill).  dv == NULL: sparse dv from (gy, y, hitj); else dense dv [E][64].
 int rev_chunks(int B, int N, int k);
 int launch_edge_bwd_nogather(const float *TP, const float *TQ, const int32_t *idx, int B, int N, int k,
                              const float *stats, const float *cc, float slope, const float *gy, const float *y,
-                             const int32_t *hitn, const float *usum, const float *dv, int *cnt, int *indeg, int *rowptr,
-                             int32_t *rev, u64 *hmask, float2 *TG, float *dR, float *dD, hipStream_t st);
+                             const uint8_t *hitj, const float *usum, const float *dv, int *cnt, int *indeg, int *rowptr,
+                             int32_t *rev, u64 *hmask, float *hrec, float *G, float *dR, float *dD, hipStream_t st);
 // BatchNorm statistics from the partial sums -> stats[ST_*]; running-statistics update
 void launch_bn_finalize(const double *partial, int nparts, double count, int training, const dgcnn_bn_params &bn,
                         float eps, float momentum, float *stats, hipStream_t st);

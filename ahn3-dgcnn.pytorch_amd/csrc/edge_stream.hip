@@ -48,13 +48,13 @@ __device__ __forceinline__ void block_reduce_store(double (&v)[NV], double *__re
 }
 
 // ---------------------------------------------------------------------------------------------
-// Also written for the backward: usum[i] = sum_j u[i][j] (fp32) and, with WANT_EXT, hitn[i] = the neighbour
-// index of the FIRST edge attaining the extreme (PyTorch's max routes the gradient to the first maximum).
+// Also written for the backward: usum[i] = sum_j u[i][j] (fp32) and, with WANT_EXT, hitj[i] = the slot j (0..k-1)
+// of the FIRST edge attaining the extreme (PyTorch's max routes the gradient to the first maximum).
 template <bool WANT_EXT>
 __global__ __launch_bounds__(256) void edge_reduce_kernel(const float *__restrict__ TP, const float *__restrict__ TQ,
                                                           const int32_t *__restrict__ idx, int N, int k, int P,
                                                           const float *__restrict__ gamma, float *__restrict__ usel,
-                                                          float *__restrict__ usum, int32_t *__restrict__ hitn,
+                                                          float *__restrict__ usum, uint8_t *__restrict__ hitj,
                                                           double *__restrict__ partial)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void edge_reduce_kernel(const float *__restric
                         if (WANT_EXT) {
                             if (neg ? (u < ext) : (u > ext)) {  // strict: the first edge attaining the extreme wins
                                 ext = u;
-                                hit = n[t];
+                                hit = j0 + j + t;
                             }
                         }
                     }
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void edge_reduce_kernel(const float *__restric
         __builtin_nontemporal_store(us, &usum[(size_t)pt * EC + lane]);
         if (WANT_EXT) {
             __builtin_nontemporal_store(ext, &usel[(size_t)pt * EC + lane]);
-            __builtin_nontemporal_store(hit, &hitn[(size_t)pt * EC + lane]);
+            __builtin_nontemporal_store((uint8_t)hit, &hitj[(size_t)pt * EC + lane]);
         }
     }
     block_reduce_store<2>(acc, partial);
@@ -318,91 +318,6 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(const float *__restrict__
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Training-mode stage-1 backward WITHOUT the TP gather.  With alpha = sc c2 rstd and
-//   A[i] = -sc (c1 + c2 rstd (TQ[i] - mean))              (the part of du that is the same for all k edges of i)
-// the edge gradient is  du[i][j] = sc dv[i][j] + A[i] - alpha TP[n(i, j)],  hence
-//   dR[m] = sum_{(i, j) -> m} (sc dv[i][j] + A[i])  -  alpha indeg(m) TP[m]       (scatter, then edge_r_finish)
-//   dD[i] = sum_j sc dv[i][j] + k A[i] - alpha (usum[i] - k TQ[i])                (usum = sum_j u[i][j], forward)
-// so each edge costs one 256-byte wave-atomic and no gather.  Sparse dv (DENSE = false): the whole dL/dy of
-// (i, c) belongs to the edge whose neighbour is hitn[i][c] (recorded by the forward).
-template <bool DENSE>
-__global__ __launch_bounds__(256) void edge_scatter_kernel(const float *__restrict__ TQ, const int32_t *__restrict__ idx,
-                                                           int N, int k, int P, const float *__restrict__ stats,
-                                                           const float *__restrict__ cc, float slope,
-                                                           const float *__restrict__ gy, const float *__restrict__ y,
-                                                           const int32_t *__restrict__ hitn,
-                                                           const float *__restrict__ usum,
-                                                           const float *__restrict__ dv, float *__restrict__ dR,
-                                                           float *__restrict__ dD)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float mean = stats[ST_MEAN + lane], rstd = stats[ST_RSTD + lane], sc = stats[ST_SC + lane];
-    const float c1 = cc[lane], c2 = cc[64 + lane];
-    const float alpha = sc * c2 * rstd;
-    const PointIter it = point_iter(P, wave, EDGE_WAVES);
-    for (int pt = it.cur; pt < it.end; pt += it.step) {
-        const int b = pt / N;
-        float *Rb = dR + (size_t)b * N * EC + lane;
-        const float q = TQ[(size_t)pt * EC + lane];
-        const int32_t *ip = idx + (size_t)pt * k;
-        const float A = -sc * (c1 + c2 * rstd * (q - mean));
-        float dvs = 0.0f;
-        int hit = -1;
-        if (!DENSE) {
-            const float yv = y[(size_t)pt * EC + lane];
-            dvs = sc * gy[(size_t)pt * EC + lane] * (yv > 0.0f ? 1.0f : slope);
-            hit = hitn[(size_t)pt * EC + lane];
-        }
-        float dsum = DENSE ? 0.0f : dvs;
-        for (int j0 = 0; j0 < k; j0 += 64) {
-            const int kk = k - j0 < 64 ? k - j0 : 64;
-            const int nv = lane < kk ? ip[j0 + lane] : 0;
-            for (int j = 0; j < kk; j += 8) {
-                float d[8];
-                if (DENSE) {
-#pragma unroll
-                    for (int t = 0; t < 8; ++t)
-                        if (j + t < kk) d[t] = dv[((size_t)pt * k + j0 + j + t) * EC + lane];
-                }
-#pragma unroll
-                for (int t = 0; t < 8; ++t)
-                    if (j + t < kk) {
-                        const int n = __builtin_amdgcn_readlane(nv, j + t);
-                        float val = A;
-                        if (DENSE) {
-                            const float sd = sc * d[t];
-                            dsum += sd;
-                            val += sd;
-                        } else if (n == hit) {
-                            val += dvs;
-                        }
-                        atomicAdd(Rb + (size_t)n * EC, val);
-                    }
-            }
-        }
-        dD[(size_t)pt * EC + lane] = dsum + (float)k * A - alpha * (usum[(size_t)pt * EC + lane] - (float)k * q);
-    }
-}
-
-// dR[m] -= alpha * indeg(m) * TP[m]
-__global__ void edge_r_finish_kernel(const float *__restrict__ TP, const int *__restrict__ indeg,
-                                     const float *__restrict__ stats, const float *__restrict__ cc, size_t n4,
-                                     float *__restrict__ dR)
-{
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n4) return;
-    const int c = (int)(t & 15) * 4;
-    const float deg = (float)indeg[t >> 4];
-    const float4 p = reinterpret_cast<const float4 *>(TP)[t];
-    float4 r = reinterpret_cast<float4 *>(dR)[t];
-    r.x -= stats[ST_SC + c + 0] * cc[64 + c + 0] * stats[ST_RSTD + c + 0] * deg * p.x;
-    r.y -= stats[ST_SC + c + 1] * cc[64 + c + 1] * stats[ST_RSTD + c + 1] * deg * p.y;
-    r.z -= stats[ST_SC + c + 2] * cc[64 + c + 2] * stats[ST_RSTD + c + 2] * deg * p.z;
-    r.w -= stats[ST_SC + c + 3] * cc[64 + c + 3] * stats[ST_RSTD + c + 3] * deg * p.w;
-    reinterpret_cast<float4 *>(dR)[t] = r;
-}
-
 // ---- measurement hook: events around the scatter kernel (dgcnn_profile_* in dgcnn_hip.h) ----------------
 namespace {
 constexpr int PROF_MAX = 256;
@@ -414,15 +329,19 @@ struct ProfState {
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
-// Reverse adjacency (CSR by destination) of the kNN graph, and the training-mode stage-1 backward as a GATHER
-// over it.  The scatter form above costs one 256-byte wave-atomic per edge (1.68 M of them at B = 8, N = 7000,
-// k = 30: ~0.33 ms at the float-atomic rate); but A[i] = a0 - alpha TQ[i] is affine in the centre's TQ row, so
+// Training-mode stage-1 backward as a GATHER over the reverse adjacency (CSR by destination) of the kNN graph.
+// With alpha = sc c2 rstd and A[i] = -sc (c1 + c2 rstd (TQ[i] - mean)) = a0 - alpha TQ[i] (the part of du that is
+// the same for all k edges of i) the edge gradient is du[i][j] = sc dv[i][j] + A[i] - alpha TP[n(i, j)], hence
 //   dR[m] = indeg(m) a0 - alpha (sum_{i in in(m)} TQ[i] + indeg(m) TP[m]) + sum_{e in in(m)} sc dv[e]
-// needs, per in-edge, one coalesced 256-byte row load and no atomic.  Building the lists costs one integer
-// atomic per edge (cursor bump), 64 times fewer than the float atomics it replaces.  Sparse dv (single-stage
-// block): the P x 64 hit gradients are added to dR with atomics by edge_point_bwd_kernel afterwards.
-// The order of a point's in-edges follows the cursor atomics, so the fp32 sum order can differ between runs
-// (as it did with float atomics).
+//   dD[i] = sum_j sc dv[i][j] + k A[i] - alpha (usum[i] - k TQ[i])                (usum = sum_j u[i][j], forward)
+// The scatter form of dR costs one 256-byte wave-atomic per edge, and global atomics run at ~20 G 64-byte
+// segments per second on MI355X whatever their width (1.68 M edges x 4 segments: 0.4 ms at B = 8, N = 7000,
+// k = 30).  The gather needs one coalesced 256-byte row load per in-edge and no atomic; the lists are built
+// with LDS atomics.  Sparse dv (single-stage block: dL/dy of (i, c) belongs to the one edge that won
+// max-over-k, slot hitj[i][c] from the forward): every edge carries a 64-bit channel mask and a compact
+// record of its first 4 hit values, so the gather adds them without reading a second row (edges with more
+// than 4 hits read the row of G).  The order of a point's in-edges follows the LDS atomics of rev_place, so
+// the fp32 sum order can differ between runs (as it did with float atomics).
 // Build, per batch element b (its in-edges occupy [b N k, (b + 1) N k) of `rev`): the sources of a batch element
 // are cut into `chunks` contiguous ranges, one workgroup each, and all counting happens with LDS atomics on an
 // N-entry table (scattered global atomics run at ~20 G/s on MI355X whatever their width: 1.68 M of them cost
@@ -521,6 +440,8 @@ __global__ __launch_bounds__(REV_THREADS) void rev_place_kernel(const int32_t *_
     for (int e = beg + threadIdx.x; e < end; e += REV_THREADS) rev[atomicAdd(&table[ib[e]], 1)] = b * ne + e;
 }
 
+constexpr int HIT_REC = 4;  // hit values stored per edge
+
 template <bool DENSE>
 __global__ __launch_bounds__(256) void edge_rgather_kernel(const float *__restrict__ TP, const float *__restrict__ TQ,
                                                            const int *__restrict__ rowptr,
@@ -528,79 +449,110 @@ __global__ __launch_bounds__(256) void edge_rgather_kernel(const float *__restri
                                                            const float *__restrict__ stats,
                                                            const float *__restrict__ cc, const float *__restrict__ dv,
                                                            const u64 *__restrict__ hmask,
-                                                           const float2 *__restrict__ TG, float *__restrict__ dR)
+                                                           const float4 *__restrict__ hrec,
+                                                           const float *__restrict__ G, float *__restrict__ dR)
 {
-    // DENSE: dv [E][64] rows by edge id.  Sparse: hmask[e] = channels whose max-over-k picked edge e, and
-    // TG [P][64] = {TQ, G} pairs, G = sc dL/dv of the centre's surviving edge per channel (both written by
-    // edge_point_bwd_kernel): one 512-byte record per in-edge instead of two row gathers.
+    // DENSE: dv [E][64] rows by edge id.  Sparse: hmask[e] = channels whose max-over-k picked edge e, hrec[e] =
+    // G of the first 4 of them in channel order, G [P][64] = sc dL/dv of the centre's surviving edge per channel
+    // (all three written by edge_point_bwd_kernel).
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float mean = stats[ST_MEAN + lane], rstd = stats[ST_RSTD + lane], sc = stats[ST_SC + lane];
     const float c1 = cc[lane], c2 = cc[64 + lane];
     const float alpha = sc * c2 * rstd, a0 = -sc * (c1 - c2 * rstd * mean);
+    __shared__ float sacc[EDGE_WAVES][64];  // sparse dv: hit gradients of the current point, by channel
+    if (!DENSE) sacc[wave][lane] = 0.0f;
     const PointIter it = point_iter(P, wave, EDGE_WAVES);
     for (int pt = it.cur; pt < it.end; pt += it.step) {
-        const int beg = rowptr[pt], end = rowptr[pt + 1];
+        // (wave-uniform values, made visibly so: lane selects of v_readlane must be scalars)
+        const int beg = __builtin_amdgcn_readfirstlane(rowptr[pt]), end = __builtin_amdgcn_readfirstlane(rowptr[pt + 1]);
         float s0 = 0.0f, s1 = 0.0f, d0 = 0.0f, d1 = 0.0f;
         for (int e0 = beg; e0 < end; e0 += 64) {
             const int cnt = end - e0 < 64 ? end - e0 : 64;
             const int ev = lane < cnt ? rev[e0 + lane] : 0;
             const int src = (int)((unsigned)ev / (unsigned)k);
+            // sparse dv: lane t owns in-edge t here -- its channel mask and hit record; the few hits of an edge
+            // (64 per centre over its k edges) go to the channel sums with LDS float atomics, so the cost is per
+            // hit and not per (edge, channel)
             u64 hm = 0;
-            if (!DENSE) hm = lane < cnt ? hmask[ev] : 0;
-            const unsigned hlo = (unsigned)hm, hhi = (unsigned)(hm >> 32);
+            float4 rec = float4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (!DENSE && lane < cnt) {
+                hm = hmask[ev];
+                rec = hrec[ev];
+            }
             for (int t = 0; t < cnt; t += 8) {
                 float q[8], d[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int tt = t + u < cnt ? t + u : t;  // clamped: no branch around the loads
                     const int i = __builtin_amdgcn_readlane(src, tt);
-                    if (DENSE) {
-                        q[u] = TQ[(size_t)i * EC + lane];
-                        d[u] = dv[(size_t)__builtin_amdgcn_readlane(ev, tt) * EC + lane];
-                    } else {
-                        const float2 tg = TG[(size_t)i * EC + lane];
-                        const unsigned w = lane < 32 ? __builtin_amdgcn_readlane(hlo, tt) : __builtin_amdgcn_readlane(hhi, tt);
-                        q[u] = tg.x;
-                        d[u] = ((w >> (lane & 31)) & 1u) ? tg.y : 0.0f;
-                    }
+                    q[u] = TQ[(size_t)i * EC + lane];
+                    if (DENSE) d[u] = dv[(size_t)__builtin_amdgcn_readlane(ev, tt) * EC + lane];
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const bool on = t + u < cnt;
                     if (u & 1) {
                         s1 += on ? q[u] : 0.0f;
-                        d1 += on ? d[u] : 0.0f;
+                        if (DENSE) d1 += on ? d[u] : 0.0f;
                     } else {
                         s0 += on ? q[u] : 0.0f;
-                        d0 += on ? d[u] : 0.0f;
+                        if (DENSE) d0 += on ? d[u] : 0.0f;
+                    }
+                }
+            }
+            if (!DENSE) {
+                const float rv[HIT_REC] = {rec.x, rec.y, rec.z, rec.w};
+#pragma unroll
+                for (int r = 0; r < HIT_REC; ++r) {
+                    if (hm) {
+                        atomicAdd(&sacc[wave][__builtin_ctzll(hm)], rv[r]);
+                        hm &= hm - 1ull;
+                    }
+                }
+                while (__ballot(hm != 0)) {  // rare: more hits on one edge than its record holds
+                    if (hm) {
+                        const int c = __builtin_ctzll(hm);
+                        atomicAdd(&sacc[wave][c], G[(size_t)src * EC + c]);
+                        hm &= hm - 1ull;
                     }
                 }
             }
         }
         const float deg = (float)(end - beg);
         float r = deg * a0 - alpha * ((s0 + s1) + deg * TP[(size_t)pt * EC + lane]);
-        r += DENSE ? sc * (d0 + d1) : (d0 + d1);
+        if (DENSE) {
+            r += sc * (d0 + d1);
+        } else {
+            __builtin_amdgcn_wave_barrier();
+            r += sacc[wave][lane];
+            sacc[wave][lane] = 0.0f;
+            __builtin_amdgcn_wave_barrier();
+        }
         dR[(size_t)pt * EC + lane] = r;
     }
 }
 
 // dD[i] = sum_j sc dv[i][j] + k A[i] - alpha (usum[i] - k TQ[i]).  Sparse dv has one non-zero per (i, c), on the
-// edge whose neighbour is hitn[i][c]: the kernel also writes TG[i][c] = {TQ, G = sc dv of that edge} and, per edge, the
-// 64-bit channel mask hmask[e] that edge_rgather_kernel uses to route G into dR.
+// edge in slot hitj[i][c]: the kernel also writes G[i][c] = sc dv of that edge and, per edge, the 64-bit channel
+// mask hmask[e] and the record hrec[e] that edge_rgather_kernel routes into dR.  The masks of a point are
+// assembled with one 64-bit LDS atomic-or per lane.
 template <bool DENSE>
-__global__ __launch_bounds__(256) void edge_point_bwd_kernel(const float *__restrict__ TQ, const int32_t *__restrict__ idx,
-                                                             int N, int k, int P, const float *__restrict__ stats,
+__global__ __launch_bounds__(256) void edge_point_bwd_kernel(const float *__restrict__ TQ, int N, int k, int P,
+                                                             const float *__restrict__ stats,
                                                              const float *__restrict__ cc, float slope,
                                                              const float *__restrict__ gy, const float *__restrict__ y,
-                                                             const int32_t *__restrict__ hitn,
+                                                             const uint8_t *__restrict__ hitj,
                                                              const float *__restrict__ usum,
                                                              const float *__restrict__ dv, u64 *__restrict__ hmask,
-                                                             float2 *__restrict__ TG, float *__restrict__ dD)
+                                                             float *__restrict__ hrec, float *__restrict__ G,
+                                                             float *__restrict__ dD)
 {
+    __shared__ u64 smask[EDGE_WAVES][128];  // by slot (k <= 96)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float mean = stats[ST_MEAN + lane], rstd = stats[ST_RSTD + lane], sc = stats[ST_SC + lane];
     const float c1 = cc[lane], c2 = cc[64 + lane];
     const float alpha = sc * c2 * rstd;
+    u64 *sm = smask[wave];
     const PointIter it = point_iter(P, wave, EDGE_WAVES);
     for (int pt = it.cur; pt < it.end; pt += it.step) {
         const size_t o = (size_t)pt * EC + lane;
@@ -620,18 +572,19 @@ __global__ __launch_bounds__(256) void edge_point_bwd_kernel(const float *__rest
         } else {
             const float yv = y[o];
             dsum = sc * gy[o] * (yv > 0.0f ? 1.0f : slope);
-            TG[o] = float2{q, dsum};
-            const int hit = hitn[o];
-            for (int j0 = 0; j0 < k; j0 += 64) {
-                const int kk = k - j0 < 64 ? k - j0 : 64;
-                const int nv = lane < kk ? idx[(size_t)pt * k + j0 + lane] : -1;
-                u64 mine = 0;
-                for (int j = 0; j < kk; ++j) {
-                    const u64 m = __ballot(hit == __builtin_amdgcn_readlane(nv, j));
-                    if (lane == j) mine = m;
-                }
-                if (lane < kk) hmask[(size_t)pt * k + j0 + lane] = mine;
-            }
+            G[o] = dsum;
+            const int hj = hitj[o];
+            sm[lane] = 0;
+            sm[64 + lane] = 0;
+            __builtin_amdgcn_wave_barrier();
+            atomicOr(&sm[hj], 1ull << lane);
+            __builtin_amdgcn_wave_barrier();
+            const u64 m = sm[hj];
+            const int rank = __popcll(m & ((1ull << lane) - 1ull));
+            if (rank < HIT_REC) hrec[((size_t)pt * k + hj) * HIT_REC + rank] = dsum;
+            if (lane < k) hmask[(size_t)pt * k + lane] = sm[lane];
+            if (64 + lane < k) hmask[(size_t)pt * k + 64 + lane] = sm[64 + lane];
+            __builtin_amdgcn_wave_barrier();
         }
         dD[o] = dsum + (float)k * A - alpha * (usum[o] - (float)k * q);
     }
@@ -648,8 +601,8 @@ int rev_chunks(int B, int N, int k)
 
 int launch_edge_bwd_nogather(const float *TP, const float *TQ, const int32_t *idx, int B, int N, int k,
                              const float *stats, const float *cc, float slope, const float *gy, const float *y,
-                             const int32_t *hitn, const float *usum, const float *dv, int *cnt, int *indeg, int *rowptr,
-                             int32_t *rev, u64 *hmask, float2 *TG, float *dR, float *dD, hipStream_t st)
+                             const uint8_t *hitj, const float *usum, const float *dv, int *cnt, int *indeg, int *rowptr,
+                             int32_t *rev, u64 *hmask, float *hrec, float *G, float *dR, float *dD, hipStream_t st)
 {
     DG_REQUIRE(N <= REV_MAX_N, "dgcnn_edgeconv_bwd: N=%d > %d unsupported in training mode", N, REV_MAX_N);
     const int P = B * N, chunks = rev_chunks(B, N, k);
@@ -667,19 +620,19 @@ int launch_edge_bwd_nogather(const float *TP, const float *TQ, const int32_t *id
     hipLaunchKernelGGL(rev_slots_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, st, rowptr, N, chunks, P, cnt);
     hipLaunchKernelGGL(rev_place_kernel, dim3(B * chunks), dim3(REV_THREADS), lds, st, idx, N, k, chunks, cnt, rev);
     if (dv)
-        hipLaunchKernelGGL((edge_point_bwd_kernel<true>), grid, block, 0, st, TQ, idx, N, k, P, stats, cc, slope, gy, y, hitn,
-                           usum, dv, hmask, TG, dD);
+        hipLaunchKernelGGL((edge_point_bwd_kernel<true>), grid, block, 0, st, TQ, N, k, P, stats, cc, slope, gy, y, hitj, usum,
+                           dv, hmask, hrec, G, dD);
     else
-        hipLaunchKernelGGL((edge_point_bwd_kernel<false>), grid, block, 0, st, TQ, idx, N, k, P, stats, cc, slope, gy, y,
-                           hitn, usum, dv, hmask, TG, dD);
+        hipLaunchKernelGGL((edge_point_bwd_kernel<false>), grid, block, 0, st, TQ, N, k, P, stats, cc, slope, gy, y, hitj, usum,
+                           dv, hmask, hrec, G, dD);
     const bool prof = g_prof.on && g_prof.n < PROF_MAX;
     if (prof) (void)hipEventRecord(g_prof.e0[g_prof.n], st);
     if (dv)
         hipLaunchKernelGGL((edge_rgather_kernel<true>), grid, block, 0, st, TP, TQ, rowptr, rev, k, P, stats, cc, dv, hmask,
-                           TG, dR);
+                           reinterpret_cast<const float4 *>(hrec), G, dR);
     else
         hipLaunchKernelGGL((edge_rgather_kernel<false>), grid, block, 0, st, TP, TQ, rowptr, rev, k, P, stats, cc, dv, hmask,
-                           TG, dR);
+                           reinterpret_cast<const float4 *>(hrec), G, dR);
     if (prof) (void)hipEventRecord(g_prof.e1[g_prof.n++], st);
     return 0;
 }
@@ -722,14 +675,14 @@ __global__ void graph_feature_bwd_kernel(const float *__restrict__ gout, const i
 
 // ---------------------------------------------------------------------------------------------
 void launch_edge_reduce(const float *TP, const float *TQ, const int32_t *idx, int N, int k, int P, const float *gamma,
-                        float *usel, float *usum, int32_t *hitn, double *partial, hipStream_t st)
+                        float *usel, float *usum, uint8_t *hitj, double *partial, hipStream_t st)
 {
     const dim3 grid(edge_grid(P)), block(256);
     if (usel)
-        hipLaunchKernelGGL((edge_reduce_kernel<true>), grid, block, 0, st, TP, TQ, idx, N, k, P, gamma, usel, usum, hitn,
+        hipLaunchKernelGGL((edge_reduce_kernel<true>), grid, block, 0, st, TP, TQ, idx, N, k, P, gamma, usel, usum, hitj,
                            partial);
     else
-        hipLaunchKernelGGL((edge_reduce_kernel<false>), grid, block, 0, st, TP, TQ, idx, N, k, P, gamma, usel, usum, hitn,
+        hipLaunchKernelGGL((edge_reduce_kernel<false>), grid, block, 0, st, TP, TQ, idx, N, k, P, gamma, usel, usum, hitj,
                            partial);
 }
 

@@ -40,7 +40,7 @@ struct Carver {
 
 struct SavedLayout {
     float *TP, *TQ, *usel, *usum, *stats1, *stats2;
-    int32_t *hitn;
+    uint8_t *hitj;
     size_t bytes;
 };
 static SavedLayout saved_layout(const dgcnn_edgeconv_desc *d, void *p)
@@ -52,7 +52,7 @@ static SavedLayout saved_layout(const dgcnn_edgeconv_desc *d, void *p)
     s.TQ = c.take<float>(P * EC);
     s.usel = c.take<float>(P * EC);
     s.usum = c.take<float>(P * EC);   // sum over k of the stage-1 pre-activation (backward, training mode)
-    s.hitn = c.take<int32_t>(P * EC);  // arg-extreme neighbour of a one-stage block
+    s.hitj = c.take<uint8_t>(P * EC);  // slot of the edge that wins max-over-k (one-stage block)
     s.stats1 = c.take<float>(ST_SIZE);
     s.stats2 = c.take<float>(ST_SIZE);
     s.bytes = c.off;
@@ -80,7 +80,7 @@ struct BwdWs {
     double *partial, *bn1_partial;
     int *cnt, *indeg, *rowptr, *rev;  // reverse adjacency of the kNN graph (training mode)
     u64 *hmask;
-    float2 *TG;
+    float *hrec, *G;
     size_t bytes;
 };
 static BwdWs bwd_ws(const dgcnn_edgeconv_desc *d, void *p)
@@ -102,7 +102,8 @@ static BwdWs bwd_ws(const dgcnn_edgeconv_desc *d, void *p)
     w.rowptr = c.take<int>(P + 1);
     w.rev = c.take<int>(P * d->k);
     w.hmask = d->n_stage == 1 ? c.take<u64>(P * d->k) : nullptr;
-    w.TG = d->n_stage == 1 ? c.take<float2>(P * EC) : nullptr;
+    w.hrec = d->n_stage == 1 ? c.take<float>(P * d->k * 4) : nullptr;
+    w.G = d->n_stage == 1 ? c.take<float>(P * EC) : nullptr;
     if (d->n_stage == 2) {
         w.dv1 = c.take<float>(P * d->k * EC);
         w.dw2_partial = c.take<float>((size_t)PART_MAX * EC * EC);
@@ -171,7 +172,7 @@ extern "C" int dgcnn_edgeconv_fwd(const dgcnn_edgeconv_desc *d, const float *x, 
     launch_rowgemm(x, C, nullptr, 0, w.wcatT, 128, s.TP, EC, s.TQ, P, st);
     if (d->n_stage == 1) {
         if (!d->training) launch_bn_finalize(w.partial, 0, E, 0, d->bn1, d->eps, d->momentum, s.stats1, st);
-        launch_edge_reduce(s.TP, s.TQ, idx, N, k, P, d->bn1.weight, s.usel, s.usum, s.hitn, w.partial, st);
+        launch_edge_reduce(s.TP, s.TQ, idx, N, k, P, d->bn1.weight, s.usel, s.usum, s.hitj, w.partial, st);
         if (d->training)
             launch_bn_finalize(w.partial, edge_grid(P), E, 1, d->bn1, d->eps, d->momentum, s.stats1, st);
         launch_edge_out(s.usel, s.stats1, d->slope, P, y, st);
@@ -214,8 +215,8 @@ extern "C" int dgcnn_edgeconv_bwd(const dgcnn_edgeconv_desc *d, const float *x, 
     if (d->n_stage == 1) {
         launch_bwd_point(gy, s.usel, s.stats1, d->slope, P, E, d->training, w.partial, g->gbn1_w, g->gbn1_b, w.cc1, st);
         if (d->training) {
-            if (launch_edge_bwd_nogather(s.TP, s.TQ, idx, d->B, N, k, s.stats1, w.cc1, d->slope, gy, y, s.hitn, s.usum,
-                                         nullptr, w.cnt, w.indeg, w.rowptr, w.rev, w.hmask, w.TG, w.dR, w.dD, st))
+            if (launch_edge_bwd_nogather(s.TP, s.TQ, idx, d->B, N, k, s.stats1, w.cc1, d->slope, gy, y, s.hitj, s.usum,
+                                         nullptr, w.cnt, w.indeg, w.rowptr, w.rev, w.hmask, w.hrec, w.G, w.dR, w.dD, st))
                 return 1;
         } else {
             launch_edge_bwd(s.TP, s.TQ, idx, N, k, P, s.stats1, w.cc1, d->slope, d->training, gy, y, nullptr, w.dR, w.dD,
@@ -229,7 +230,7 @@ extern "C" int dgcnn_edgeconv_bwd(const dgcnn_edgeconv_desc *d, const float *x, 
         launch_bn_bwd_finalize(w.bn1_partial, mlp_grid(P), E, d->training, g->gbn1_w, g->gbn1_b, w.cc1, st);
         if (d->training) {
             if (launch_edge_bwd_nogather(s.TP, s.TQ, idx, d->B, N, k, s.stats1, w.cc1, d->slope, gy, y, nullptr, s.usum,
-                                         w.dv1, w.cnt, w.indeg, w.rowptr, w.rev, nullptr, nullptr, w.dR, w.dD, st))
+                                         w.dv1, w.cnt, w.indeg, w.rowptr, w.rev, nullptr, nullptr, nullptr, w.dR, w.dD, st))
                 return 1;
         } else {
             launch_edge_bwd(s.TP, s.TQ, idx, N, k, P, s.stats1, w.cc1, d->slope, d->training, gy, y, w.dv1, w.dR, w.dD, st);
