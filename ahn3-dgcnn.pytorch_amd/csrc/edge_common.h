@@ -37,6 +37,10 @@ static inline int point_grid(int P, int waves_per_wg, int max_slots)
 
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.0f ? v : v * slope; }
 
+// fp64 partial records [2][64] written per workgroup by the statistics passes: at most PART_MAX of them, followed
+// in the same buffer by PART_FOLD records of scratch for the folding step of the finalize kernels
+constexpr int PART_MAX = 4096, PART_FOLD = 32;
+
 // stats block of one BatchNorm stage inside `saved`: 4 rows of 64 floats
 enum { ST_MEAN = 0, ST_RSTD = 64, ST_SC = 128, ST_SH = 192, ST_SIZE = 256 };
 

@@ -36,7 +36,7 @@ int launch_edge_bwd_nogather(const float *TP, const float *TQ, const int32_t *id
                              const uint8_t *hitj, const float *usum, const float *dv, int *cnt, int *indeg, int *rowptr,
                              int32_t *rev, u64 *hmask, float *hrec, float *G, float *dR, float *dD, hipStream_t st);
 // BatchNorm statistics from the partial sums -> stats[ST_*]; running-statistics update
-void launch_bn_finalize(const double *partial, int nparts, double count, int training, const dgcnn_bn_params &bn,
+void launch_bn_finalize(double *partial, int nparts, double count, int training, const dgcnn_bn_params &bn,
                         float eps, float momentum, float *stats, hipStream_t st);
 // y = LeakyReLU(sc * usel + sh)
 void launch_edge_out(const float *usel, const float *stats, float slope, int P, float *y, hipStream_t st);
@@ -53,7 +53,7 @@ void launch_graph_feature_fwd(const float *x, const int32_t *idx, int B, int N, 
 void launch_graph_feature_bwd(const float *gout, const int32_t *idx, int B, int N, int C, int k, float *gx,
                               hipStream_t st);
 // generic: finalize (sum_b, sum_g) fp64 partials into gbn_w, gbn_b, cc  (used by both BN stages)
-void launch_bn_bwd_finalize(const double *partial, int nparts, double count, int training, float *gbn_w,
+void launch_bn_bwd_finalize(double *partial, int nparts, double count, int training, float *gbn_w,
                             float *gbn_b, float *cc, hipStream_t st);
 
 // ---- edge_mlp.hip : per-edge 64 -> 64 contraction on MFMA (second stage of blocks 1, 2) ------

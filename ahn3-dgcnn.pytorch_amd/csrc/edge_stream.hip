@@ -21,10 +21,22 @@ namespace dgcnn {
 
 constexpr int EDGE_WAVES = 4;  // waves per workgroup in the streaming passes
 
-int edge_grid(int P)
+// Workgroups per streaming pass (speed only).  The passes are bound by the latency of the row gathers, so the
+// right number is "as many resident waves as the registers allow": measured at B = 8, N = 7000, k = 30
+// (us at 64 / 128 / 256 / 512 slots per XCD): edge_reduce 194 / 115 / 109 / 92, edge_rgather 211 / 152 / 128 / 131,
+// edge_point_bwd 43 / 29 / 24 / 24.
+static int slots_override()
 {
-    static const int slots = getenv("DGCNN_EDGE_SLOTS") ? atoi(getenv("DGCNN_EDGE_SLOTS")) : 128;  // experiments
-    return point_grid(P, EDGE_WAVES, slots);
+    static const int v = getenv("DGCNN_EDGE_SLOTS") ? atoi(getenv("DGCNN_EDGE_SLOTS")) : 0;  // experiments
+    return v;
+}
+int edge_grid(int P)  // edge_reduce / edge_bwd: also the number of fp64 partial records (<= PART_MAX)
+{
+    return point_grid(P, EDGE_WAVES, slots_override() ? slots_override() : 512);
+}
+static int stream_grid(int P)  // passes without partial records
+{
+    return point_grid(P, EDGE_WAVES, slots_override() ? slots_override() : 256);
 }
 
 // sum the per-lane doubles of the workgroup's 4 waves and write partial[blockIdx][which][64]
@@ -127,12 +139,27 @@ __global__ __launch_bounds__(256) void edge_reduce_kernel(const float *__restric
 // association, so the result is deterministic (and identical for every launch geometry).
 constexpr int FIN_WAVES = 16;
 __device__ __forceinline__ void reduce_records(const double *__restrict__ partial, int nparts, double &s0,
-                                               double &s1)
+                                               double &s1, int first = 0)
 {
+    partial += (size_t)first * 2 * 64;
     __shared__ double red[FIN_WAVES][2][64];
     const int c = threadIdx.x & 63, w = threadIdx.x >> 6;
     double a0 = 0.0, a1 = 0.0;
-    for (int g = w; g < nparts; g += FIN_WAVES) {
+    int g = w;
+    for (; g + 3 * FIN_WAVES < nparts; g += 4 * FIN_WAVES) {  // four records in flight, added in record order
+        double v0[4], v1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            v0[u] = partial[((size_t)(g + u * FIN_WAVES) * 2 + 0) * 64 + c];
+            v1[u] = partial[((size_t)(g + u * FIN_WAVES) * 2 + 1) * 64 + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a0 += v0[u];
+            a1 += v1[u];
+        }
+    }
+    for (; g < nparts; g += FIN_WAVES) {
         a0 += partial[((size_t)g * 2 + 0) * 64 + c];
         a1 += partial[((size_t)g * 2 + 1) * 64 + c];
     }
@@ -145,6 +172,32 @@ __device__ __forceinline__ void reduce_records(const double *__restrict__ partia
         s0 += red[i][0][c];
         s1 += red[i][1][c];
     }
+}
+
+// A single workgroup reads its records at one CU's bandwidth (4096 records = 4 MB: ~60 us), so large record
+// sets are first folded to PART_FOLD records by PART_FOLD workgroups (fixed ranges and order: deterministic).
+__global__ __launch_bounds__(1024) void fold_records_kernel(const double *__restrict__ partial, int nparts,
+                                                            double *__restrict__ folded)
+{
+    const int per = (nparts + PART_FOLD - 1) / PART_FOLD;
+    const int first = blockIdx.x * per;
+    int n = nparts - first;
+    n = n < 0 ? 0 : (n < per ? n : per);
+    double s0, s1;
+    reduce_records(partial, n, s0, s1, first);
+    if (threadIdx.x < 64) {
+        folded[((size_t)blockIdx.x * 2 + 0) * 64 + threadIdx.x] = s0;
+        folded[((size_t)blockIdx.x * 2 + 1) * 64 + threadIdx.x] = s1;
+    }
+}
+// returns the record set the finalize kernel should read
+static const double *fold_records(double *partial, int &nparts, hipStream_t st)
+{
+    if (nparts <= 4 * PART_FOLD) return partial;
+    double *folded = partial + (size_t)PART_MAX * 2 * 64;
+    hipLaunchKernelGGL(fold_records_kernel, dim3(PART_FOLD), dim3(1024), 0, st, partial, nparts, folded);
+    nparts = PART_FOLD;
+    return folded;
 }
 
 // one workgroup of 1024 threads; the first wave finishes channel c = lane.
@@ -613,7 +666,7 @@ int launch_edge_bwd_nogather(const float *TP, const float *TQ, const int32_t *id
         (void)hipFuncSetAttribute((const void *)rev_place_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, REV_MAX_N * 4);
         attr_done = true;
     }
-    const dim3 grid(edge_grid(P)), block(256);
+    const dim3 grid(stream_grid(P)), block(256);
     hipLaunchKernelGGL(rev_count_kernel, dim3(B * chunks), dim3(REV_THREADS), lds, st, idx, N, k, chunks, cnt);
     hipLaunchKernelGGL(rev_degree_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, st, cnt, N, chunks, P, indeg);
     hipLaunchKernelGGL(rev_scan_kernel, dim3(B), dim3(REV_THREADS), 0, st, indeg, N, k, rowptr);
@@ -686,10 +739,11 @@ void launch_edge_reduce(const float *TP, const float *TQ, const int32_t *idx, in
                            partial);
 }
 
-void launch_bn_finalize(const double *partial, int nparts, double count, int training, const dgcnn_bn_params &bn,
+void launch_bn_finalize(double *partial, int nparts, double count, int training, const dgcnn_bn_params &bn,
                         float eps, float momentum, float *stats, hipStream_t st)
 {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(1024), 0, st, partial, nparts, count, training, bn, eps,
+    const double *rec = fold_records(partial, nparts, st);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(1024), 0, st, rec, nparts, count, training, bn, eps,
                        momentum, stats);
 }
 
@@ -699,10 +753,11 @@ void launch_edge_out(const float *usel, const float *stats, float slope, int P, 
     hipLaunchKernelGGL(edge_out_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, usel, stats, slope, n4, y);
 }
 
-void launch_bn_bwd_finalize(const double *partial, int nparts, double count, int training, float *gbn_w, float *gbn_b,
+void launch_bn_bwd_finalize(double *partial, int nparts, double count, int training, float *gbn_w, float *gbn_b,
                             float *cc, hipStream_t st)
 {
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(1024), 0, st, partial, nparts, count, training, gbn_w,
+    const double *rec = fold_records(partial, nparts, st);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(1024), 0, st, rec, nparts, count, training, gbn_w,
                        gbn_b, cc);
 }
 

@@ -23,7 +23,6 @@
 
 namespace dgcnn {
 
-constexpr int PART_MAX = 2048;  // upper bound on the number of per-workgroup partial records
 
 struct Carver {
     char *base;
@@ -70,7 +69,7 @@ static FwdWs fwd_ws(const dgcnn_edgeconv_desc *d, void *p)
     FwdWs w;
     w.wcatT = c.take<float>((size_t)(d->C + 1) * 128);
     w.wcat = c.take<float>((size_t)128 * d->C);
-    w.partial = c.take<double>((size_t)PART_MAX * 2 * 64);
+    w.partial = c.take<double>((size_t)(PART_MAX + PART_FOLD) * 2 * 64);
     w.bytes = c.off;
     return w;
 }
@@ -90,7 +89,7 @@ static BwdWs bwd_ws(const dgcnn_edgeconv_desc *d, void *p)
     const size_t P = (size_t)d->B * d->N;
     w.wcatT = c.take<float>((size_t)(d->C + 1) * 128);
     w.wcat = c.take<float>((size_t)128 * d->C);
-    w.partial = c.take<double>((size_t)PART_MAX * 2 * 64);
+    w.partial = c.take<double>((size_t)(PART_MAX + PART_FOLD) * 2 * 64);
     w.cc1 = c.take<float>(128);
     w.cc2 = c.take<float>(128);
     w.dR = c.take<float>(P * EC);
@@ -107,7 +106,7 @@ static BwdWs bwd_ws(const dgcnn_edgeconv_desc *d, void *p)
     if (d->n_stage == 2) {
         w.dv1 = c.take<float>(P * d->k * EC);
         w.dw2_partial = c.take<float>((size_t)PART_MAX * EC * EC);
-        w.bn1_partial = c.take<double>((size_t)PART_MAX * 2 * 64);
+        w.bn1_partial = c.take<double>((size_t)(PART_MAX + PART_FOLD) * 2 * 64);
     } else {
         w.dv1 = nullptr;
         w.dw2_partial = nullptr;

@@ -12,10 +12,10 @@ every rank runs that workload on its own shard (weak scaling: the batch elements
 units) and the step ends with one RCCL all-reduce of the flat parameter-gradient buffer.
 
 Rank 0 prints ONE JSON line (the contract of the build prompt) with two extra objects:
-  roofline     -- the dominant kernel (edge_scatter_kernel, the scatter-add of the first convolution's
-                  backward): algorithmic bytes / its HIP-event time (events recorded inside the C ABI on
-                  the launch stream), against the HBM peak of MI355X_MICROARCH.md; the kNN graph build
-                  (three kernels) is reported beside it as `knn`
+  roofline     -- the dominant kernel (edge_rgather_kernel, the gather over the reverse kNN graph of the
+                  first convolution's backward): algorithmic bytes / its HIP-event time (events recorded
+                  inside the C ABI on the launch stream), against the HBM peak of MI355X_MICROARCH.md; the
+                  kNN graph build is reported beside it as `knn`
   cpu_baseline -- oracle/torch_ref.py (the reference's own PyTorch-CPU op sequence) timed on the
                   host cores of the same box on a bounded sample of the same workload
 """
@@ -38,7 +38,6 @@ import torch.distributed as dist  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md, "HBM3E peak BW" (spec; 6.29 TB/s measured by a float4 copy)
-PEAK_F32_ATOMIC_GBS = 1300.0  # MI355X_MICROARCH.md, "Global float atomics": chip-wide rate of added bytes
 
 
 def make_edge_stage(cin, cout=64):
@@ -174,14 +173,18 @@ def main():
     lib.dgcnn_profile_enable(0)
     if rank == 0:
         P, E = B * N, B * N * k
-        # algorithmic bytes of one edge_scatter_kernel launch: one fp32 [64] row added per
-        # edge, the neighbour index of every edge, and per point the rows TQ, gy, y, hitn, usum (read) and dD (written)
-        scatter_bytes = 4.0 * E * 64 + 4.0 * E + 6 * 4.0 * P * 64
+        # algorithmic bytes of one edge_rgather_kernel launch: per edge one fp32 [64] row of
+        # TQ (two-stage blocks: also one row of dv), its reverse-list entry and (one-stage) the 8-byte channel mask
+        # and 16-byte hit record; per point the list bounds, the TP row (read) and the dR row (written)
+        if args.stages == 1:
+            scatter_bytes = E * (256.0 + 4 + 8 + 16) + P * (8.0 + 256 + 256)
+        else:
+            scatter_bytes = E * (512.0 + 4) + P * (8.0 + 256 + 256)
         achieved = scatter_bytes / (scatter_ms * 1e-3) / 1e9 if scatter_ms > 0 else 0.0
         knn_flops = 2.0 * B * N * N * C  # FLOPs_kNN = 2 B N^2 C
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "scatter_traffic.json")
-        if os.path.exists(tpath):
+        tpath = os.path.join(ROOT, "profiles", "rgather_traffic.json")
+        if args.stages == 1 and os.path.exists(tpath):  # measured on the one-stage workload
             with open(tpath) as f:
                 traffic = json.load(f).get("hbm_bytes_per_launch")
         out = {
@@ -202,13 +205,11 @@ def main():
                                    (" + conv 64->64 + BN + LeakyReLU" if args.stages == 2 else ""),
                        "batch_per_gpu": B, "points": N, "k": k, "channels": C, "stages": args.stages,
                        "parallelism": "dp%d (batch elements sharded, one all-reduce of the flat grad buffer)" % world},
-            "roofline": {"bound": "hbm", "kernel": "edge_scatter_kernel (scatter-add of the first conv's backward, "
-                                                    "global_atomic_add_f32, one 256-B row per edge)",
+            "roofline": {"bound": "hbm", "kernel": "edge_rgather_kernel (first conv's backward as a gather over the "
+                                                    "reverse kNN graph, one 256-B row per edge)",
                          "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
                          "traffic": traffic, "kernel_ms": scatter_ms, "samples": scatter_n,
-                         "algorithmic_bytes_per_launch": scatter_bytes,
-                         "float_atomic_rate": {"achieved": 4.0 * E * 64 / (scatter_ms * 1e-3) / 1e9 if scatter_ms > 0 else 0.0,
-                                               "peak": PEAK_F32_ATOMIC_GBS, "unit": "GB/s of added bytes"}},
+                         "algorithmic_bytes_per_launch": scatter_bytes},
             "knn": {"ms": knn_ms, "algorithmic_flops": knn_flops, "tflops": knn_flops / (knn_ms * 1e-3) / 1e12,
                     "frac_of_f32_mfma_peak": knn_flops / (knn_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                     "note": "whole dgcnn_knn call (prep + fp16 threshold pass + fp16 filter + exact fp32 refine); "
