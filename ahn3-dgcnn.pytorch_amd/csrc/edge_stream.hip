@@ -84,7 +84,9 @@ __global__ __launch_bounds__(256) void edge_reduce_kernel(const float *__restric
     }
     for (; pt < it.end; pt += it.step) {
         const int b = pt / N;
-        const float *Pb = TP + (size_t)b * N * EC + lane;
+        // wave-uniform table base + 32-bit element offsets: each row load is v_readlane, one v_lshl_add and a
+        // global_load with scalar base (64-bit address arithmetic per row costs ~10 scalar instructions)
+        const float *Pb = TP + (size_t)b * N * EC;
         const float q = q_next;
         int nv = nv_next;  // neighbours 0..63 of this point (lane j holds idx[pt][j])
         const int32_t *ip = idx + (size_t)pt * k;
@@ -93,41 +95,60 @@ __global__ __launch_bounds__(256) void edge_reduce_kernel(const float *__restric
             nv_next = lane < k ? __builtin_nontemporal_load(&idx[(size_t)ptn * k + lane]) : 0;
             q_next = __builtin_nontemporal_load(&TQ[(size_t)ptn * EC + lane]);
         }
-        float ext = neg ? __builtin_inff() : -__builtin_inff();
+        // the extreme is tracked on sign-flipped values where gamma < 0 (exact negation), so one comparison serves
+        // both directions
+        const unsigned sgn = neg ? 0x80000000u : 0u;
+        float ext = -__builtin_inff();
         float us = 0.0f;
         int hit = 0;
+        auto row = [&](float pv, int slot) {
+            const float u = pv + q;
+            acc[0] += (double)u;
+            acc[1] = __builtin_fma((double)u, (double)u, acc[1]);
+            us += u;
+            if (WANT_EXT) {
+                const float uf = __uint_as_float(__float_as_uint(u) ^ sgn);
+                const bool better = uf > ext;  // strict: the first edge attaining the extreme wins
+                ext = better ? uf : ext;
+                hit = better ? slot : hit;
+            }
+        };
         for (int j0 = 0; j0 < k; j0 += 64) {
             const int kk = k - j0 < 64 ? k - j0 : 64;
             if (j0 > 0) nv = lane < kk ? ip[j0 + lane] : 0;
             for (int j = 0; j < kk; j += 32) {
+                // all loads of up to 32 rows are issued before the first is consumed, in groups of 8 behind one
+                // uniform branch each; rows past the list end repeat its last row (loaded, never used)
+                const int nrow = kk - j < 32 ? kk - j : 32;
                 float p[32];
-                int n[32];
 #pragma unroll
-                for (int t = 0; t < 32; ++t)
-                    if (j + t < kk) {
-                        n[t] = __builtin_amdgcn_readlane(nv, j + t);
-                        p[t] = Pb[(size_t)n[t] * EC];
-                    }
+                for (int g = 0; g < 4; ++g) {
+                    if (g * 8 < nrow) {
 #pragma unroll
-                for (int t = 0; t < 32; ++t)
-                    if (j + t < kk) {
-                        const float u = p[t] + q;
-                        acc[0] += (double)u;
-                        acc[1] = __builtin_fma((double)u, (double)u, acc[1]);
-                        us += u;
-                        if (WANT_EXT) {
-                            if (neg ? (u < ext) : (u > ext)) {  // strict: the first edge attaining the extreme wins
-                                ext = u;
-                                hit = j0 + j + t;
-                            }
+                        for (int t = 0; t < 8; ++t) {
+                            const int tt = j + g * 8 + t < kk ? j + g * 8 + t : kk - 1;
+                            const unsigned n = (unsigned)__builtin_amdgcn_readlane(nv, tt);
+                            p[g * 8 + t] = Pb[n * (unsigned)EC + (unsigned)lane];
                         }
                     }
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if (g * 8 + 8 <= nrow) {
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) row(p[g * 8 + t], j0 + j + g * 8 + t);
+                    } else if (g * 8 < nrow) {
+#pragma unroll
+                        for (int t = 0; t < 8; ++t)
+                            if (g * 8 + t < nrow) row(p[g * 8 + t], j0 + j + g * 8 + t);
+                    }
+                }
             }
         }
         // streaming outputs bypass the cache hierarchy's retention: the gather table must stay in L2
         __builtin_nontemporal_store(us, &usum[(size_t)pt * EC + lane]);
         if (WANT_EXT) {
-            __builtin_nontemporal_store(ext, &usel[(size_t)pt * EC + lane]);
+            __builtin_nontemporal_store(__uint_as_float(__float_as_uint(ext) ^ sgn), &usel[(size_t)pt * EC + lane]);
             __builtin_nontemporal_store((uint8_t)hit, &hitj[(size_t)pt * EC + lane]);
         }
     }
@@ -538,7 +559,7 @@ __global__ __launch_bounds__(256) void edge_rgather_kernel(const float *__restri
                 for (int u = 0; u < 8; ++u) {
                     const int tt = t + u < cnt ? t + u : t;  // clamped: no branch around the loads
                     const int i = __builtin_amdgcn_readlane(src, tt);
-                    q[u] = TQ[(size_t)i * EC + lane];
+                    q[u] = TQ[(unsigned)i * (unsigned)EC + (unsigned)lane];  // scalar base + 32-bit offset
                     if (DENSE) d[u] = dv[(size_t)__builtin_amdgcn_readlane(ev, tt) * EC + lane];
                 }
 #pragma unroll
