@@ -458,10 +458,11 @@ __global__ __launch_bounds__(256) void rev_degree_kernel(const int *__restrict__
 
 // rowptr = exclusive scan of indeg; one workgroup = one batch element
 __global__ __launch_bounds__(REV_THREADS) void rev_scan_kernel(const int *__restrict__ indeg, int N, int k,
-                                                              int *__restrict__ rowptr)
+                                                              int *__restrict__ rowptr, int *__restrict__ nextra)
 {
     __shared__ int part[REV_THREADS];
     const int b = blockIdx.x, tid = threadIdx.x;
+    if (b == 0 && tid == 0) *nextra = 0;  // counter of rev_heavy_kernel
     const int *deg = indeg + (size_t)b * N;
     const int per = (N + REV_THREADS - 1) / REV_THREADS;
     const int beg = tid * per < N ? tid * per : N, end = beg + per < N ? beg + per : N;
@@ -515,91 +516,186 @@ __global__ __launch_bounds__(REV_THREADS) void rev_place_kernel(const int32_t *_
 }
 
 constexpr int HIT_REC = 4;  // hit values stored per edge
+// what the sparse backward keeps per edge (one 32-byte sector, read once by the gather): the channels whose
+// max-over-k picked this edge and the gradient of the first HIT_REC of them (measured: records written in
+// reverse-list order make the gather's read coalesced but cost more as scattered writes: 101 + 60 us against
+// 113 + 27 us)
+struct __attribute__((aligned(16))) HitRec {
+    u64 mask;
+    float v[HIT_REC];
+    u64 pad;
+};
+static_assert(sizeof(HitRec) == 32, "HitRec is one 32-byte sector");
 
+// kNN graphs in feature space have hubs (at B = 8, N = 7000, k = 30 on Gaussian features: median in-degree 12,
+// maximum 1372), and one wave walking a hub's list alone would set the kernel time.  A point's list is therefore
+// cut into segments of REV_SEG in-edges: edge_rgather_kernel<., false> does segment 0 of every point and writes
+// dR, rev_heavy_kernel lists the remaining (point, segment) pairs, and edge_rgather_kernel<., true> adds those
+// with one 256-byte wave-atomic each.
+constexpr int REV_SEG = 128;
+
+__global__ __launch_bounds__(256) void rev_heavy_kernel(const int *__restrict__ rowptr, int P, int *__restrict__ nextra,
+                                                        int2 *__restrict__ extra)
+{
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= P) return;
+    const int deg = rowptr[m + 1] - rowptr[m];
+    if (deg <= REV_SEG) return;
+    const int n = (deg - 1) / REV_SEG;  // segments 1 .. n
+    const int base = atomicAdd(nextra, n);
+    for (int sgm = 0; sgm < n; ++sgm) extra[base + sgm] = int2{m, sgm + 1};
+}
+
+// sums over the list entries [beg, end) (at most REV_SEG; ev_first = entries beg .. beg + 63 in the lanes):
+// sq = sum of the sources' TQ rows, sd = sum of their dv rows (DENSE); sparse hits go to sacc[channel]
 template <bool DENSE>
+__device__ __forceinline__ void rgather_segment(const float *__restrict__ TQ, const int32_t *__restrict__ rev, int k,
+                                                const float *__restrict__ dv, const HitRec *__restrict__ hits,
+                                                const float *__restrict__ G, int beg, int end, int ev_first,
+                                                float *sacc, int lane, float &sq, float &sd)
+{
+    float s0 = 0.0f, s1 = 0.0f, d0 = 0.0f, d1 = 0.0f;
+    for (int e0 = beg; e0 < end; e0 += 64) {
+        const int cnt = end - e0 < 64 ? end - e0 : 64;
+        const int ev = e0 == beg ? ev_first : (lane < cnt ? rev[e0 + lane] : 0);
+        const int src = (int)((unsigned)ev / (unsigned)k);
+        // sparse dv: lane t owns in-edge t here -- its channel mask and hit record; the few hits of an edge
+        // (64 per centre over its k edges) go to the channel sums with LDS float atomics, so the cost is per
+        // hit and not per (edge, channel)
+        u64 hm = 0;
+        float4 rec = float4{0.0f, 0.0f, 0.0f, 0.0f};
+#ifndef RG_ABLATE_HITS  // timing experiment: no hit records (results are wrong)
+        if (!DENSE && lane < cnt) {
+            const HitRec *h = hits + ev;
+            hm = h->mask;
+            rec = *reinterpret_cast<const float4 *>(h->v);
+        }
+#endif
+        // 8 rows in flight per wave (16, as two groups, measured slower: most lists are short)
+        for (int t = 0; t < cnt; t += 8) {
+            float q[8], d[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int tt = t + u < cnt ? t + u : t;  // clamped: no branch around the loads
+                const int i = __builtin_amdgcn_readlane(src, tt);
+                q[u] = TQ[(unsigned)i * (unsigned)EC + (unsigned)lane];  // scalar base + 32-bit offset
+                if (DENSE) d[u] = dv[(size_t)__builtin_amdgcn_readlane(ev, tt) * EC + lane];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool on = t + u < cnt;
+                if (u & 1) {
+                    s1 += on ? q[u] : 0.0f;
+                    if (DENSE) d1 += on ? d[u] : 0.0f;
+                } else {
+                    s0 += on ? q[u] : 0.0f;
+                    if (DENSE) d0 += on ? d[u] : 0.0f;
+                }
+            }
+        }
+        if (!DENSE) {
+            const float rv[HIT_REC] = {rec.x, rec.y, rec.z, rec.w};
+#pragma unroll
+            for (int r = 0; r < HIT_REC; ++r) {
+                if (hm) {
+                    atomicAdd(&sacc[__builtin_ctzll(hm)], rv[r]);
+                    hm &= hm - 1ull;
+                }
+            }
+            while (__ballot(hm != 0)) {  // rare: more hits on one edge than its record holds
+                if (hm) {
+                    const int c = __builtin_ctzll(hm);
+                    atomicAdd(&sacc[c], G[(size_t)src * EC + c]);
+                    hm &= hm - 1ull;
+                }
+            }
+        }
+    }
+    sq = s0 + s1;
+    sd = d0 + d1;
+}
+
+template <bool DENSE, bool EXTRA>
 __global__ __launch_bounds__(256) void edge_rgather_kernel(const float *__restrict__ TP, const float *__restrict__ TQ,
                                                            const int *__restrict__ rowptr,
                                                            const int32_t *__restrict__ rev, int k, int P,
                                                            const float *__restrict__ stats,
                                                            const float *__restrict__ cc, const float *__restrict__ dv,
-                                                           const u64 *__restrict__ hmask,
-                                                           const float4 *__restrict__ hrec,
-                                                           const float *__restrict__ G, float *__restrict__ dR)
+                                                           const HitRec *__restrict__ hits,
+                                                           const float *__restrict__ G, const int *__restrict__ nextra,
+                                                           const int2 *__restrict__ extra, float *__restrict__ dR)
 {
-    // DENSE: dv [E][64] rows by edge id.  Sparse: hmask[e] = channels whose max-over-k picked edge e, hrec[e] =
-    // G of the first 4 of them in channel order, G [P][64] = sc dL/dv of the centre's surviving edge per channel
-    // (all three written by edge_point_bwd_kernel).
+    // DENSE: dv [E][64] rows by edge id.  Sparse: hits[e] by edge id and G [P][64] = sc dL/dv of the centre's
+    // surviving edge per channel, both written by edge_point_bwd_kernel.
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float mean = stats[ST_MEAN + lane], rstd = stats[ST_RSTD + lane], sc = stats[ST_SC + lane];
     const float c1 = cc[lane], c2 = cc[64 + lane];
     const float alpha = sc * c2 * rstd, a0 = -sc * (c1 - c2 * rstd * mean);
-    __shared__ float sacc[EDGE_WAVES][64];  // sparse dv: hit gradients of the current point, by channel
-    if (!DENSE) sacc[wave][lane] = 0.0f;
-    const PointIter it = point_iter(P, wave, EDGE_WAVES);
-    for (int pt = it.cur; pt < it.end; pt += it.step) {
-        // (wave-uniform values, made visibly so: lane selects of v_readlane must be scalars)
-        const int beg = __builtin_amdgcn_readfirstlane(rowptr[pt]), end = __builtin_amdgcn_readfirstlane(rowptr[pt + 1]);
-        float s0 = 0.0f, s1 = 0.0f, d0 = 0.0f, d1 = 0.0f;
-        for (int e0 = beg; e0 < end; e0 += 64) {
-            const int cnt = end - e0 < 64 ? end - e0 : 64;
-            const int ev = lane < cnt ? rev[e0 + lane] : 0;
-            const int src = (int)((unsigned)ev / (unsigned)k);
-            // sparse dv: lane t owns in-edge t here -- its channel mask and hit record; the few hits of an edge
-            // (64 per centre over its k edges) go to the channel sums with LDS float atomics, so the cost is per
-            // hit and not per (edge, channel)
-            u64 hm = 0;
-            float4 rec = float4{0.0f, 0.0f, 0.0f, 0.0f};
-            if (!DENSE && lane < cnt) {
-                hm = hmask[ev];
-                rec = hrec[ev];
+    __shared__ float sacc_all[EDGE_WAVES][64];  // sparse dv: hit gradients of the current point, by channel
+    float *sacc = sacc_all[wave];
+    if (!DENSE) sacc[lane] = 0.0f;
+    if (EXTRA) {
+        const int n = *nextra;
+        for (int w = blockIdx.x * EDGE_WAVES + wave; w < n; w += gridDim.x * EDGE_WAVES) {
+            const int2 ps = extra[w];
+            const int pbeg = __builtin_amdgcn_readfirstlane(rowptr[ps.x]), pend = __builtin_amdgcn_readfirstlane(rowptr[ps.x + 1]);
+            const int beg = pbeg + __builtin_amdgcn_readfirstlane(ps.y) * REV_SEG;
+            const int end = beg + REV_SEG < pend ? beg + REV_SEG : pend;
+            const int ev_first = lane < end - beg ? rev[beg + lane] : 0;
+            float sq, sd;
+            rgather_segment<DENSE>(TQ, rev, k, dv, hits, G, beg, end, ev_first, sacc, lane, sq, sd);
+            float r = -alpha * sq;
+            if (DENSE) {
+                r += sc * sd;
+            } else {
+                __builtin_amdgcn_wave_barrier();
+                r += sacc[lane];
+                sacc[lane] = 0.0f;
+                __builtin_amdgcn_wave_barrier();
             }
-            for (int t = 0; t < cnt; t += 8) {
-                float q[8], d[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int tt = t + u < cnt ? t + u : t;  // clamped: no branch around the loads
-                    const int i = __builtin_amdgcn_readlane(src, tt);
-                    q[u] = TQ[(unsigned)i * (unsigned)EC + (unsigned)lane];  // scalar base + 32-bit offset
-                    if (DENSE) d[u] = dv[(size_t)__builtin_amdgcn_readlane(ev, tt) * EC + lane];
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const bool on = t + u < cnt;
-                    if (u & 1) {
-                        s1 += on ? q[u] : 0.0f;
-                        if (DENSE) d1 += on ? d[u] : 0.0f;
-                    } else {
-                        s0 += on ? q[u] : 0.0f;
-                        if (DENSE) d0 += on ? d[u] : 0.0f;
-                    }
-                }
-            }
-            if (!DENSE) {
-                const float rv[HIT_REC] = {rec.x, rec.y, rec.z, rec.w};
-#pragma unroll
-                for (int r = 0; r < HIT_REC; ++r) {
-                    if (hm) {
-                        atomicAdd(&sacc[wave][__builtin_ctzll(hm)], rv[r]);
-                        hm &= hm - 1ull;
-                    }
-                }
-                while (__ballot(hm != 0)) {  // rare: more hits on one edge than its record holds
-                    if (hm) {
-                        const int c = __builtin_ctzll(hm);
-                        atomicAdd(&sacc[wave][c], G[(size_t)src * EC + c]);
-                        hm &= hm - 1ull;
-                    }
-                }
-            }
+            atomicAdd(dR + (size_t)__builtin_amdgcn_readfirstlane(ps.x) * EC + lane, r);
         }
+        return;
+    }
+    const PointIter it = point_iter(P, wave, EDGE_WAVES);
+    // The chain list bounds -> list entries -> rows is three dependent loads deep, so it is software-pipelined
+    // across the points of a wave: the bounds are fetched two points ahead, the first 64 list entries one.
+    int pt = it.cur;
+    int beg_n = 0, end_n = 0, ev_n = 0;  // bounds (uniform) and first entries of the point about to be processed
+    int b0_nn = 0, b1_nn = 0;            // bounds of the point after it, in flight
+    if (pt < it.end) {
+        beg_n = __builtin_amdgcn_readfirstlane(rowptr[pt]);
+        end_n = __builtin_amdgcn_readfirstlane(rowptr[pt + 1]);
+        ev_n = lane < end_n - beg_n ? rev[beg_n + lane] : 0;
+        if (pt + it.step < it.end) {
+            b0_nn = rowptr[pt + it.step];
+            b1_nn = rowptr[pt + it.step + 1];
+        }
+    }
+    for (; pt < it.end; pt += it.step) {
+        // (wave-uniform values are made visibly so: lane selects of v_readlane must be scalars)
+        const int beg = beg_n, end = end_n;
+        const int ev_first = ev_n;
+        if (pt + it.step < it.end) {
+            beg_n = __builtin_amdgcn_readfirstlane(b0_nn);
+            end_n = __builtin_amdgcn_readfirstlane(b1_nn);
+            ev_n = lane < end_n - beg_n ? rev[beg_n + lane] : 0;
+        }
+        if (pt + 2 * it.step < it.end) {
+            b0_nn = rowptr[pt + 2 * it.step];
+            b1_nn = rowptr[pt + 2 * it.step + 1];
+        }
+        float sq, sd;
+        rgather_segment<DENSE>(TQ, rev, k, dv, hits, G, beg, beg + REV_SEG < end ? beg + REV_SEG : end, ev_first, sacc,
+                               lane, sq, sd);
         const float deg = (float)(end - beg);
-        float r = deg * a0 - alpha * ((s0 + s1) + deg * TP[(size_t)pt * EC + lane]);
+        float r = deg * a0 - alpha * (sq + deg * TP[(size_t)pt * EC + lane]);
         if (DENSE) {
-            r += sc * (d0 + d1);
+            r += sc * sd;
         } else {
             __builtin_amdgcn_wave_barrier();
-            r += sacc[wave][lane];
-            sacc[wave][lane] = 0.0f;
+            r += sacc[lane];
+            sacc[lane] = 0.0f;
             __builtin_amdgcn_wave_barrier();
         }
         dR[(size_t)pt * EC + lane] = r;
@@ -607,9 +703,9 @@ __global__ __launch_bounds__(256) void edge_rgather_kernel(const float *__restri
 }
 
 // dD[i] = sum_j sc dv[i][j] + k A[i] - alpha (usum[i] - k TQ[i]).  Sparse dv has one non-zero per (i, c), on the
-// edge in slot hitj[i][c]: the kernel also writes G[i][c] = sc dv of that edge and, per edge, the 64-bit channel
-// mask hmask[e] and the record hrec[e] that edge_rgather_kernel routes into dR.  The masks of a point are
-// assembled with one 64-bit LDS atomic-or per lane.
+// edge in slot hitj[i][c]: the kernel also writes G[i][c] = sc dv of that edge and the HitRec of every edge of
+// the point.  The records of a point are assembled in LDS:
+// one 64-bit atomic-or per channel lane builds the masks, then lane j owns edge j.
 template <bool DENSE>
 __global__ __launch_bounds__(256) void edge_point_bwd_kernel(const float *__restrict__ TQ, int N, int k, int P,
                                                              const float *__restrict__ stats,
@@ -617,11 +713,12 @@ __global__ __launch_bounds__(256) void edge_point_bwd_kernel(const float *__rest
                                                              const float *__restrict__ gy, const float *__restrict__ y,
                                                              const uint8_t *__restrict__ hitj,
                                                              const float *__restrict__ usum,
-                                                             const float *__restrict__ dv, u64 *__restrict__ hmask,
-                                                             float *__restrict__ hrec, float *__restrict__ G,
+                                                             const float *__restrict__ dv,
+                                                             HitRec *__restrict__ hits, float *__restrict__ G,
                                                              float *__restrict__ dD)
 {
-    __shared__ u64 smask[EDGE_WAVES][128];  // by slot (k <= 96)
+    __shared__ u64 smask[EDGE_WAVES][128];          // by slot (k <= 96)
+    __shared__ float sval[EDGE_WAVES][128][HIT_REC];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float mean = stats[ST_MEAN + lane], rstd = stats[ST_RSTD + lane], sc = stats[ST_SC + lane];
     const float c1 = cc[lane], c2 = cc[64 + lane];
@@ -653,11 +750,19 @@ __global__ __launch_bounds__(256) void edge_point_bwd_kernel(const float *__rest
             __builtin_amdgcn_wave_barrier();
             atomicOr(&sm[hj], 1ull << lane);
             __builtin_amdgcn_wave_barrier();
-            const u64 m = sm[hj];
-            const int rank = __popcll(m & ((1ull << lane) - 1ull));
-            if (rank < HIT_REC) hrec[((size_t)pt * k + hj) * HIT_REC + rank] = dsum;
-            if (lane < k) hmask[(size_t)pt * k + lane] = sm[lane];
-            if (64 + lane < k) hmask[(size_t)pt * k + 64 + lane] = sm[64 + lane];
+            const int rank = __popcll(sm[hj] & ((1ull << lane) - 1ull));
+            if (rank < HIT_REC) sval[wave][hj][rank] = dsum;
+            __builtin_amdgcn_wave_barrier();
+            if (lane < k) {
+                HitRec *h = hits + (size_t)pt * k + lane;
+                h->mask = sm[lane];
+                *reinterpret_cast<float4 *>(h->v) = *reinterpret_cast<const float4 *>(sval[wave][lane]);
+            }
+            if (64 + lane < k) {
+                HitRec *h = hits + (size_t)pt * k + 64 + lane;
+                h->mask = sm[64 + lane];
+                *reinterpret_cast<float4 *>(h->v) = *reinterpret_cast<const float4 *>(sval[wave][64 + lane]);
+            }
             __builtin_amdgcn_wave_barrier();
         }
         dD[o] = dsum + (float)k * A - alpha * (usum[o] - (float)k * q);
@@ -676,7 +781,7 @@ int rev_chunks(int B, int N, int k)
 int launch_edge_bwd_nogather(const float *TP, const float *TQ, const int32_t *idx, int B, int N, int k,
                              const float *stats, const float *cc, float slope, const float *gy, const float *y,
                              const uint8_t *hitj, const float *usum, const float *dv, int *cnt, int *indeg, int *rowptr,
-                             int32_t *rev, u64 *hmask, float *hrec, float *G, float *dR, float *dD, hipStream_t st)
+                             int32_t *rev, int *extra, void *hits, float *G, float *dR, float *dD, hipStream_t st)
 {
     DG_REQUIRE(N <= REV_MAX_N, "dgcnn_edgeconv_bwd: N=%d > %d unsupported in training mode", N, REV_MAX_N);
     const int P = B * N, chunks = rev_chunks(B, N, k);
@@ -690,23 +795,32 @@ int launch_edge_bwd_nogather(const float *TP, const float *TQ, const int32_t *id
     const dim3 grid(stream_grid(P)), block(256);
     hipLaunchKernelGGL(rev_count_kernel, dim3(B * chunks), dim3(REV_THREADS), lds, st, idx, N, k, chunks, cnt);
     hipLaunchKernelGGL(rev_degree_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, st, cnt, N, chunks, P, indeg);
-    hipLaunchKernelGGL(rev_scan_kernel, dim3(B), dim3(REV_THREADS), 0, st, indeg, N, k, rowptr);
+    int *nextra = extra;                                      // [0]: counter, then (point, segment) pairs
+    int2 *elist = reinterpret_cast<int2 *>(extra + 2);
+    hipLaunchKernelGGL(rev_scan_kernel, dim3(B), dim3(REV_THREADS), 0, st, indeg, N, k, rowptr, nextra);
     hipLaunchKernelGGL(rev_slots_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, st, rowptr, N, chunks, P, cnt);
     hipLaunchKernelGGL(rev_place_kernel, dim3(B * chunks), dim3(REV_THREADS), lds, st, idx, N, k, chunks, cnt, rev);
+    hipLaunchKernelGGL(rev_heavy_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, st, rowptr, P, nextra, elist);
     if (dv)
         hipLaunchKernelGGL((edge_point_bwd_kernel<true>), grid, block, 0, st, TQ, N, k, P, stats, cc, slope, gy, y, hitj, usum,
-                           dv, hmask, hrec, G, dD);
+                           dv, (HitRec *)hits, G, dD);
     else
         hipLaunchKernelGGL((edge_point_bwd_kernel<false>), grid, block, 0, st, TQ, N, k, P, stats, cc, slope, gy, y, hitj, usum,
-                           dv, hmask, hrec, G, dD);
+                           dv, (HitRec *)hits, G, dD);
     const bool prof = g_prof.on && g_prof.n < PROF_MAX;
     if (prof) (void)hipEventRecord(g_prof.e0[g_prof.n], st);
-    if (dv)
-        hipLaunchKernelGGL((edge_rgather_kernel<true>), grid, block, 0, st, TP, TQ, rowptr, rev, k, P, stats, cc, dv, hmask,
-                           reinterpret_cast<const float4 *>(hrec), G, dR);
-    else
-        hipLaunchKernelGGL((edge_rgather_kernel<false>), grid, block, 0, st, TP, TQ, rowptr, rev, k, P, stats, cc, dv, hmask,
-                           reinterpret_cast<const float4 *>(hrec), G, dR);
+    const dim3 xgrid(1024);  // extra segments: a few thousand at most, about one per wave
+    if (dv) {
+        hipLaunchKernelGGL((edge_rgather_kernel<true, false>), grid, block, 0, st, TP, TQ, rowptr, rev, k, P, stats, cc, dv,
+                           (const HitRec *)hits, G, nextra, elist, dR);
+        hipLaunchKernelGGL((edge_rgather_kernel<true, true>), xgrid, block, 0, st, TP, TQ, rowptr, rev, k, P, stats, cc, dv,
+                           (const HitRec *)hits, G, nextra, elist, dR);
+    } else {
+        hipLaunchKernelGGL((edge_rgather_kernel<false, false>), grid, block, 0, st, TP, TQ, rowptr, rev, k, P, stats, cc, dv,
+                           (const HitRec *)hits, G, nextra, elist, dR);
+        hipLaunchKernelGGL((edge_rgather_kernel<false, true>), xgrid, block, 0, st, TP, TQ, rowptr, rev, k, P, stats, cc, dv,
+                           (const HitRec *)hits, G, nextra, elist, dR);
+    }
     if (prof) (void)hipEventRecord(g_prof.e1[g_prof.n++], st);
     return 0;
 }

@@ -77,9 +77,9 @@ static FwdWs fwd_ws(const dgcnn_edgeconv_desc *d, void *p)
 struct BwdWs {
     float *wcatT, *wcat, *cc1, *cc2, *dR, *dD, *wg_partial, *wg_sum, *dv1, *dw2_partial;
     double *partial, *bn1_partial;
-    int *cnt, *indeg, *rowptr, *rev;  // reverse adjacency of the kNN graph (training mode)
-    u64 *hmask;
-    float *hrec, *G;
+    int *cnt, *indeg, *rowptr, *rev, *extra;  // reverse adjacency of the kNN graph (training mode)
+    void *hits;
+    float *G;
     size_t bytes;
 };
 static BwdWs bwd_ws(const dgcnn_edgeconv_desc *d, void *p)
@@ -100,8 +100,8 @@ static BwdWs bwd_ws(const dgcnn_edgeconv_desc *d, void *p)
     w.indeg = c.take<int>(P);
     w.rowptr = c.take<int>(P + 1);
     w.rev = c.take<int>(P * d->k);
-    w.hmask = d->n_stage == 1 ? c.take<u64>(P * d->k) : nullptr;
-    w.hrec = d->n_stage == 1 ? c.take<float>(P * d->k * 4) : nullptr;
+    w.extra = c.take<int>(2 + 2 * (P * d->k / 128 + 1));  // counter + (point, segment) pairs of long in-edge lists
+    w.hits = d->n_stage == 1 ? (void *)c.take<u64>(P * d->k * 4) : nullptr;  // 32 bytes per edge
     w.G = d->n_stage == 1 ? c.take<float>(P * EC) : nullptr;
     if (d->n_stage == 2) {
         w.dv1 = c.take<float>(P * d->k * EC);
@@ -216,7 +216,7 @@ extern "C" int dgcnn_edgeconv_bwd(const dgcnn_edgeconv_desc *d, const float *x, 
         launch_bwd_point(gy, s.usel, s.stats1, d->slope, P, E, d->training, w.partial, g->gbn1_w, g->gbn1_b, w.cc1, st);
         if (d->training) {
             if (launch_edge_bwd_nogather(s.TP, s.TQ, idx, d->B, N, k, s.stats1, w.cc1, d->slope, gy, y, s.hitj, s.usum,
-                                         nullptr, w.cnt, w.indeg, w.rowptr, w.rev, w.hmask, w.hrec, w.G, w.dR, w.dD, st))
+                                         nullptr, w.cnt, w.indeg, w.rowptr, w.rev, w.extra, w.hits, w.G, w.dR, w.dD, st))
                 return 1;
         } else {
             launch_edge_bwd(s.TP, s.TQ, idx, N, k, P, s.stats1, w.cc1, d->slope, d->training, gy, y, nullptr, w.dR, w.dD,
@@ -230,7 +230,7 @@ extern "C" int dgcnn_edgeconv_bwd(const dgcnn_edgeconv_desc *d, const float *x, 
         launch_bn_bwd_finalize(w.bn1_partial, mlp_grid(P), E, d->training, g->gbn1_w, g->gbn1_b, w.cc1, st);
         if (d->training) {
             if (launch_edge_bwd_nogather(s.TP, s.TQ, idx, d->B, N, k, s.stats1, w.cc1, d->slope, gy, y, nullptr, s.usum,
-                                         w.dv1, w.cnt, w.indeg, w.rowptr, w.rev, nullptr, nullptr, nullptr, w.dR, w.dD, st))
+                                         w.dv1, w.cnt, w.indeg, w.rowptr, w.rev, w.extra, nullptr, nullptr, w.dR, w.dD, st))
                 return 1;
         } else {
             launch_edge_bwd(s.TP, s.TQ, idx, N, k, P, s.stats1, w.cc1, d->slope, d->training, gy, y, w.dv1, w.dR, w.dD, st);
