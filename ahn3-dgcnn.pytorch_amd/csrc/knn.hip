@@ -1051,26 +1051,29 @@ __global__ __launch_bounds__(KNN_ST_THREADS) void knn_filter16_kernel(const half
         }
         return bits;
     };
-    // rounds: every lane that still holds survivors appends its lowest one (uniform loop; ~6 of the 1024
-    // pairs of a tile survive, so 1-3 rounds)
-    auto rounds = [&](unsigned bits, int cand) {
+    // rounds: every lane that still holds survivors appends its lowest one (uniform loop).  The sign bits of the
+    // four tiles handled in one iteration are extracted together (bit 16 t + r = tile t, register r; tile t holds
+    // candidates cand + 32 t): ~24 survivors over 64 lanes need ~3 rounds, against ~2.3 per tile one by one.
+    auto rounds = [&](u64 bits, int cand) {
 #ifdef KNN_ABLATE_ROUNDS  // timing experiment: no survivor extraction (results are garbage)
         asm volatile("" ::"v"(bits));
         return;
 #endif
-        u64 m = __ballot(bits != 0u);
+        u64 m = __ballot(bits != 0ull);
         while (m != 0) {
             if (qn > KNN_QCAP - 64) {  // room for a full round of survivors (loose thresholds only)
                 while (qn >= 64) flush(64);
             }
-            if (bits != 0u) {
-                const int r = __builtin_ctz(bits);
+            if (bits != 0ull) {
+                const int pos = __builtin_ctzll(bits);
+                const int r = pos & 15;
                 const int off = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-                queue[(qhead + qn + off) & (KNN_QCAP - 1)] = ((unsigned)((r & 3) + 8 * (r >> 2) + 4 * h) << 27) | (unsigned)cand;
-                bits &= bits - 1u;
+                queue[(qhead + qn + off) & (KNN_QCAP - 1)] =
+                    ((unsigned)((r & 3) + 8 * (r >> 2) + 4 * h) << 27) | (unsigned)(cand + (pos >> 4) * 32);
+                bits &= bits - 1ull;
             }
             qn += __popcll(m);
-            m = __ballot(bits != 0u);
+            m = __ballot(bits != 0ull);
         }
         if (qn >= 64) flush(64);
     };
@@ -1098,18 +1101,11 @@ __global__ __launch_bounds__(KNN_ST_THREADS) void knn_filter16_kernel(const half
         const int cand0 = c * KNN_ST_TILES * 32 + j32;
         f32x16 a0, a1;
         mfma_pair(cur, 0, a0, a1);
-        {
-            const unsigned keep = c > c0 ? ~0u : 0u;  // nothing is pending in the first iteration
-            const unsigned b0 = signs(pa0, py0) & keep, b1 = signs(pa1, py1) & keep;
-            rounds(b0, cand0 - 64);
-            rounds(b1, cand0 - 32);
-        }
+        const unsigned keep = c > c0 ? ~0u : 0u;  // nothing is pending in the first iteration
+        const unsigned bp0 = signs(pa0, py0) & keep, bp1 = signs(pa1, py1) & keep;
         mfma_pair(cur, 2, pa0, pa1);
-        {
-            const unsigned b0 = signs(a0, ycur[0]), b1 = signs(a1, ycur[1]);
-            rounds(b0, cand0);
-            rounds(b1, cand0 + 32);
-        }
+        const unsigned b0 = signs(a0, ycur[0]), b1 = signs(a1, ycur[1]);
+        rounds(((u64)(b0 | (b1 << 16)) << 32) | (bp0 | (bp1 << 16)), cand0 - 64);
         py0 = ycur[2];
         py1 = ycur[3];
         st.swrite(sbuf[(c - c0 + 1) & 1], tid);
@@ -1122,8 +1118,7 @@ __global__ __launch_bounds__(KNN_ST_THREADS) void knn_filter16_kernel(const half
     {
         const int cand0 = c1 * KNN_ST_TILES * 32 + j32;
         const unsigned b0 = signs(pa0, py0), b1 = signs(pa1, py1);
-        rounds(b0, cand0 - 64);
-        rounds(b1, cand0 - 32);
+        rounds((u64)(b0 | (b1 << 16)), cand0 - 64);
     }
     while (qn > 0) flush(qn < 64 ? qn : 64);
     if (lane == 0) {
@@ -1174,43 +1169,53 @@ __global__ __launch_bounds__(64) void knn_refine_kernel(const float *__restrict_
         taus[lane] = -__builtin_inff();
     }
 
+    // The chain list entry -> candidate row -> arithmetic is two dependent loads deep and a wave has little
+    // company on its SIMD (LDS bounds the residency), so the list entries are fetched two batches ahead and the
+    // candidate rows one batch ahead of the arithmetic.
+    constexpr int NV = CP / 4;  // float4 per candidate row
+    auto entry = [&](int base) -> unsigned {
+        const int e = base + lane;
+        return e < n ? list[e < n0 ? e : seg1 + e] : 0u;
+    };
+    auto fetch = [&](unsigned qe, float4(&v)[NV], float &yy) {
+        const float *xl = xraw + (size_t)(qe & 0x7ffffffu) * C;
+        yy = xxb[qe & 0x7ffffffu];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = (4 * i < C) ? *reinterpret_cast<const float4 *>(xl + 4 * i) : float4{0, 0, 0, 0};
+    };
+    const bool vec = (C & 3) == 0;
+    unsigned qe_c = entry(0), qe_n = entry(64);
+    float4 vc[NV], vn[NV];
+    float yc = 0.0f, yn = 0.0f;
+    if (vec) fetch(qe_c, vc, yc);
     for (int base = 0; base < n; base += 64) {
         const bool act = base + lane < n;
-        const int e = base + lane;
-        const unsigned qe = act ? list[e < n0 ? e : seg1 + e] : 0u;
+        const unsigned qe = qe_c;
+        const unsigned qe_nn = entry(base + 128);
+        if (vec) fetch(qe_n, vn, yn);
         const int row = (int)(qe >> 27), cand = (int)(qe & 0x7ffffffu);
-        const float *xl = xraw + (size_t)cand * C;
-        float dot = 0.0f;
-        if ((C & 3) == 0) {
-            // the candidate row is fetched in two halves, each with all its loads in flight at once;
+        float dot = 0.0f, ycand;
+        if (vec) {
+            ycand = yc;
+            yc = yn;
             // channels beyond C multiply zeros: fma(0, 0, dot) == dot
-            constexpr int HV = CP / 8 > 0 ? CP / 8 : 1;  // float4 per half
-            float4 v0[HV], v1[HV];
 #pragma unroll
-            for (int i = 0; i < HV; ++i) v0[i] = (4 * i < C) ? *reinterpret_cast<const float4 *>(xl + 4 * i) : float4{0, 0, 0, 0};
-#pragma unroll
-            for (int i = 0; i < HV; ++i)
-                v1[i] = (4 * (HV + i) < C && HV + i < CP / 4) ? *reinterpret_cast<const float4 *>(xl + 4 * (HV + i)) : float4{0, 0, 0, 0};
-#pragma unroll
-            for (int i = 0; i < HV; ++i) {
-                dot = __builtin_fmaf(xq[row][4 * i + 0], v0[i].x, dot);
-                dot = __builtin_fmaf(xq[row][4 * i + 1], v0[i].y, dot);
-                dot = __builtin_fmaf(xq[row][4 * i + 2], v0[i].z, dot);
-                dot = __builtin_fmaf(xq[row][4 * i + 3], v0[i].w, dot);
+            for (int i = 0; i < NV; ++i) {
+                dot = __builtin_fmaf(xq[row][4 * i + 0], vc[i].x, dot);
+                dot = __builtin_fmaf(xq[row][4 * i + 1], vc[i].y, dot);
+                dot = __builtin_fmaf(xq[row][4 * i + 2], vc[i].z, dot);
+                dot = __builtin_fmaf(xq[row][4 * i + 3], vc[i].w, dot);
             }
-            if constexpr (CP / 4 > HV) {
 #pragma unroll
-                for (int i = 0; i < HV; ++i) {
-                    dot = __builtin_fmaf(xq[row][4 * (HV + i) + 0], v1[i].x, dot);
-                    dot = __builtin_fmaf(xq[row][4 * (HV + i) + 1], v1[i].y, dot);
-                    dot = __builtin_fmaf(xq[row][4 * (HV + i) + 2], v1[i].z, dot);
-                    dot = __builtin_fmaf(xq[row][4 * (HV + i) + 3], v1[i].w, dot);
-                }
-            }
+            for (int i = 0; i < NV; ++i) vc[i] = vn[i];
         } else {
+            const float *xl = xraw + (size_t)cand * C;
+            ycand = xxb[cand];
             for (int c = 0; c < C; ++c) dot = __builtin_fmaf(xq[row][c], xl[c], dot);
         }
-        const float pd = __builtin_fmaf(2.0f, dot, -xxb[cand]) - xxq[row];  // the oracle's arithmetic
+        qe_c = qe_n;
+        qe_n = qe_nn;
+        const float pd = __builtin_fmaf(2.0f, dot, -ycand) - xxq[row];  // the oracle's arithmetic
         const u64 key = make_key(pd, cand);
         bool pending = act;
         for (;;) {
