@@ -136,25 +136,38 @@ __global__ __launch_bounds__(64) void wgrad_kernel(const float *__restrict__ A0,
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
 
-    for (int p = pbeg; p < pend; p += 2) {
-        const int pp = p + h;
-        const bool pv = pp < pend;
-        float a[MT], b[NT];
+    // the loads of 8 points (4 MFMA steps) are issued together: the wave is alone on its SIMD and a step's
+    // operands are 6 dwords per lane, so one step per round trip is latency-bound
+    constexpr int UN = 4;
+    for (int p = pbeg; p < pend; p += 2 * UN) {
+        float a[UN][MT], b[UN][NT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int m = mt * 32 + i32;
-            a[mt] = (pv && m < M) ? (m < M0 ? A0[(size_t)pp * M0 + m] : A1[(size_t)pp * M1 + (m - M0)]) : 0.0f;
+        for (int u = 0; u < UN; ++u) {
+            const int pp = p + 2 * u + h;
+            const bool pv = pp < pend;
+            const int pc = pv ? pp : pbeg;  // clamped row: the load is unconditional, the value masked
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int m = mt * 32 + i32;
+                float v = 0.0f;
+                if (m < M) v = m < M0 ? A0[(size_t)pc * M0 + m] : A1[(size_t)pc * M1 + (m - M0)];
+                a[u][mt] = pv ? v : 0.0f;
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int n = nt * 32 + i32;
+                float v = 0.0f;
+                if (n < C) v = X[(size_t)pc * C + n];
+                b[u][nt] = pv ? v : 0.0f;
+            }
         }
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int n = nt * 32 + i32;
-            b[nt] = (pv && n < C) ? X[(size_t)pp * C + n] : 0.0f;
-        }
+        for (int u = 0; u < UN; ++u)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][mt], b[u][nt], acc[mt][nt], 0, 0, 0);
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -182,8 +195,17 @@ __global__ __launch_bounds__(1024) void sum_partials_kernel(const float *__restr
     const int q = (nchunk + SUM_WAVES - 1) / SUM_WAVES;
     const int c0 = w * q, c1 = c0 + q < nchunk ? c0 + q : nchunk;
     float s = 0.0f;
-    if (e < n)
-        for (int ch = c0; ch < c1; ++ch) s += partial[(size_t)ch * n + e];
+    if (e < n) {
+        int ch = c0;
+        for (; ch + 8 <= c1; ch += 8) {  // eight chunks in flight, added in chunk order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(ch + u) * n + e];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; ch < c1; ++ch) s += partial[(size_t)ch * n + e];
+    }
     red[w][lane] = s;
     __syncthreads();
     if (w == 0 && e < n) {

@@ -5,7 +5,7 @@ import torch
 from ahn3_dgcnn_pytorch_amd import _lib
 dev = torch.device("cuda:0")
 B, N, C, k = 8, 7000, int(sys.argv[1]) if len(sys.argv) > 1 else 64, 30
-x = torch.randn(B, N, C, device=dev, generator=torch.Generator(device=dev).manual_seed(0))
+x = torch.randn(B, N, C, generator=torch.Generator().manual_seed(1000)).to(dev)  # the bench input
 lib = _lib.load()
 idx = torch.empty((B, N, k), dtype=torch.int32, device=dev)
 nb = lib.dgcnn_knn_workspace_bytes(B, C, N, k)
