@@ -16,6 +16,7 @@
 #include <stdlib.h>
 
 #include "edge_kernels.h"
+#include "prof.h"
 
 namespace dgcnn {
 
@@ -391,16 +392,6 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(const float *__restrict__
         dD[(size_t)pt * EC + lane] = dsum;
     }
 }
-
-// ---- measurement hook: events around the scatter kernel (dgcnn_profile_* in dgcnn_hip.h) ----------------
-namespace {
-constexpr int PROF_MAX = 256;
-struct ProfState {
-    bool on = false, created = false;
-    int n = 0;
-    hipEvent_t e0[PROF_MAX], e1[PROF_MAX];
-} g_prof;
-}  // namespace
 
 // ---------------------------------------------------------------------------------------------
 // Training-mode stage-1 backward as a GATHER over the reverse adjacency (CSR by destination) of the kNN graph.
@@ -807,8 +798,7 @@ int launch_edge_bwd_nogather(const float *TP, const float *TQ, const int32_t *id
     else
         hipLaunchKernelGGL((edge_point_bwd_kernel<false>), grid, block, 0, st, TQ, N, k, P, stats, cc, slope, gy, y, hitj, usum,
                            dv, (HitRec *)hits, G, dD);
-    const bool prof = g_prof.on && g_prof.n < PROF_MAX;
-    if (prof) (void)hipEventRecord(g_prof.e0[g_prof.n], st);
+    prof_begin(PROF_EDGE_RGATHER, st);
     const dim3 xgrid(1024);  // extra segments: a few thousand at most, about one per wave
     if (dv) {
         hipLaunchKernelGGL((edge_rgather_kernel<true, false>), grid, block, 0, st, TP, TQ, rowptr, rev, k, P, stats, cc, dv,
@@ -821,7 +811,7 @@ int launch_edge_bwd_nogather(const float *TP, const float *TQ, const int32_t *id
         hipLaunchKernelGGL((edge_rgather_kernel<false, true>), xgrid, block, 0, st, TP, TQ, rowptr, rev, k, P, stats, cc, dv,
                            (const HitRec *)hits, G, nextra, elist, dR);
     }
-    if (prof) (void)hipEventRecord(g_prof.e1[g_prof.n++], st);
+    prof_end(PROF_EDGE_RGATHER, st);
     return 0;
 }
 
@@ -866,12 +856,14 @@ void launch_edge_reduce(const float *TP, const float *TQ, const int32_t *idx, in
                         float *usel, float *usum, uint8_t *hitj, double *partial, hipStream_t st)
 {
     const dim3 grid(edge_grid(P)), block(256);
+    prof_begin(PROF_EDGE_REDUCE, st);
     if (usel)
         hipLaunchKernelGGL((edge_reduce_kernel<true>), grid, block, 0, st, TP, TQ, idx, N, k, P, gamma, usel, usum, hitj,
                            partial);
     else
         hipLaunchKernelGGL((edge_reduce_kernel<false>), grid, block, 0, st, TP, TQ, idx, N, k, P, gamma, usel, usum, hitj,
                            partial);
+    prof_end(PROF_EDGE_REDUCE, st);
 }
 
 void launch_bn_finalize(double *partial, int nparts, double count, int training, const dgcnn_bn_params &bn,
@@ -935,32 +927,3 @@ void launch_graph_feature_bwd(const float *gout, const int32_t *idx, int B, int 
 }
 
 }  // namespace dgcnn
-
-extern "C" int dgcnn_profile_enable(int on)
-{
-    auto &p = dgcnn::g_prof;
-    if (on && !p.created) {
-        for (int i = 0; i < dgcnn::PROF_MAX; ++i) {
-            if (hipEventCreate(&p.e0[i]) != hipSuccess || hipEventCreate(&p.e1[i]) != hipSuccess) return 1;
-        }
-        p.created = true;
-    }
-    p.on = on != 0;
-    p.n = 0;
-    return 0;
-}
-
-extern "C" int dgcnn_profile_samples(void) { return dgcnn::g_prof.n; }
-
-extern "C" float dgcnn_profile_mean_ms(void)
-{
-    auto &p = dgcnn::g_prof;
-    if (p.n == 0) return 0.0f;
-    float sum = 0.0f;
-    for (int i = 0; i < p.n; ++i) {
-        float ms = 0.0f;
-        if (hipEventElapsedTime(&ms, p.e0[i], p.e1[i]) != hipSuccess) return -1.0f;
-        sum += ms;
-    }
-    return sum / (float)p.n;
-}

@@ -46,6 +46,7 @@
 #include <utility>
 
 #include "common.h"
+#include "prof.h"
 
 namespace dgcnn {
 
@@ -1333,14 +1334,18 @@ static void knn_f16_launch(int cap, int parts, const KnnWs &w, const float *x, i
                            int32_t *idx, hipStream_t st)
 {
     const dim3 grid(B * (Npad / 32)), block(64);
+    prof_begin(PROF_KNN_FILTER, st);
     hipLaunchKernelGGL((knn_filter16_kernel<CP>), dim3(B * parts * (Npad / (32 * KNN_ST_WAVES))), dim3(KNN_ST_THREADS), 0,
                        st, w.xh, w.xxc, w.tau0, w.eps, w.f16ok, B, Npad, parts, w.lists, w.lcount, w.rbflag);
+    prof_end(PROF_KNN_FILTER, st);
+    prof_begin(PROF_KNN_REFINE, st);
     if (cap == 64)
         hipLaunchKernelGGL((knn_refine_kernel<CP, 64>), grid, block, 0, st, x, w.xx, w.lists, w.lcount, w.rbflag, B, N, C,
                            Npad, k, parts, idx);
     else
         hipLaunchKernelGGL((knn_refine_kernel<CP, 128>), grid, block, 0, st, x, w.xx, w.lists, w.lcount, w.rbflag, B, N, C,
                            Npad, k, parts, idx);
+    prof_end(PROF_KNN_REFINE, st);
 }
 
 }  // namespace dgcnn
@@ -1401,6 +1406,7 @@ extern "C" int dgcnn_knn(const float *x, int B, int N, int C, int k, int32_t *id
             if (hipMemsetAsync(w.rbflag, 0, (size_t)B * (Npad / 32) * sizeof(int), st) != hipSuccess)
                 DG_FAIL("dgcnn_knn: memset failed");
             const dim3 bgrid(B * parts * (Npad / (32 * KNN_ST_WAVES))), bblock(KNN_ST_THREADS);
+            prof_begin(PROF_KNN_BOUND, st);
 #define DG_BOUND16(CP_)                                                                                              \
     hipLaunchKernelGGL((knn_bound16s_kernel<CP_>), bgrid, bblock, 0, st, w.xh, w.xxc, xx, w.bmax, B, Npad, k, parts, \
                        w.exch, w.tau0, w.eps)
@@ -1414,6 +1420,7 @@ extern "C" int dgcnn_knn(const float *x, int B, int N, int C, int k, int32_t *id
             if (parts == 2)
                 hipLaunchKernelGGL(knn_bound_merge_kernel, dim3(B * (Npad / 32)), dim3(64), 0, st, w.exch, w.xxc, xx, w.bmax, B,
                                    Npad, k, w.tau0, w.eps);
+            prof_end(PROF_KNN_BOUND, st);
         } else if (CP == 8) {
             knn_bound_launch<8, false>(B, st, xt, xx, xx, w.bmax, Npad, k, w.tau0, nullptr);
         } else {

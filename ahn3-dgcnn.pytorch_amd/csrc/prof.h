@@ -1,0 +1,20 @@
+// prof.h -- measurement hook: HIP events around named kernel groups of the hot path, recorded on the stream the
+// kernels are launched on (dgcnn_profile_* in dgcnn_hip.h).  Disabled (the default) it costs one load per launch.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace dgcnn {
+
+enum ProfRegion {
+    PROF_KNN_BOUND = 0,   // knn_bound16s_kernel (+ knn_bound_merge_kernel): fp16 threshold pass
+    PROF_KNN_FILTER,      // knn_filter16_kernel: fp16 all-pairs filter
+    PROF_KNN_REFINE,      // knn_refine_kernel: exact fp32 distances of the survivors, selection
+    PROF_EDGE_REDUCE,     // edge_reduce_kernel: forward gather, BatchNorm statistics, max-over-k
+    PROF_EDGE_RGATHER,    // edge_rgather_kernel (both launches): backward gather over the reverse kNN graph
+    PROF_NREGION
+};
+
+void prof_begin(int region, hipStream_t st);
+void prof_end(int region, hipStream_t st);
+
+}  // namespace dgcnn

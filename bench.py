@@ -12,10 +12,10 @@ every rank runs that workload on its own shard (weak scaling: the batch elements
 units) and the step ends with one RCCL all-reduce of the flat parameter-gradient buffer.
 
 Rank 0 prints ONE JSON line (the contract of the build prompt) with two extra objects:
-  roofline     -- the dominant kernel (edge_rgather_kernel, the gather over the reverse kNN graph of the
-                  first convolution's backward): algorithmic bytes / its HIP-event time (events recorded
-                  inside the C ABI on the launch stream), against the HBM peak of MI355X_MICROARCH.md; the
-                  kNN graph build is reported beside it as `knn`
+  roofline     -- the dominant kernel (the largest of the five profiled kernels of the path): algorithmic
+                  bytes or flops / its HIP-event time (events recorded inside the C ABI on the launch
+                  stream), against the HBM or fp16-MFMA peak of MI355X_MICROARCH.md; the other four follow
+                  in `kernels`, the whole kNN graph build in `knn`
   cpu_baseline -- oracle/torch_ref.py (the reference's own PyTorch-CPU op sequence) timed on the
                   host cores of the same box on a bounded sample of the same workload
 """
@@ -37,6 +37,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md, dense fp16/bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md, "HBM3E peak BW" (spec; 6.29 TB/s measured by a float4 copy)
 
 
@@ -168,25 +169,41 @@ def main():
         dt = float(t.item())
 
     knn_ms = sum(a.elapsed_time(b) for a, b in knn_events) / max(1, len(knn_events))
-    scatter_ms = float(lib.dgcnn_profile_mean_ms())
-    scatter_n = int(lib.dgcnn_profile_samples())
+    regions = {lib.dgcnn_profile_region_name(r).decode(): (float(lib.dgcnn_profile_mean_ms(r)), int(lib.dgcnn_profile_samples(r)))
+               for r in range(lib.dgcnn_profile_regions())}
     lib.dgcnn_profile_enable(0)
     if rank == 0:
         P, E = B * N, B * N * k
-        # algorithmic bytes of one edge_rgather_kernel launch: per edge one fp32 [64] row of
-        # TQ (two-stage blocks: also one row of dv), its reverse-list entry and (one-stage) the 8-byte channel mask
-        # and 16-byte hit record; per point the list bounds, the TP row (read) and the dR row (written)
-        if args.stages == 1:
-            scatter_bytes = E * (256.0 + 4 + 8 + 16) + P * (8.0 + 256 + 256)
-        else:
-            scatter_bytes = E * (512.0 + 4) + P * (8.0 + 256 + 256)
-        achieved = scatter_bytes / (scatter_ms * 1e-3) / 1e9 if scatter_ms > 0 else 0.0
         knn_flops = 2.0 * B * N * N * C  # FLOPs_kNN = 2 B N^2 C
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "rgather_traffic.json")
+        # Algorithmic work of one launch of each large kernel.
+        #  knn_bound16s / knn_filter16: each evaluates all B N^2 pairs once on fp16 MFMA -> 2 B N^2 C flops
+        #  knn_refine: exact fp32 distance of at least the k winners of every row: one C-float row, its norm and
+        #              its list entry per winner, the index row written
+        #  edge_reduce: per edge one fp32 [64] row of TP and its index; per point TQ (read), usel, usum, hitj (written)
+        #  edge_rgather: per edge one fp32 [64] row of TQ (two-stage blocks: also one row of dv), its reverse-list
+        #              entry and (one-stage) the 32-byte hit record; per point the list bounds, TP (read), dR (written)
+        work = {
+            "knn_bound16s_kernel": ("mfma", knn_flops, PEAK_F16_MFMA_TFLOPS),
+            "knn_filter16_kernel": ("mfma", knn_flops, PEAK_F16_MFMA_TFLOPS),
+            "knn_refine_kernel": ("hbm", E * (4.0 * C + 4 + 4 + 4), PEAK_HBM_GBS),
+            "edge_reduce_kernel": ("hbm", E * (256.0 + 4) + P * (256.0 * 3 + 64), PEAK_HBM_GBS),
+            "edge_rgather_kernel": ("hbm", (E * (256.0 + 4 + 32) if args.stages == 1 else E * (512.0 + 4)) + P * (8.0 + 512),
+                                    PEAK_HBM_GBS),
+        }
+        traffic_by_kernel = {}
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if args.stages == 1 and os.path.exists(tpath):  # measured on the one-stage workload
             with open(tpath) as f:
-                traffic = json.load(f).get("hbm_bytes_per_launch")
+                traffic_by_kernel = json.load(f).get("hbm_bytes_per_launch", {})
+        kernels = []
+        for name, (ms, n) in regions.items():
+            bound, amount, peak = work[name]
+            unit = "TFLOP/s" if bound == "mfma" else "GB/s"
+            ach = amount / (ms * 1e-3) / (1e12 if bound == "mfma" else 1e9) if ms > 0 else 0.0
+            kernels.append({"kernel": name, "bound": bound, "achieved": ach, "peak": peak, "unit": unit,
+                            "frac": ach / peak, "traffic": traffic_by_kernel.get(name), "kernel_ms": ms, "samples": n,
+                            "algorithmic_%s_per_launch" % ("flops" if bound == "mfma" else "bytes"): amount})
+        kernels.sort(key=lambda d: -d["kernel_ms"])
         out = {
             "metric": "EdgeConv fwd+bwd points/sec (B=8,N=7000,k=30)",
             "value": world * B * N * args.steps / dt,
@@ -205,11 +222,9 @@ def main():
                                    (" + conv 64->64 + BN + LeakyReLU" if args.stages == 2 else ""),
                        "batch_per_gpu": B, "points": N, "k": k, "channels": C, "stages": args.stages,
                        "parallelism": "dp%d (batch elements sharded, one all-reduce of the flat grad buffer)" % world},
-            "roofline": {"bound": "hbm", "kernel": "edge_rgather_kernel (first conv's backward as a gather over the "
-                                                    "reverse kNN graph, one 256-B row per edge)",
-                         "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
-                         "traffic": traffic, "kernel_ms": scatter_ms, "samples": scatter_n,
-                         "algorithmic_bytes_per_launch": scatter_bytes},
+            # the dominant kernel = the largest of the profiled kernels; the others follow in "kernels"
+            "roofline": kernels[0],
+            "kernels": kernels[1:],
             "knn": {"ms": knn_ms, "algorithmic_flops": knn_flops, "tflops": knn_flops / (knn_ms * 1e-3) / 1e12,
                     "frac_of_f32_mfma_peak": knn_flops / (knn_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                     "note": "whole dgcnn_knn call (prep + fp16 threshold pass + fp16 filter + exact fp32 refine); "

@@ -140,13 +140,16 @@ int dgcnn_bn_lrelu_bwd(const float *x, const float *y, const float *gy, const fl
                        size_t workspace_bytes, void *stream);
 
 /* ---- measurement hook (bench.py) ----------------------------------------------------------------------
- * HIP events around the DOMINANT kernel of the EdgeConv path (edge_scatter_kernel, the scatter-add of the
- * first convolution's backward), recorded on the stream the kernel is launched on.  enable(1) resets the
- * sample ring; mean_ms() returns the mean kernel time of the samples recorded since (call it after the
- * stream has been synchronised; at most 256 samples are kept).  No effect on results. */
+ * HIP events around the large kernels of the path, recorded on the stream each kernel is launched on.  Regions
+ * (dgcnn_profile_region_name): the fp16 threshold pass, the fp16 filter and the exact refine of dgcnn_knn, the
+ * forward gather/reduce pass and the backward reverse gather of dgcnn_edgeconv_*.  enable(1) resets the sample
+ * rings; mean_ms(region) returns the mean time of the samples recorded since (call it after the stream has been
+ * synchronised; at most 256 samples per region are kept).  No effect on results. */
 int dgcnn_profile_enable(int on);
-float dgcnn_profile_mean_ms(void);
-int dgcnn_profile_samples(void);
+int dgcnn_profile_regions(void);
+const char *dgcnn_profile_region_name(int region);
+float dgcnn_profile_mean_ms(int region);
+int dgcnn_profile_samples(int region);
 
 #ifdef __cplusplus
 }

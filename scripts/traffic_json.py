@@ -1,15 +1,25 @@
-"""HBM traffic of the dominant kernel from the two PMC passes of scripts/profile_bench.sh.
+"""HBM traffic of the profiled kernels from the two PMC passes of scripts/profile_bench.sh.
 
-    python scripts/traffic_json.py gpurun_out/prof_<tag> edge_rgather profiles/rgather_traffic.json
+    python scripts/traffic_json.py gpurun_out/prof_<tag> profiles/hbm_traffic.json
 
 Corrections follow MI355X_MICROARCH.md (section HBM): rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KB; on gfx950
-FETCH_SIZE counts half of the fetched bytes (doubled here); WRITE_SIZE is taken as is.
+FETCH_SIZE counts half of the fetched bytes (doubled here; calibrated for 16-byte-per-lane streams, so the read side
+of the dword-per-lane gathers is approximate); WRITE_SIZE is taken as is.  A region of bench.py's `kernels` list may
+span two launches (listed below): their per-launch means are added.
 """
 import collections
 import csv
 import glob
 import json
 import sys
+
+REGIONS = {
+    "knn_bound16s_kernel": ["knn_bound16s_kernel", "knn_bound_merge_kernel"],
+    "knn_filter16_kernel": ["knn_filter16_kernel"],
+    "knn_refine_kernel": ["knn_refine_kernel"],
+    "edge_reduce_kernel": ["edge_reduce_kernel"],
+    "edge_rgather_kernel": ["edge_rgather_kernel"],   # both launches (segment 0 of every point, extra segments)
+}
 
 
 def per_kernel(root, counter):
@@ -25,25 +35,21 @@ def per_kernel(root, counter):
 
 
 def main():
-    root, pat, out = sys.argv[1], sys.argv[2], sys.argv[3]
+    root, out = sys.argv[1], sys.argv[2]
     fetch, write = per_kernel(root + "/fetch", "FETCH_SIZE"), per_kernel(root + "/write", "WRITE_SIZE")
-    name = [k for k in fetch if pat in k][0]
-    short = lambda k: k.replace("void dgcnn::", "").replace("dgcnn::", "").split("(")[0][:48]
     doc = {
-        "kernel": short(name),
         "command": "scripts/profile_bench.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separately, WRITE_SIZE) "
                    "-- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline",
-        "FETCH_SIZE_KB_per_launch": fetch[name],
-        "WRITE_SIZE_KB_per_launch": write.get(name, 0.0),
-        "correction": "MI355X_MICROARCH.md section HBM: on gfx950 FETCH_SIZE reports half of the fetched bytes (doubled "
-                      "here; this kernel reads dword-per-lane rows, not the calibrated 16-B pattern, so the read side "
-                      "is approximate); WRITE_SIZE as reported",
-        "hbm_bytes_per_launch": 2.0 * fetch[name] * 1024.0 + write.get(name, 0.0) * 1024.0,
-        "all_kernels_KB_per_launch": {short(k): {"FETCH_SIZE": fetch[k], "WRITE_SIZE": write.get(k, 0.0)}
-                                      for k in sorted(fetch, key=lambda k: -fetch[k])[:16]},
+        "correction": "hbm_bytes = 2 * FETCH_SIZE_KB * 1024 + WRITE_SIZE_KB * 1024 (MI355X_MICROARCH.md section HBM)",
+        "hbm_bytes_per_launch": {}, "FETCH_SIZE_KB": {}, "WRITE_SIZE_KB": {},
     }
+    for region, pats in REGIONS.items():
+        f = sum(v for k, v in fetch.items() if any(p in k for p in pats))
+        w = sum(v for k, v in write.items() if any(p in k for p in pats))
+        doc["FETCH_SIZE_KB"][region], doc["WRITE_SIZE_KB"][region] = f, w
+        doc["hbm_bytes_per_launch"][region] = 2.0 * f * 1024.0 + w * 1024.0
     json.dump(doc, open(out, "w"), indent=1)
-    print(json.dumps({k: doc[k] for k in ("kernel", "hbm_bytes_per_launch")}))
+    print(json.dumps(doc["hbm_bytes_per_launch"]))
 
 
 if __name__ == "__main__":
