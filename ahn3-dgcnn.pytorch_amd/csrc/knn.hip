@@ -242,87 +242,91 @@ __global__ __launch_bounds__(256) void knn_center_kernel(const float *__restrict
     }
 }
 
-// fp16 operand tiles of the centred features for v_mfma_f32_32x32x16_f16: lane (j, h) of a 32-point
-// tile supplies, at k-step ks, channels 16 ks + 8 h + e (e = 0..7) of point j:
-//   xh[tile][ks][lane][e] = half(x[tile * 32 + (lane & 31)][16 ks + 8 (lane >> 5) + e] - mu)
-// plus the centred squared norms xxc (fp32; +inf for padding rows) and, per batch element, the
-// largest centred and raw norm (bmax[b][0..1], as uint bits of non-negative floats).
-__global__ void knn_half_kernel(const float *__restrict__ x, const float *__restrict__ mu, int N, int C, int Npad,
-                                int CP, half8 *__restrict__ xh)
+// Maximum over a batch element of the per-tile norm maxima tmax[b][which][ntiles] (uint bits of non-negative
+// floats; which = 0 centred, 1 raw).  Wave-wide call, uniform result.
+__device__ __forceinline__ float batch_max(const unsigned *__restrict__ tmax, int b, int which, int ntiles)
 {
-    const int KS = CP / 16;
-    const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int b = blockIdx.y;
-    const size_t nvec = (size_t)(Npad / 32) * KS * 64;
-    if (v >= nvec) return;
-    const int lane = (int)(v & 63);
-    const int ks = (int)((v >> 6) % KS);
-    const int tile = (int)((v >> 6) / KS);
-    const int n = tile * 32 + (lane & 31), h = lane >> 5;
-    half8 out;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int c = 16 * ks + 8 * h + e;
-        const float val = (n < N && c < C) ? x[((size_t)b * N + n) * C + c] - mu[(size_t)b * C + c] : 0.0f;
-        out[e] = (_Float16)val;
-    }
-    xh[(size_t)b * (Npad / 32) * KS * 64 + v] = out;
-}
-
-// centred squared norms (any summation order will do: they only feed the pre-pass and its error
-// bound): 16 lanes per point, C <= 128 -> up to two float4 per lane, shuffle reduction.
-__global__ __launch_bounds__(256) void knn_cnorm_kernel(const float *__restrict__ x, const float *__restrict__ mu,
-                                                        int N, int C, int Npad, float *__restrict__ xxc)
-{
-    const int sub = threadIdx.x & 15;
-    const int n = blockIdx.x * 16 + (threadIdx.x >> 4);  // Npad is a multiple of 16
-    const int b = blockIdx.y;
-    float acc = 0.0f;
-    if (n < N) {
-        const float *src = x + ((size_t)b * N + n) * C;
-        const float *m = mu + (size_t)b * C;
-        for (int c = sub; c < C; c += 16) {
-            const float d = src[c] - m[c];
-            acc = __builtin_fmaf(d, d, acc);
-        }
-    }
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-    if (n >= N) acc = __builtin_inff();
-    if (sub == 0) xxc[(size_t)b * Npad + n] = acc;
-}
-
-// bmax[b] = (largest centred norm, largest raw norm) of batch element b, as uint bits of non-negative
-// floats; one workgroup per batch element.
-__global__ __launch_bounds__(1024) void knn_bmax_kernel(const float *__restrict__ xxc, const float *__restrict__ xx,
-                                                        int N, int Npad, unsigned *__restrict__ bmax,
-                                                        int *__restrict__ f16ok)
-{
-    __shared__ unsigned red[2][16];
-    const int b = blockIdx.x;
-    unsigned mc = 0u, mr = 0u;
-    for (int n = threadIdx.x; n < N; n += 1024) {
-        const unsigned c = __float_as_uint(xxc[(size_t)b * Npad + n]), r = __float_as_uint(xx[(size_t)b * Npad + n]);
-        mc = mc > c ? mc : c;
-        mr = mr > r ? mr : r;
-    }
+    const unsigned *p = tmax + ((size_t)b * 2 + which) * ntiles;
+    unsigned m = 0u;
+    for (int i = (int)(threadIdx.x & 63); i < ntiles; i += 64) m = m > p[i] ? m : p[i];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
-        const unsigned oc = __shfl_xor(mc, o), orr = __shfl_xor(mr, o);
-        mc = mc > oc ? mc : oc;
-        mr = mr > orr ? mr : orr;
+        const unsigned t = __shfl_xor(m, o);
+        m = m > t ? m : t;
     }
-    if ((threadIdx.x & 63) == 0) {
-        red[0][threadIdx.x >> 6] = mc;
-        red[1][threadIdx.x >> 6] = mr;
+    return __uint_as_float(m);
+}
+
+// Preparation for C >= 16 in one pass over x: one workgroup = one 32-point tile, rows staged in LDS.
+//   xx   raw squared norms in the oracle's chain order (+inf for padding rows)
+//   xxc  squared norms of the mean-centred features (any order: they only feed the fp16 streams and their bound)
+//   xh   centred features as fp16 operand tiles of v_mfma_f32_32x32x16_f16: lane (j, h) of a 32-point tile
+//        supplies, at step ks, channels 16 ks + 8 h .. + 7 of point j; xh[tile][ks][lane] is one 16-byte vector
+//   xt   raw features as fp32 operand tiles (the layout of knn_tile_kernel<4>) for the fallback kernel
+//   bmax[b][which][tile] = largest centred (which = 0) / raw (1) norm of the tile, as uint bits of non-negative
+//        floats (NaN bits win the comparison, as they must); batch_max() reduces them where they are needed
+__global__ __launch_bounds__(256) void knn_prep16_kernel(const float *__restrict__ x, const float *__restrict__ mu,
+                                                         int N, int C, int Npad, int CP, float *__restrict__ xx,
+                                                         float *__restrict__ xxc, half8 *__restrict__ xh,
+                                                         float *__restrict__ xt, unsigned *__restrict__ bmax)
+{
+    __shared__ float xs[32][129];  // C <= 128; odd stride: conflict-free column walks
+    __shared__ float ms[128];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y, tile = blockIdx.x, q0 = tile * 32;
+    for (int i = tid; i < 32 * C; i += 256) {
+        const int r = i / C, c = i - r * C;
+        xs[r][c] = q0 + r < N ? x[((size_t)b * N + q0) * C + i] : 0.0f;
     }
+    if (tid < C) ms[tid] = mu[(size_t)b * C + tid];
     __syncthreads();
-    if (threadIdx.x < 2) {
-        unsigned m = 0u;
-        for (int i = 0; i < 16; ++i) m = m > red[threadIdx.x][i] ? m : red[threadIdx.x][i];
-        bmax[2 * b + threadIdx.x] = m;
-        // centred features must fit fp16 (|y| <= sqrt(cmax) < 65504) with room; NaN/inf norms fail the test
-        if (threadIdx.x == 0) f16ok[b] = (__uint_as_float(m) < 1.0e9f) ? 1 : 0;
+    // norms: wave 0 lanes 0..31 the raw chain, wave 1 lanes 0..31 the centred one
+    if ((tid & 63) < 32 && tid < 128) {
+        const int r = tid & 31;
+        const bool centred = tid >= 64;
+        float acc = 0.0f;
+        if (centred) {
+            for (int c = 0; c < C; ++c) {
+                const float d = xs[r][c] - ms[c];
+                acc = __builtin_fmaf(d, d, acc);
+            }
+        } else {
+            for (int c = 0; c < C; ++c) acc = __builtin_fmaf(xs[r][c], xs[r][c], acc);
+        }
+        const bool real = q0 + r < N;
+        (centred ? xxc : xx)[(size_t)b * Npad + q0 + r] = real ? acc : __builtin_inff();
+        unsigned m = real ? __float_as_uint(acc) : 0u;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+            const unsigned t = __shfl_xor(m, o);
+            m = m > t ? m : t;
+        }
+        if (r == 0) bmax[((size_t)b * 2 + (centred ? 0 : 1)) * (Npad / 32) + tile] = m;
+    }
+    // fp16 operand tiles: vector v = ks * 64 + lane; lane (j, h) holds channels 16 ks + 8 h .. + 7 of point j
+    const int KS = CP / 16;
+    for (int v = tid; v < KS * 64; v += 256) {
+        const int lane = v & 63, ks = v >> 6, r = lane & 31, h = lane >> 5;
+        half8 out;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = 16 * ks + 8 * h + e;
+            out[e] = (_Float16)((q0 + r < N && c < C) ? xs[r][c] - ms[c] : 0.0f);
+        }
+        xh[((size_t)b * (Npad / 32) + tile) * KS * 64 + v] = out;
+    }
+    // fp32 operand tiles (knn_tile_kernel<4>): vector v = g * 64 + lane, element e = channel 2 (4 g + e) + h
+    const int G = CP / 8;
+    for (int v = tid; v < G * 64; v += 256) {
+        const int lane = v & 63, g = v >> 6, r = lane & 31, h = lane >> 5;
+        float4 out;
+        float *o = reinterpret_cast<float *>(&out);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = 2 * (g * 4 + e) + h;
+            o[e] = (q0 + r < N && c < C) ? xs[r][c] : 0.0f;
+        }
+        reinterpret_cast<float4 *>(xt + (size_t)b * Npad * CP + (size_t)tile * 32 * CP)[v] = out;
     }
 }
 
@@ -452,7 +456,7 @@ __global__ __launch_bounds__(64) void knn_bound_kernel(const void *__restrict__ 
     }
 
     // k-th largest of the 64 class maxima of every row, minus the row's own norm and the error bound
-    const float cmax = __uint_as_float(bmax[2 * b + 0]), rmax = __uint_as_float(bmax[2 * b + 1]);
+    const float cmax = F16 ? batch_max(bmax, b, 0, Npad / 32) : 0.0f, rmax = F16 ? batch_max(bmax, b, 1, Npad / 32) : 0.0f;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
@@ -644,8 +648,8 @@ __global__ __launch_bounds__(KNN_ST_THREADS) void knn_bound16s_kernel(const half
     unsigned kth = w[0];
 #pragma unroll
     for (int i = 1; i < 32; ++i) kth = sel == i ? w[i] : kth;
+    const float cmax = batch_max(bmax, b, 0, Npad / 32), rmax = batch_max(bmax, b, 1, Npad / 32);
     if (h == ((k - 1) >> 5)) {
-        const float cmax = __uint_as_float(bmax[2 * b + 0]), rmax = __uint_as_float(bmax[2 * b + 1]);
         const float vk = __uint_as_float((kth & 0x80000000u) ? (kth & 0x7fffffffu) : ~kth);
         const int row = rb * 32 + j32;
         const float xi = yb[row], xr = xx_raw[(size_t)b * Npad + row];
@@ -700,8 +704,8 @@ __global__ __launch_bounds__(64) void knn_bound_merge_kernel(const unsigned *__r
     unsigned kth = w[0];
 #pragma unroll
     for (int i = 1; i < 32; ++i) kth = sel == i ? w[i] : kth;
+    const float cmax = batch_max(bmax, b, 0, Npad / 32), rmax = batch_max(bmax, b, 1, Npad / 32);
     if (h == ((k - 1) >> 5)) {
-        const float cmax = __uint_as_float(bmax[2 * b + 0]), rmax = __uint_as_float(bmax[2 * b + 1]);
         const float vk = __uint_as_float((kth & 0x80000000u) ? (kth & 0x7fffffffu) : ~kth);
         const float xi = xxc[row], xr = xx_raw[row];
         const float eps = knn_f16_eps(xi, cmax, xr, rmax);
@@ -956,7 +960,7 @@ template <int CP>
 __global__ __launch_bounds__(KNN_ST_THREADS) void knn_filter16_kernel(const half8 *__restrict__ xh, const float *__restrict__ xxc,
                                                            const float *__restrict__ tau0,
                                                            const float *__restrict__ epsr,
-                                                           const int *__restrict__ f16ok, int B, int Npad,
+                                                           const unsigned *__restrict__ bmax, int B, int Npad,
                                                            int parts, unsigned *__restrict__ lists,
                                                            int *__restrict__ lcount, int *__restrict__ rbflag)
 {
@@ -972,7 +976,8 @@ __global__ __launch_bounds__(KNN_ST_THREADS) void knn_filter16_kernel(const half
     const int c0 = part * nchunks / parts, c1 = (part + 1) * nchunks / parts;
     const int wid = b * ntiles + rb;
     const int listcap = KNN_LISTCAP / parts;
-    if (!f16ok[b]) {  // uniform over the workgroup
+    // centred features must fit fp16 (|y| <= sqrt(cmax) < 65504) with room; NaN/inf norms fail the test
+    if (!(batch_max(bmax, b, 0, Npad / 32) < 1.0e9f)) {  // uniform over the workgroup
         if (lane == 0) {
             rbflag[wid] = 1;
             lcount[2 * wid + part] = 0;
@@ -1298,7 +1303,7 @@ struct KnnWs {
     float *xt, *xx, *xxc, *tau0, *eps, *mu;
     half8 *xh;
     unsigned *bmax, *lists, *exch;
-    int *f16ok, *lcount, *rbflag;
+    int *lcount, *rbflag;
     size_t bytes;
 };
 static KnnWs knn_ws(int B, int C, int N, void *base)
@@ -1319,9 +1324,8 @@ static KnnWs knn_ws(int B, int C, int N, void *base)
     w.eps = (float *)take((size_t)B * npad * sizeof(float));
     w.mu = (float *)take((size_t)B * cp * sizeof(float));
     w.xh = (half8 *)take((size_t)B * npad * cp * sizeof(_Float16));
-    w.bmax = (unsigned *)take((size_t)B * 2 * sizeof(unsigned));
-    w.f16ok = (int *)take((size_t)B * sizeof(int));
     w.lcount = (int *)take((size_t)B * (npad / 32) * 2 * sizeof(int));
+    w.bmax = (unsigned *)take((size_t)B * 2 * (npad / 32) * sizeof(unsigned));
     w.rbflag = (int *)take((size_t)B * (npad / 32) * sizeof(int));
     w.exch = (unsigned *)take(cp >= 16 ? (size_t)B * npad * 2 * 64 * sizeof(unsigned) : 0);
     w.lists = (unsigned *)take(cp >= 16 ? (size_t)B * (npad / 32) * KNN_LISTCAP * sizeof(unsigned) : 0);
@@ -1336,7 +1340,7 @@ static void knn_f16_launch(int cap, int parts, const KnnWs &w, const float *x, i
     const dim3 grid(B * (Npad / 32)), block(64);
     prof_begin(PROF_KNN_FILTER, st);
     hipLaunchKernelGGL((knn_filter16_kernel<CP>), dim3(B * parts * (Npad / (32 * KNN_ST_WAVES))), dim3(KNN_ST_THREADS), 0,
-                       st, w.xh, w.xxc, w.tau0, w.eps, w.f16ok, B, Npad, parts, w.lists, w.lcount, w.rbflag);
+                       st, w.xh, w.xxc, w.tau0, w.eps, w.bmax, B, Npad, parts, w.lists, w.lcount, w.rbflag);
     prof_end(PROF_KNN_FILTER, st);
     prof_begin(PROF_KNN_REFINE, st);
     if (cap == 64)
@@ -1374,22 +1378,31 @@ extern "C" int dgcnn_knn(const float *x, int B, int N, int C, int k, int32_t *id
     const KnnWs w = knn_ws(B, C, N, workspace);
     float *xt = w.xt, *xx = w.xx;
 
-    hipLaunchKernelGGL(knn_norm_kernel, dim3(ceil_div(Npad, 256), B), dim3(256), 0, st, x, N, C, Npad, xx);
-    const size_t nvec = (size_t)Npad * CP / (CP >= 8 ? 4 : 2);
-    const dim3 tgrid((unsigned)((nvec + 255) / 256), B);
-    if (CP >= 8)
-        hipLaunchKernelGGL((knn_tile_kernel<4>), tgrid, dim3(256), 0, st, x, N, C, Npad, CP, xt);
-    else
-        hipLaunchKernelGGL((knn_tile_kernel<2>), tgrid, dim3(256), 0, st, x, N, C, Npad, CP, xt);
+    static const bool prepass_off = getenv("DGCNN_KNN_NO_PREPASS") != nullptr;
+    static const bool f16_off = getenv("DGCNN_KNN_NO_F16") != nullptr;
+    const bool prepass = k <= 40 && N >= 256 && !prepass_off;
+    const bool f16path = prepass && CP >= 16 && !f16_off;
+    if (prepass && CP >= 16) {
+        // one pass over x: norms, fp16 and fp32 operand tiles, norm maxima (after the centre of each batch element)
+        hipLaunchKernelGGL(knn_center_kernel, dim3(B), dim3(256), 0, st, x, N, C, w.mu);
+        if (hipMemsetAsync(w.rbflag, 0, (size_t)B * (Npad / 32) * sizeof(int), st) != hipSuccess)
+            DG_FAIL("dgcnn_knn: memset failed");
+        hipLaunchKernelGGL(knn_prep16_kernel, dim3(Npad / 32, B), dim3(256), 0, st, x, w.mu, N, C, Npad, CP, xx, w.xxc, w.xh,
+                           xt, w.bmax);
+    } else {
+        hipLaunchKernelGGL(knn_norm_kernel, dim3(ceil_div(Npad, 256), B), dim3(256), 0, st, x, N, C, Npad, xx);
+        const size_t nvec = (size_t)Npad * CP / (CP >= 8 ? 4 : 2);
+        const dim3 tgrid((unsigned)((nvec + 255) / 256), B);
+        if (CP >= 8)
+            hipLaunchKernelGGL((knn_tile_kernel<4>), tgrid, dim3(256), 0, st, x, N, C, Npad, CP, xt);
+        else
+            hipLaunchKernelGGL((knn_tile_kernel<2>), tgrid, dim3(256), 0, st, x, N, C, Npad, CP, xt);
+    }
     DG_CHECK_LAUNCH("knn prep kernels");
 
     // threshold pre-pass (speed only; see the header).  64 candidate classes per row: worth it for k <= 40.
     const float *tau0 = nullptr;
     const int *rbflag = nullptr;
-    static const bool prepass_off = getenv("DGCNN_KNN_NO_PREPASS") != nullptr;
-    static const bool f16_off = getenv("DGCNN_KNN_NO_F16") != nullptr;
-    const bool prepass = k <= 40 && N >= 256 && !prepass_off;
-    const bool f16path = prepass && CP >= 16 && !f16_off;
     const int cap = (k <= 32) ? 64 : 128;
     // the fp16 streams split the candidates of a row group over two workgroups when there are enough chunks:
     // twice the waves per SIMD (the streams are latency-bound at 1.7) and 128 instead of 64 threshold classes
@@ -1397,14 +1410,6 @@ extern "C" int dgcnn_knn(const float *x, int B, int N, int C, int k, int32_t *id
     if (prepass) {
         // (knn_bound_kernel writes tau0 for every row, padded rows included)
         if (CP >= 16) {
-            hipLaunchKernelGGL(knn_center_kernel, dim3(B), dim3(256), 0, st, x, N, C, w.mu);
-            const size_t nvec = (size_t)Npad * CP / 8;
-            hipLaunchKernelGGL(knn_half_kernel, dim3((unsigned)((nvec + 255) / 256), B), dim3(256), 0, st, x, w.mu, N, C,
-                               Npad, CP, w.xh);
-            hipLaunchKernelGGL(knn_cnorm_kernel, dim3(Npad / 16, B), dim3(256), 0, st, x, w.mu, N, C, Npad, w.xxc);
-            hipLaunchKernelGGL(knn_bmax_kernel, dim3(B), dim3(1024), 0, st, w.xxc, xx, N, Npad, w.bmax, w.f16ok);
-            if (hipMemsetAsync(w.rbflag, 0, (size_t)B * (Npad / 32) * sizeof(int), st) != hipSuccess)
-                DG_FAIL("dgcnn_knn: memset failed");
             const dim3 bgrid(B * parts * (Npad / (32 * KNN_ST_WAVES))), bblock(KNN_ST_THREADS);
             prof_begin(PROF_KNN_BOUND, st);
 #define DG_BOUND16(CP_)                                                                                              \
