@@ -28,13 +28,17 @@ int edge_grid(int P);
 void launch_edge_reduce(const float *TP, const float *TQ, const int32_t *idx, int N, int k, int P,
                         const float *gamma, float *usel, float *usum, uint8_t *hitj, double *partial, hipStream_t st);
 // training-mode stage-1 backward as a gather over the reverse adjacency of the kNN graph (see edge_stream.hip).
-// Scratch: cnt [B * rev_chunks][N], indeg [P], rowptr [P + 1], rev [E], extra [2 + 2 (E / 128 + 1)] ints; sparse dv only: hits [E] x 32 bytes, G [P][64].
-// dR is overwritten (no zero fill).  dv == NULL: sparse dv from (gy, y, hitj); else dense dv [E][64].
+// launch_rev_build: the lists (depends on idx only).  Scratch: cnt [B * rev_chunks][N], indeg [P]; results: rowptr
+// [P + 1], rev [E], extra [2 + 2 (E / 128 + 1)] ints.
+// launch_edge_bwd_nogather: sparse dv only: hits [E] x 32 bytes, G [P][64].  dR is overwritten (no zero fill).
+// dv == NULL: sparse dv from (gy, y, hitj); else dense dv [E][64].
 int rev_chunks(int B, int N, int k);
-int launch_edge_bwd_nogather(const float *TP, const float *TQ, const int32_t *idx, int B, int N, int k,
-                             const float *stats, const float *cc, float slope, const float *gy, const float *y,
-                             const uint8_t *hitj, const float *usum, const float *dv, int *cnt, int *indeg, int *rowptr,
-                             int32_t *rev, int *extra, void *hits, float *G, float *dR, float *dD, hipStream_t st);
+int launch_rev_build(const int32_t *idx, int B, int N, int k, int *cnt, int *indeg, int *rowptr, int32_t *rev, int *extra,
+                     hipStream_t st);
+int launch_edge_bwd_nogather(const float *TP, const float *TQ, int B, int N, int k, const float *stats, const float *cc,
+                             float slope, const float *gy, const float *y, const uint8_t *hitj, const float *usum,
+                             const float *dv, const int *rowptr, const int32_t *rev, const int *extra, void *hits,
+                             float *G, float *dR, float *dD, hipStream_t st);
 // BatchNorm statistics from the partial sums -> stats[ST_*]; running-statistics update
 void launch_bn_finalize(double *partial, int nparts, double count, int training, const dgcnn_bn_params &bn,
                         float eps, float momentum, float *stats, hipStream_t st);

@@ -453,7 +453,7 @@ __global__ __launch_bounds__(REV_THREADS) void rev_scan_kernel(const int *__rest
 {
     __shared__ int part[REV_THREADS];
     const int b = blockIdx.x, tid = threadIdx.x;
-    if (b == 0 && tid == 0) *nextra = 0;  // counter of rev_heavy_kernel
+    if (b == 0 && tid == 0) *nextra = 0;  // counter of rev_slots_kernel
     const int *deg = indeg + (size_t)b * N;
     const int per = (N + REV_THREADS - 1) / REV_THREADS;
     const int beg = tid * per < N ? tid * per : N, end = beg + per < N ? beg + per : N;
@@ -475,20 +475,41 @@ __global__ __launch_bounds__(REV_THREADS) void rev_scan_kernel(const int *__rest
     if (b == (int)gridDim.x - 1 && tid == REV_THREADS - 1) rowptr[(size_t)gridDim.x * N] = (int)gridDim.x * N * k;
 }
 
-// cnt[b][chunk][m] <- first slot of chunk's edges into m
+// cnt[b][chunk][m] <- first slot of chunk's edges into m; also lists the extra segments of long lists:
+// (point, segment) pairs for segments 1 .. (deg - 1) / REV_SEG, allocated with one atomic per wave
+constexpr int REV_SEG = 128;
 __global__ __launch_bounds__(256) void rev_slots_kernel(const int *__restrict__ rowptr, int N, int chunks, int P,
-                                                        int *__restrict__ cnt)
+                                                        int *__restrict__ cnt, int *__restrict__ nextra,
+                                                        int2 *__restrict__ extra)
 {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= P) return;
-    const int b = g / N, m = g - b * N;
-    int *cb = cnt + (size_t)b * chunks * N + m;
-    int slot = rowptr[g];
-    for (int c = 0; c < chunks; ++c) {
-        const int n = cb[(size_t)c * N];
-        cb[(size_t)c * N] = slot;
-        slot += n;
+    int nseg = 0;
+    if (g < P) {
+        const int b = g / N, m = g - b * N;
+        int *cb = cnt + (size_t)b * chunks * N + m;
+        int slot = rowptr[g];
+        nseg = (rowptr[g + 1] - slot - 1) / REV_SEG;  // deg <= REV_SEG (also 0): none
+        nseg = nseg < 0 ? 0 : nseg;
+        for (int c = 0; c < chunks; ++c) {
+            const int n = cb[(size_t)c * N];
+            cb[(size_t)c * N] = slot;
+            slot += n;
+        }
     }
+    // wave-aggregated allocation: inclusive scan of nseg over the lanes, one atomicAdd by the last lane
+    const int lane = threadIdx.x & 63;
+    int incl = nseg;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    const int total = __shfl(incl, 63);
+    if (total == 0) return;
+    int base = 0;
+    if (lane == 63) base = atomicAdd(nextra, total);
+    base = __shfl(base, 63) + incl - nseg;
+    for (int sgm = 0; sgm < nseg; ++sgm) extra[base + sgm] = int2{g, sgm + 1};
 }
 
 __global__ __launch_bounds__(REV_THREADS) void rev_place_kernel(const int32_t *__restrict__ idx, int N, int k,
@@ -521,22 +542,8 @@ static_assert(sizeof(HitRec) == 32, "HitRec is one 32-byte sector");
 // kNN graphs in feature space have hubs (at B = 8, N = 7000, k = 30 on Gaussian features: median in-degree 12,
 // maximum 1372), and one wave walking a hub's list alone would set the kernel time.  A point's list is therefore
 // cut into segments of REV_SEG in-edges: edge_rgather_kernel<., false> does segment 0 of every point and writes
-// dR, rev_heavy_kernel lists the remaining (point, segment) pairs, and edge_rgather_kernel<., true> adds those
+// dR, rev_slots_kernel lists the remaining (point, segment) pairs, and edge_rgather_kernel<., true> adds those
 // with one 256-byte wave-atomic each.
-constexpr int REV_SEG = 128;
-
-__global__ __launch_bounds__(256) void rev_heavy_kernel(const int *__restrict__ rowptr, int P, int *__restrict__ nextra,
-                                                        int2 *__restrict__ extra)
-{
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= P) return;
-    const int deg = rowptr[m + 1] - rowptr[m];
-    if (deg <= REV_SEG) return;
-    const int n = (deg - 1) / REV_SEG;  // segments 1 .. n
-    const int base = atomicAdd(nextra, n);
-    for (int sgm = 0; sgm < n; ++sgm) extra[base + sgm] = int2{m, sgm + 1};
-}
-
 // sums over the list entries [beg, end) (at most REV_SEG; ev_first = entries beg .. beg + 63 in the lanes):
 // sq = sum of the sources' TQ rows, sd = sum of their dv rows (DENSE); sparse hits go to sacc[channel]
 template <bool DENSE>
@@ -769,10 +776,8 @@ int rev_chunks(int B, int N, int k)
     return c < 1 ? 1 : c;
 }
 
-int launch_edge_bwd_nogather(const float *TP, const float *TQ, const int32_t *idx, int B, int N, int k,
-                             const float *stats, const float *cc, float slope, const float *gy, const float *y,
-                             const uint8_t *hitj, const float *usum, const float *dv, int *cnt, int *indeg, int *rowptr,
-                             int32_t *rev, int *extra, void *hits, float *G, float *dR, float *dD, hipStream_t st)
+int launch_rev_build(const int32_t *idx, int B, int N, int k, int *cnt, int *indeg, int *rowptr, int32_t *rev, int *extra,
+                     hipStream_t st)
 {
     DG_REQUIRE(N <= REV_MAX_N, "dgcnn_edgeconv_bwd: N=%d > %d unsupported in training mode", N, REV_MAX_N);
     const int P = B * N, chunks = rev_chunks(B, N, k);
@@ -783,15 +788,25 @@ int launch_edge_bwd_nogather(const float *TP, const float *TQ, const int32_t *id
         (void)hipFuncSetAttribute((const void *)rev_place_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, REV_MAX_N * 4);
         attr_done = true;
     }
-    const dim3 grid(stream_grid(P)), block(256);
+    int *nextra = extra;  // [0]: counter, then (point, segment) pairs
+    int2 *elist = reinterpret_cast<int2 *>(extra + 2);
     hipLaunchKernelGGL(rev_count_kernel, dim3(B * chunks), dim3(REV_THREADS), lds, st, idx, N, k, chunks, cnt);
     hipLaunchKernelGGL(rev_degree_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, st, cnt, N, chunks, P, indeg);
-    int *nextra = extra;                                      // [0]: counter, then (point, segment) pairs
-    int2 *elist = reinterpret_cast<int2 *>(extra + 2);
     hipLaunchKernelGGL(rev_scan_kernel, dim3(B), dim3(REV_THREADS), 0, st, indeg, N, k, rowptr, nextra);
-    hipLaunchKernelGGL(rev_slots_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, st, rowptr, N, chunks, P, cnt);
+    hipLaunchKernelGGL(rev_slots_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, st, rowptr, N, chunks, P, cnt, nextra, elist);
     hipLaunchKernelGGL(rev_place_kernel, dim3(B * chunks), dim3(REV_THREADS), lds, st, idx, N, k, chunks, cnt, rev);
-    hipLaunchKernelGGL(rev_heavy_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, st, rowptr, P, nextra, elist);
+    return 0;
+}
+
+int launch_edge_bwd_nogather(const float *TP, const float *TQ, int B, int N, int k, const float *stats, const float *cc,
+                             float slope, const float *gy, const float *y, const uint8_t *hitj, const float *usum,
+                             const float *dv, const int *rowptr, const int32_t *rev, const int *extra, void *hits,
+                             float *G, float *dR, float *dD, hipStream_t st)
+{
+    const int P = B * N;
+    const dim3 grid(stream_grid(P)), block(256);
+    const int *nextra = extra;
+    const int2 *elist = reinterpret_cast<const int2 *>(extra + 2);
     if (dv)
         hipLaunchKernelGGL((edge_point_bwd_kernel<true>), grid, block, 0, st, TQ, N, k, P, stats, cc, slope, gy, y, hitj, usum,
                            dv, (HitRec *)hits, G, dD);

@@ -19,6 +19,8 @@
 //   edge_bwd         du1 -> dD (sum over k) and dR (scatter-add to neighbours)
 //   wgrad + finish   gW1 = [ (dR - dD)^T x | dD^T x ]                           (MFMA, per point)
 //   rowgemm          gx = dR Wa + dD (Wb - Wa)                                   (MFMA, per point)
+#include <stdlib.h>
+
 #include "edge_kernels.h"
 
 namespace dgcnn {
@@ -38,7 +40,7 @@ struct Carver {
 };
 
 struct SavedLayout {
-    float *TP, *TQ, *usel, *usum, *stats1, *stats2;
+    float *TP, *TQ, *usel, *usum, *stats1, *stats2, *wcat;
     uint8_t *hitj;
     size_t bytes;
 };
@@ -54,12 +56,13 @@ static SavedLayout saved_layout(const dgcnn_edgeconv_desc *d, void *p)
     s.hitj = c.take<uint8_t>(P * EC);  // slot of the edge that wins max-over-k (one-stage block)
     s.stats1 = c.take<float>(ST_SIZE);
     s.stats2 = c.take<float>(ST_SIZE);
+    s.wcat = c.take<float>((size_t)128 * d->C);  // [Wa ; Wb - Wa] of the forward, reused by the backward's dgrad
     s.bytes = c.off;
     return s;
 }
 
 struct FwdWs {
-    float *wcatT, *wcat;
+    float *wcatT;
     double *partial;
     size_t bytes;
 };
@@ -68,14 +71,13 @@ static FwdWs fwd_ws(const dgcnn_edgeconv_desc *d, void *p)
     Carver c(p);
     FwdWs w;
     w.wcatT = c.take<float>((size_t)(d->C + 1) * 128);
-    w.wcat = c.take<float>((size_t)128 * d->C);
     w.partial = c.take<double>((size_t)(PART_MAX + PART_FOLD) * 2 * 64);
     w.bytes = c.off;
     return w;
 }
 
 struct BwdWs {
-    float *wcatT, *wcat, *cc1, *cc2, *dR, *dD, *wg_partial, *wg_sum, *dv1, *dw2_partial;
+    float *cc1, *cc2, *dR, *dD, *wg_partial, *wg_sum, *dv1, *dw2_partial;
     double *partial, *bn1_partial;
     int *cnt, *indeg, *rowptr, *rev, *extra;  // reverse adjacency of the kNN graph (training mode)
     void *hits;
@@ -87,8 +89,6 @@ static BwdWs bwd_ws(const dgcnn_edgeconv_desc *d, void *p)
     Carver c(p);
     BwdWs w;
     const size_t P = (size_t)d->B * d->N;
-    w.wcatT = c.take<float>((size_t)(d->C + 1) * 128);
-    w.wcat = c.take<float>((size_t)128 * d->C);
     w.partial = c.take<double>((size_t)(PART_MAX + PART_FOLD) * 2 * 64);
     w.cc1 = c.take<float>(128);
     w.cc2 = c.take<float>(128);
@@ -168,7 +168,7 @@ extern "C" int dgcnn_edgeconv_fwd(const dgcnn_edgeconv_desc *d, const float *x, 
     const int P = d->B * d->N, N = d->N, C = d->C, k = d->k;
     const double E = (double)P * k;
 
-    launch_prep_wcat(d->w1, C, C, w.wcatT, w.wcat, st);
+    launch_prep_wcat(d->w1, C, C, w.wcatT, s.wcat, st);
     launch_rowgemm(x, C, nullptr, 0, w.wcatT, 128, s.TP, EC, s.TQ, P, st);
     if (d->n_stage == 1) {
         if (!d->training) launch_bn_finalize(w.partial, 0, E, 0, d->bn1, d->eps, d->momentum, s.stats1, st);
@@ -209,14 +209,16 @@ extern "C" int dgcnn_edgeconv_bwd(const dgcnn_edgeconv_desc *d, const float *x, 
     const int P = d->B * d->N, N = d->N, C = d->C, k = d->k;
     const double E = (double)P * k;
 
-    launch_prep_wcat(d->w1, C, C, w.wcatT, w.wcat, st);
     if (!d->training && hipMemsetAsync(w.dR, 0, (size_t)P * EC * sizeof(float), st) != hipSuccess)
         DG_FAIL("dgcnn_edgeconv_bwd: hipMemsetAsync failed");  // eval mode scatters into dR
+    // (measured: building the lists on a side stream, concurrently with the BatchNorm-backward sums and the
+    // per-point pass, costs more in cross-stream barriers than it hides: 0.776 ms against 0.725 ms per step)
+    if (d->training && launch_rev_build(idx, d->B, N, k, w.cnt, w.indeg, w.rowptr, w.rev, w.extra, st)) return 1;
     if (d->n_stage == 1) {
         launch_bwd_point(gy, s.usel, s.stats1, d->slope, P, E, d->training, w.partial, g->gbn1_w, g->gbn1_b, w.cc1, st);
         if (d->training) {
-            if (launch_edge_bwd_nogather(s.TP, s.TQ, idx, d->B, N, k, s.stats1, w.cc1, d->slope, gy, y, s.hitj, s.usum,
-                                         nullptr, w.cnt, w.indeg, w.rowptr, w.rev, w.extra, w.hits, w.G, w.dR, w.dD, st))
+            if (launch_edge_bwd_nogather(s.TP, s.TQ, d->B, N, k, s.stats1, w.cc1, d->slope, gy, y, s.hitj, s.usum, nullptr,
+                                         w.rowptr, w.rev, w.extra, w.hits, w.G, w.dR, w.dD, st))
                 return 1;
         } else {
             launch_edge_bwd(s.TP, s.TQ, idx, N, k, P, s.stats1, w.cc1, d->slope, d->training, gy, y, nullptr, w.dR, w.dD,
@@ -229,8 +231,8 @@ extern "C" int dgcnn_edgeconv_bwd(const dgcnn_edgeconv_desc *d, const float *x, 
         launch_sum_partials(w.dw2_partial, mlp_grid(P), EC * EC, g->gw2, st);
         launch_bn_bwd_finalize(w.bn1_partial, mlp_grid(P), E, d->training, g->gbn1_w, g->gbn1_b, w.cc1, st);
         if (d->training) {
-            if (launch_edge_bwd_nogather(s.TP, s.TQ, idx, d->B, N, k, s.stats1, w.cc1, d->slope, gy, y, nullptr, s.usum,
-                                         w.dv1, w.cnt, w.indeg, w.rowptr, w.rev, w.extra, nullptr, nullptr, w.dR, w.dD, st))
+            if (launch_edge_bwd_nogather(s.TP, s.TQ, d->B, N, k, s.stats1, w.cc1, d->slope, gy, y, nullptr, s.usum, w.dv1,
+                                         w.rowptr, w.rev, w.extra, nullptr, nullptr, w.dR, w.dD, st))
                 return 1;
         } else {
             launch_edge_bwd(s.TP, s.TQ, idx, N, k, P, s.stats1, w.cc1, d->slope, d->training, gy, y, w.dv1, w.dR, w.dD, st);
@@ -238,7 +240,7 @@ extern "C" int dgcnn_edgeconv_bwd(const dgcnn_edgeconv_desc *d, const float *x, 
     }
     launch_wgrad(w.dR, EC, w.dD, EC, x, C, P, w.wg_partial, st);
     launch_finish_dw1(w.wg_partial, wgrad_chunks(P), C, w.wg_sum, g->gw1, st);
-    if (g->gx) launch_rowgemm(w.dR, EC, w.dD, EC, w.wcat, C, g->gx, C, nullptr, P, st);
+    if (g->gx) launch_rowgemm(w.dR, EC, w.dD, EC, s.wcat, C, g->gx, C, nullptr, P, st);
     DG_CHECK_LAUNCH("dgcnn_edgeconv_bwd");
     return 0;
 }
