@@ -115,6 +115,60 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(const float *__restrict__ 
     }
 }
 
+// Fast path of rowgemm_kernel for the shapes of the 64-channel blocks (forward K = 64 -> NO = 128, dgrad K = 128 ->
+// NO = 64): everything is compile-time or wave-uniform, so the K loop is straight-line code (the general kernel
+// above guards every operand and ends up with one branch and one s_waitcnt per MFMA).
+//   K = 2 KH, NO = 32 NT, K * NO <= RG_LDS_FLOATS, NO0 a multiple of 32, and either K1 == 0 or K0 == KH, so that the
+//   KH values of a lane (k = h KH + s) are one contiguous run of one source row.
+template <int KH, int NT>
+__global__ __launch_bounds__(256) void rowgemm_fast_kernel(const float *__restrict__ A0, int K0,
+                                                           const float *__restrict__ A1, int K1,
+                                                           const float *__restrict__ W, float *__restrict__ Y0, int NO0,
+                                                           float *__restrict__ Y1, int P)
+{
+    constexpr int K = 2 * KH, NO = 32 * NT;
+    __shared__ float wl[K * NO];
+    for (int e = threadIdx.x; e < K * NO / 4; e += 256)
+        reinterpret_cast<float4 *>(wl)[e] = reinterpret_cast<const float4 *>(W)[e];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, i32 = lane & 31;
+    const int p0 = (blockIdx.x * 4 + wave) * 32;
+    const int row = p0 + i32 < P ? p0 + i32 : P - 1;  // clamped: loads are unconditional, stores guarded
+    const float *src = (K1 == 0 || h == 0) ? A0 + (size_t)row * K0 + h * (K1 == 0 ? KH : 0) : A1 + (size_t)row * K1;
+    float4 av[KH / 4];
+#pragma unroll
+    for (int i = 0; i < KH / 4; ++i) av[i] = reinterpret_cast<const float4 *>(src)[i];
+    __syncthreads();
+    if (p0 >= P) return;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
+    const float *wrow = wl + (size_t)h * KH * NO + i32;
+#pragma unroll
+    for (int i = 0; i < KH / 4; ++i) {
+        const float a4[4] = {av[i].x, av[i].y, av[i].z, av[i].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], wrow[(4 * i + e) * NO + nt * 32], acc[nt], 0, 0, 0);
+    }
+    const bool full = p0 + 32 <= P;
+    const int NO1 = NO - NO0;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = nt * 32 + i32;
+        float *dst = n < NO0 ? Y0 + n : Y1 + (n - NO0);
+        const int ld = n < NO0 ? NO0 : NO1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int pr = p0 + mfma32_row(r, h);
+            if (full || pr < P) dst[(size_t)pr * ld] = acc[nt][r];
+        }
+    }
+}
+
 constexpr int WGRAD_CHUNK = 64;  // points per wave (875 waves at P = 56 000)
 
 // partial[chunk][m][n] = sum_p A(p, m) X[p][n]: contraction over the points (MFMA K dimension).
@@ -236,6 +290,18 @@ void launch_rowgemm(const float *A0, int K0, const float *A1, int K1, const floa
 {
     const dim3 grid(ceil_div(ceil_div(P, 32), 4)), block(256);
     const int nt = ceil_div(NO, 32);
+    const int K = K0 + K1, NO1 = NO - NO0;
+    const bool runs_ok = (K1 == 0 || K0 == K / 2) && (K0 & 3) == 0 && (K1 & 3) == 0;
+    if (runs_ok && NO0 % 32 == 0 && NO1 % 32 == 0 && (NO1 == 0 || Y1)) {
+        if (K == 64 && NO == 128) {
+            hipLaunchKernelGGL((rowgemm_fast_kernel<32, 4>), grid, block, 0, st, A0, K0, A1, K1, W, Y0, NO0, Y1, P);
+            return;
+        }
+        if (K == 128 && NO == 64) {
+            hipLaunchKernelGGL((rowgemm_fast_kernel<64, 2>), grid, block, 0, st, A0, K0, A1, K1, W, Y0, NO0, Y1, P);
+            return;
+        }
+    }
     if (nt <= 1)
         hipLaunchKernelGGL((rowgemm_kernel<1>), grid, block, 0, st, A0, K0, A1, K1, W, NO, Y0, NO0, Y1, P);
     else if (nt == 2)
