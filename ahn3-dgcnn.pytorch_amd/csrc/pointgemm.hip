@@ -310,12 +310,76 @@ void launch_rowgemm(const float *A0, int K0, const float *A1, int K1, const floa
         hipLaunchKernelGGL((rowgemm_kernel<4>), grid, block, 0, st, A0, K0, A1, K1, W, NO, Y0, NO0, Y1, P);
 }
 
+// wgrad_kernel for M0 = M1 = 64, C = 64 (the 64-channel blocks): no operand guards, only the row clamp
+__global__ __launch_bounds__(64) void wgrad_fast64_kernel(const float *__restrict__ A0, const float *__restrict__ A1,
+                                                          const float *__restrict__ X, int P, float *__restrict__ partial)
+{
+    constexpr int MT = 4, NT = 2, UN = 4;
+    const int lane = threadIdx.x, h = lane >> 5, i32 = lane & 31;
+    const int pbeg = blockIdx.x * WGRAD_CHUNK;
+    const int pend = pbeg + WGRAD_CHUNK < P ? pbeg + WGRAD_CHUNK : P;
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+    // operands of 8 points per step; the next step's loads are issued before this step's 32 MFMAs (the wave is
+    // alone on its SIMD: without the prefetch every step pays a full load round trip)
+    float a[UN][MT], b[UN][NT], an[UN][MT], bn[UN][NT];
+    auto fetch = [&](int p, float(&fa)[UN][MT], float(&fb)[UN][NT]) {
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int pp = p + 2 * u + h;
+            const bool pv = pp < pend;
+            const size_t ro = (size_t)(pv ? pp : pbeg) * 64 + i32;  // clamped row: unconditional loads, masked values
+            const float a0 = A0[ro], a1 = A0[ro + 32], a2 = A1[ro], a3 = A1[ro + 32], b0 = X[ro], b1 = X[ro + 32];
+            fa[u][0] = pv ? a0 : 0.0f;
+            fa[u][1] = pv ? a1 : 0.0f;
+            fa[u][2] = pv ? a2 : 0.0f;
+            fa[u][3] = pv ? a3 : 0.0f;
+            fb[u][0] = pv ? b0 : 0.0f;
+            fb[u][1] = pv ? b1 : 0.0f;
+        }
+    };
+    fetch(pbeg, a, b);
+    for (int p = pbeg; p < pend; p += 2 * UN) {
+        fetch(p + 2 * UN, an, bn);  // past the chunk end: all rows masked
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][mt], b[u][nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[u][mt] = an[u][mt];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) b[u][nt] = bn[u][nt];
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                partial[((size_t)blockIdx.x * 128 + mt * 32 + mfma32_row(r, h)) * 64 + nt * 32 + i32] = acc[mt][nt][r];
+}
+
 int wgrad_chunks(int P) { return ceil_div(P, WGRAD_CHUNK); }
 
 void launch_wgrad(const float *A0, int M0, const float *A1, int M1, const float *X, int C, int P, float *partial,
                   hipStream_t st)
 {
     const dim3 grid(wgrad_chunks(P)), block(64);
+    if (M0 == 64 && M1 == 64 && C == 64) {
+        hipLaunchKernelGGL(wgrad_fast64_kernel, grid, block, 0, st, A0, A1, X, P, partial);
+        return;
+    }
     const int mt = ceil_div(M0 + M1, 32), nt = ceil_div(C, 32);
 #define DG_WG(MT_, NT_) \
     hipLaunchKernelGGL((wgrad_kernel<MT_, NT_>), grid, block, 0, st, A0, M0, A1, M1, X, C, P, partial)
