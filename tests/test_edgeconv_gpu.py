@@ -118,6 +118,47 @@ def test_two_stage_block(B, C, N, k, train, device):
     compare(B, C, N, k, 2, train, device)
 
 
+def hub_graph(B, N, k, seed):
+    """a neighbour graph (not a kNN graph) in which point 0 is everybody's first neighbour: in-degree N, which the
+    backward has to cut into 128-edge segments; the other neighbours are random and distinct"""
+    rng = np.random.default_rng(seed)
+    idx = np.empty((B, N, k), dtype=np.int32)
+    for b in range(B):
+        for i in range(N):
+            idx[b, i, 0] = 0
+            idx[b, i, 1:] = rng.choice(np.arange(1, N), size=k - 1, replace=False)
+    return idx
+
+
+@pytest.mark.parametrize("n_stage", [1, 2])
+@pytest.mark.parametrize("N,k", [(400, 16), (150, 3)])
+def test_backward_with_hub_points_and_crowded_edges(N, k, n_stage, device):
+    # (400, 16): in-degree 400 -> three extra list segments;  (150, 3): ~21 of the 64 channel maxima land on each
+    # edge, far more than the 4 values a hit record holds (the spill path reads the row of G)
+    B, C = 2, 16
+    base = make_stages(2 * C, n_stage)
+    for seed in range(200):
+        x = torch.randn(B, C, N, generator=torch.Generator().manual_seed(seed))
+        idx = hub_graph(B, N, k, seed)
+        if premax_top2_gap(x, idx, base, True) >= 2e-6:
+            break
+    else:
+        raise AssertionError("no near-tie-free input found")
+    R = cotangent((B, 64, N), tag="edge")
+    import copy
+    y0, gx0, st0 = run_oracle(x, idx, copy.deepcopy(base), True, R)
+    y1, gx1, st1 = run_hip(x, idx, base, True, R, device)
+    np.testing.assert_allclose(y1.numpy(), y0.numpy(), rtol=0, atol=ATOL_FWD)
+    for a, b, what in [(gx1, gx0, "grad x")] + [(s1[0].weight.grad.cpu(), s0[0].weight.grad, "grad conv weight %d" % i)
+                                                  for i, (s0, s1) in enumerate(zip(st0, st1))]:
+        tol = RTOL_GRAD * float(b.abs().max())
+        assert float((a - b).abs().max()) <= tol, what
+
+
+def test_single_stage_block_k_above_64(device):
+    compare(1, 8, 200, 70, 1, True, device)
+
+
 def test_block_with_large_mean_inputs(device):
     # |mean| >> sigma in the conv outputs: the BatchNorm batch statistics must not cancel (fp64 sums)
     g = torch.Generator().manual_seed(3)
