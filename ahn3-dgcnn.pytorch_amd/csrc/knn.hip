@@ -265,15 +265,18 @@ __device__ __forceinline__ float batch_max(const unsigned *__restrict__ tmax, in
 //   xt   raw features as fp32 operand tiles (the layout of knn_tile_kernel<4>) for the fallback kernel
 //   bmax[b][which][tile] = largest centred (which = 0) / raw (1) norm of the tile, as uint bits of non-negative
 //        floats (NaN bits win the comparison, as they must); batch_max() reduces them where they are needed
+//   rbflag[b][tile] = 0: the fallback flag of the row block, set later by the filter / refine kernels
 __global__ __launch_bounds__(256) void knn_prep16_kernel(const float *__restrict__ x, const float *__restrict__ mu,
                                                          int N, int C, int Npad, int CP, float *__restrict__ xx,
                                                          float *__restrict__ xxc, half8 *__restrict__ xh,
-                                                         float *__restrict__ xt, unsigned *__restrict__ bmax)
+                                                         float *__restrict__ xt, unsigned *__restrict__ bmax,
+                                                         int *__restrict__ rbflag)
 {
     __shared__ float xs[32][129];  // C <= 128; odd stride: conflict-free column walks
     __shared__ float ms[128];
     const int tid = threadIdx.x;
     const int b = blockIdx.y, tile = blockIdx.x, q0 = tile * 32;
+    if (tid == 0) rbflag[(size_t)b * (Npad / 32) + tile] = 0;  // fallback flag of this row block (set by filter / refine)
     for (int i = tid; i < 32 * C; i += 256) {
         const int r = i / C, c = i - r * C;
         xs[r][c] = q0 + r < N ? x[((size_t)b * N + q0) * C + i] : 0.0f;
@@ -1048,6 +1051,7 @@ __global__ __launch_bounds__(KNN_ST_THREADS) void knn_filter16_kernel(const half
         asm volatile("" : "+v"(bits) : "v"(acc));
         return bits;
 #endif
+        // (plain fp32 fma / sub instead of the packed forms: 101 against 104 us -- not worth the doubled issue slots)
 #pragma unroll
         for (int i = 7; i >= 0; --i) {
             const f32x2 t = __builtin_elementwise_fma(f32x2{acc[2 * i], acc[2 * i + 1]}, f32x2{2.0f, 2.0f}, f32x2{-y, -y});
@@ -1440,10 +1444,8 @@ extern "C" int dgcnn_knn(const float *x, int B, int N, int C, int k, int32_t *id
     if (prepass && CP >= 16) {
         // one pass over x: norms, fp16 and fp32 operand tiles, norm maxima (after the centre of each batch element)
         hipLaunchKernelGGL(knn_center_kernel, dim3(B), dim3(256), 0, st, x, N, C, w.mu);
-        if (hipMemsetAsync(w.rbflag, 0, (size_t)B * (Npad / 32) * sizeof(int), st) != hipSuccess)
-            DG_FAIL("dgcnn_knn: memset failed");
         hipLaunchKernelGGL(knn_prep16_kernel, dim3(Npad / 32, B), dim3(256), 0, st, x, w.mu, N, C, Npad, CP, xx, w.xxc, w.xh,
-                           xt, w.bmax);
+                           xt, w.bmax, w.rbflag);
     } else {
         hipLaunchKernelGGL(knn_norm_kernel, dim3(ceil_div(Npad, 256), B), dim3(256), 0, st, x, N, C, Npad, xx);
         const size_t nvec = (size_t)Npad * CP / (CP >= 8 ? 4 : 2);
