@@ -61,7 +61,8 @@ void launch_bn_bwd_finalize(double *partial, int nparts, double count, int train
                             float *gbn_b, float *cc, hipStream_t st);
 
 // ---- edge_mlp.hip : per-edge 64 -> 64 contraction on MFMA (second stage of blocks 1, 2) ------
-int mlp_grid(int P);
+int mlp_grid(int P);      // backward: number of gW2 / BN1 partial records
+int mlp_grid_fwd(int P);  // forward: number of BN2 partial records
 void launch_edge_mlp_fwd(const float *TP, const float *TQ, const int32_t *idx, int N, int k, int P,
                          const float *stats1, const float *w2, const float *gamma2, float slope, float *usel2,
                          double *partial, hipStream_t st);

@@ -14,6 +14,8 @@
 //           the A operand (contraction over the edge rows held in the registers); da1 = du2 W2
 //           goes through one LDS transpose; dv1 = da1 * LReLU'(v1) is written to HBM ([E][64])
 //           for the stage-1 streaming pass, together with the BN1 backward sums.
+#include <stdlib.h>
+
 #include "edge_kernels.h"
 
 namespace dgcnn {
@@ -21,7 +23,15 @@ namespace dgcnn {
 constexpr int MLP_WAVES = 4;
 constexpr int TSTR = 68;  // LDS tile row stride in floats (64 + 4: conflict-free b128 rows)
 
+// workgroups: the backward holds 136 KB of LDS (one workgroup per CU); the forward 39 KB, so three per CU hide
+// each other's gather and LDS latencies (measured: 304 us at 32 slots per XCD)
+static int mlp_slots_fwd()
+{
+    static const int v = getenv("DGCNN_MLP_SLOTS") ? atoi(getenv("DGCNN_MLP_SLOTS")) : 96;  // experiments
+    return v;
+}
 int mlp_grid(int P) { return point_grid(P, MLP_WAVES, 32); }
+int mlp_grid_fwd(int P) { return point_grid(P, MLP_WAVES, mlp_slots_fwd()); }
 
 __device__ __forceinline__ double shfl_xor_d(double v, int m)
 {
@@ -356,7 +366,7 @@ void launch_edge_mlp_fwd(const float *TP, const float *TQ, const int32_t *idx, i
                          const float *stats1, const float *w2, const float *gamma2, float slope, float *usel2,
                          double *partial, hipStream_t st)
 {
-    hipLaunchKernelGGL(edge_mlp_fwd_kernel, dim3(mlp_grid(P)), dim3(256), 0, st, TP, TQ, idx, N, k, P, stats1, w2,
+    hipLaunchKernelGGL(edge_mlp_fwd_kernel, dim3(mlp_grid_fwd(P)), dim3(256), 0, st, TP, TQ, idx, N, k, P, stats1, w2,
                        gamma2, slope, usel2, partial);
 }
 

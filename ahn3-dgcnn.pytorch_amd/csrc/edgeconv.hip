@@ -186,7 +186,7 @@ extern "C" int dgcnn_edgeconv_fwd(const dgcnn_edgeconv_desc *d, const float *x, 
         }
         launch_edge_mlp_fwd(s.TP, s.TQ, idx, N, k, P, s.stats1, d->w2, d->bn2.weight, d->slope, s.usel, w.partial, st);
         if (d->training)
-            launch_bn_finalize(w.partial, mlp_grid(P), E, 1, d->bn2, d->eps, d->momentum, s.stats2, st);
+            launch_bn_finalize(w.partial, mlp_grid_fwd(P), E, 1, d->bn2, d->eps, d->momentum, s.stats2, st);
         launch_edge_out(s.usel, s.stats2, d->slope, P, y, st);
     }
     DG_CHECK_LAUNCH("dgcnn_edgeconv_fwd");
