@@ -41,28 +41,34 @@ __device__ __forceinline__ double shfl_xor_d(double v, int m)
     return __hiloint2double(hi, lo);
 }
 
-// gather one M-tile (edges j0 .. j0 + 31 of point pt) and leave a1 (and optionally u1) in LDS
-template <bool KEEP_U>
-__device__ __forceinline__ void gather_tile(const float *__restrict__ Pb, float q, int nv, int kk, float sc1,
-                                            float sh1, float slope, float (*tileA)[TSTR], float (*tileU)[TSTR],
-                                            int lane)
+// gather one M-tile (edges j0 .. j0 + 31 of a point): the loads (rows of TP -> registers; wave-uniform table base,
+// 32-bit element offsets, rows past the list end repeat its last row) are split from the consumer, so that the
+// next point's rows can be in flight under the current point's MFMA phases
+__device__ __forceinline__ void gather_rows(const float *__restrict__ Pb, int nv, int kk, int lane, float (&p)[32])
 {
 #pragma unroll
-    for (int j = 0; j < 32; j += 8) {
-        float p[8];
+    for (int g = 0; g < 4; ++g) {
+        if (g * 8 < kk) {
 #pragma unroll
-        for (int t = 0; t < 8; ++t)
-            if (j + t < kk) p[t] = Pb[(size_t)__builtin_amdgcn_readlane(nv, j + t) * EC];
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            float a = 0.0f, u = 0.0f;
-            if (j + t < kk) {
-                u = p[t] + q;
-                a = lrelu(__builtin_fmaf(u, sc1, sh1), slope);
+            for (int t = 0; t < 8; ++t) {
+                const int tt = g * 8 + t < kk ? g * 8 + t : kk - 1;
+                p[g * 8 + t] = Pb[(unsigned)__builtin_amdgcn_readlane(nv, tt) * (unsigned)EC + (unsigned)lane];
             }
-            tileA[j + t][lane] = a;
-            if (KEEP_U) tileU[j + t][lane] = u;
         }
+    }
+}
+// leave a1 (and optionally u1) of the gathered tile in LDS; rows >= kk are zero
+template <bool KEEP_U>
+__device__ __forceinline__ void stage_tile(const float (&p)[32], float q, int kk, float sc1, float sh1, float slope,
+                                           float (*tileA)[TSTR], float (*tileU)[TSTR], int lane)
+{
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const bool on = j < kk;
+        const float u = on ? p[j] + q : 0.0f;
+        const float a = on ? lrelu(__builtin_fmaf(u, sc1, sh1), slope) : 0.0f;
+        tileA[j][lane] = a;
+        if (KEEP_U) tileU[j][lane] = u;
     }
 }
 
@@ -105,9 +111,11 @@ __global__ __launch_bounds__(256) void edge_mlp_fwd_kernel(const float *__restri
 
     double sum[2] = {0.0, 0.0}, sq[2] = {0.0, 0.0};
     const PointIter it = point_iter(P, wave, MLP_WAVES);
+    // (three workgroups per CU hide the gather latency here: prefetching the next point's rows as the backward does
+    // costs registers and residency -- measured 280 us against 217)
     for (int pt = it.cur; pt < it.end; pt += it.step) {
         const int b = pt / N;
-        const float *Pb = TP + (size_t)b * N * EC + lane;
+        const float *Pb = TP + (size_t)b * N * EC;
         const float q = TQ[(size_t)pt * EC + lane];
         const int32_t *ip = idx + (size_t)pt * k;
         float ext[2];
@@ -115,8 +123,25 @@ __global__ __launch_bounds__(256) void edge_mlp_fwd_kernel(const float *__restri
         for (int nt = 0; nt < 2; ++nt) ext[nt] = neg[nt] ? __builtin_inff() : -__builtin_inff();
         for (int j0 = 0; j0 < k; j0 += 32) {
             const int kk = k - j0 < 32 ? k - j0 : 32;
-            const int nv = lane < kk ? ip[j0 + lane] : 0;
-            gather_tile<false>(Pb, q, nv, kk, sc1, sh1, slope, tileA, nullptr, lane);
+            {
+                // eight rows at a time (registers: the kernel has to stay at three waves per SIMD)
+                const int nv = lane < kk ? ip[j0 + lane] : 0;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float p[8];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        const int tt = g * 8 + t < kk ? g * 8 + t : kk - 1;
+                        p[t] = Pb[(unsigned)__builtin_amdgcn_readlane(nv, tt) * (unsigned)EC + (unsigned)lane];
+                    }
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        const bool on = g * 8 + t < kk;
+                        const float u = p[t] + q;
+                        tileA[g * 8 + t][lane] = on ? lrelu(__builtin_fmaf(u, sc1, sh1), slope) : 0.0f;
+                    }
+                }
+            }
             float a[32];
             load_a_operand(tileA, i32, h, a);
             f32x16 acc[2];
@@ -221,10 +246,20 @@ __global__ __launch_bounds__(256) void edge_mlp_bwd_kernel(
     double sb[2] = {0.0, 0.0}, sg[2] = {0.0, 0.0};  // BN1: sum dv1, sum dv1 * uhat1
 
     const PointIter it = point_iter(P, wave, MLP_WAVES);
+    // index rows two points ahead, table rows one point ahead (see the forward)
+    const int kk0 = k < 32 ? k : 32;
+    float pn[32], qn = 0.0f;
+    int nvnn = 0;
+    if (it.cur < it.end) {
+        const int nv0 = lane < kk0 ? idx[(size_t)it.cur * k + lane] : 0;
+        qn = TQ[(size_t)it.cur * EC + lane];
+        gather_rows(TP + (size_t)(it.cur / N) * N * EC, nv0, kk0, lane, pn);
+        if (it.cur + it.step < it.end) nvnn = lane < kk0 ? idx[(size_t)(it.cur + it.step) * k + lane] : 0;
+    }
     for (int pt = it.cur; pt < it.end; pt += it.step) {
         const int b = pt / N;
-        const float *Pb = TP + (size_t)b * N * EC + lane;
-        const float q = TQ[(size_t)pt * EC + lane];
+        const float *Pb = TP + (size_t)b * N * EC;
+        const float q = qn;
         const int32_t *ip = idx + (size_t)pt * k;
         float yv[2], dvs[2];
         bool found[2] = {false, false};
@@ -235,8 +270,21 @@ __global__ __launch_bounds__(256) void edge_mlp_bwd_kernel(
         }
         for (int j0 = 0; j0 < k; j0 += 32) {
             const int kk = k - j0 < 32 ? k - j0 : 32;
-            const int nv = lane < kk ? ip[j0 + lane] : 0;
-            gather_tile<true>(Pb, q, nv, kk, sc1g, sh1g, slope, tileA, tileU, lane);
+            if (j0 == 0) {
+                stage_tile<true>(pn, q, kk, sc1g, sh1g, slope, tileA, tileU, lane);
+                const int ptn = pt + it.step;
+                if (ptn < it.end) {
+                    const int nvn = nvnn;
+                    qn = TQ[(size_t)ptn * EC + lane];
+                    gather_rows(TP + (size_t)(ptn / N) * N * EC, nvn, kk0, lane, pn);
+                    if (ptn + it.step < it.end) nvnn = lane < kk0 ? idx[(size_t)(ptn + it.step) * k + lane] : 0;
+                }
+            } else {
+                float p2[32];
+                const int nv = lane < kk ? ip[j0 + lane] : 0;
+                gather_rows(Pb, nv, kk, lane, p2);
+                stage_tile<true>(p2, q, kk, sc1g, sh1g, slope, tileA, tileU, lane);
+            }
 
             // ---- u2 = a1 . W2^T
             float a[32];
