@@ -31,13 +31,14 @@ void launch_edge_reduce(const float *TP, const float *TQ, const int32_t *idx, in
 // launch_rev_build: the lists (depends on idx only).  Scratch: cnt [B * rev_chunks][N], indeg [P]; results: rowptr
 // [P + 1], rev [E], extra [2 + 2 (E / 128 + 1)] ints.
 // launch_edge_bwd_nogather: sparse dv only: hits [E] x 32 bytes, G [P][64].  dR is overwritten (no zero fill).
-// dv == NULL: sparse dv from (gy, y, hitj); else dense dv [E][64].
+// dv == NULL: sparse dv from (gy, y, hitj); else dense dv [E][64] with dvsum [P][64] = its sums over k.
 int rev_chunks(int B, int N, int k);
 int launch_rev_build(const int32_t *idx, int B, int N, int k, int *cnt, int *indeg, int *rowptr, int32_t *rev, int *extra,
                      hipStream_t st);
 int launch_edge_bwd_nogather(const float *TP, const float *TQ, int B, int N, int k, const float *stats, const float *cc,
                              float slope, const float *gy, const float *y, const uint8_t *hitj, const float *usum,
-                             const float *dv, const int *rowptr, const int32_t *rev, const int *extra, void *hits,
+                             const float *dv, const float *dvsum, const int *rowptr, const int32_t *rev, const int *extra,
+                             void *hits,
                              float *G, float *dR, float *dD, hipStream_t st);
 // BatchNorm statistics from the partial sums -> stats[ST_*]; running-statistics update
 void launch_bn_finalize(double *partial, int nparts, double count, int training, const dgcnn_bn_params &bn,
@@ -66,10 +67,11 @@ int mlp_grid_fwd(int P);  // forward: number of BN2 partial records
 void launch_edge_mlp_fwd(const float *TP, const float *TQ, const int32_t *idx, int N, int k, int P,
                          const float *stats1, const float *w2, const float *gamma2, float slope, float *usel2,
                          double *partial, hipStream_t st);
-// dv1 [E][64]; partial_dw2 [grid][64][64]; partial_bn1 [grid][2][64] doubles (sum dv1, sum dv1 * uhat1)
+// dv1 [E][64]; dvsum [P][64] = sum over each point's k edges of dv1; partial_dw2 [grid][64][64]; partial_bn1
+// [grid][2][64] doubles (sum dv1, sum dv1 * uhat1)
 void launch_edge_mlp_bwd(const float *TP, const float *TQ, const int32_t *idx, int N, int k, int P,
                          const float *stats1, const float *stats2, const float *cc2, const float *w2, float slope,
-                         int training, const float *gy, const float *y, float *dv1, float *partial_dw2,
+                         int training, const float *gy, const float *y, float *dv1, float *dvsum, float *partial_dw2,
                          double *partial_bn1, hipStream_t st);
 
 }  // namespace dgcnn

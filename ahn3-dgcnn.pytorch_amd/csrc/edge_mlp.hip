@@ -199,8 +199,8 @@ __global__ __launch_bounds__(256) void edge_mlp_bwd_kernel(
     const float *__restrict__ TP, const float *__restrict__ TQ, const int32_t *__restrict__ idx, int N, int k, int P,
     const float *__restrict__ stats1, const float *__restrict__ stats2, const float *__restrict__ cc2,
     const float *__restrict__ w2, float slope, int training, const float *__restrict__ gy,
-    const float *__restrict__ y, float *__restrict__ dv1, float *__restrict__ partial_dw2,
-    double *__restrict__ partial_bn1)
+    const float *__restrict__ y, float *__restrict__ dv1, float *__restrict__ dvsum,
+    float *__restrict__ partial_dw2, double *__restrict__ partial_bn1)
 {
     // W2 as the B operand of the two products that contract over a channel index:
     //   imgU[nt][s][lane (n, h)] = W2[co = nt 32 + n][ci = 32 h + s]     (u2  = a1 . W2^T)
@@ -262,6 +262,7 @@ __global__ __launch_bounds__(256) void edge_mlp_bwd_kernel(
         const float q = qn;
         const int32_t *ip = idx + (size_t)pt * k;
         float yv[2], dvs[2];
+        float dcol[2] = {0.0f, 0.0f};  // sum over the point's edges of dv1, per channel (for the centre term dD)
         bool found[2] = {false, false};
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
@@ -366,10 +367,16 @@ __global__ __launch_bounds__(256) void edge_mlp_bwd_kernel(
                         const float d = acc[nt][r] * (ba[nt][r] > 0.0f ? 1.0f : slope);
                         const float uhat = (tileU[row][nt * 32 + i32] - mean1[nt]) * rstd1[nt];
                         dv1[((size_t)pt * k + j0 + row) * EC + nt * 32 + i32] = d;
+                        dcol[nt] += d;
                         sb[nt] += (double)d;
                         sg[nt] = __builtin_fma((double)d, (double)uhat, sg[nt]);
                     }
                 }
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const float t = dcol[nt] + __shfl_xor(dcol[nt], 32);
+            if (h == 0) dvsum[(size_t)pt * EC + nt * 32 + i32] = t;
         }
     }
 
@@ -420,11 +427,11 @@ void launch_edge_mlp_fwd(const float *TP, const float *TQ, const int32_t *idx, i
 
 void launch_edge_mlp_bwd(const float *TP, const float *TQ, const int32_t *idx, int N, int k, int P,
                          const float *stats1, const float *stats2, const float *cc2, const float *w2, float slope,
-                         int training, const float *gy, const float *y, float *dv1, float *partial_dw2,
+                         int training, const float *gy, const float *y, float *dv1, float *dvsum, float *partial_dw2,
                          double *partial_bn1, hipStream_t st)
 {
     hipLaunchKernelGGL(edge_mlp_bwd_kernel, dim3(mlp_grid(P)), dim3(256), 0, st, TP, TQ, idx, N, k, P, stats1, stats2,
-                       cc2, w2, slope, training, gy, y, dv1, partial_dw2, partial_bn1);
+                       cc2, w2, slope, training, gy, y, dv1, dvsum, partial_dw2, partial_bn1);
 }
 
 }  // namespace dgcnn

@@ -700,7 +700,8 @@ __global__ __launch_bounds__(256) void edge_rgather_kernel(const float *__restri
     }
 }
 
-// dD[i] = sum_j sc dv[i][j] + k A[i] - alpha (usum[i] - k TQ[i]).  Sparse dv has one non-zero per (i, c), on the
+// dD[i] = sum_j sc dv[i][j] + k A[i] - alpha (usum[i] - k TQ[i]).  Dense dv: `dv` here is its per-point sum over the
+// k edges [P][64].  Sparse dv has one non-zero per (i, c), on the
 // edge in slot hitj[i][c]: the kernel also writes G[i][c] = sc dv of that edge and the HitRec of every edge of
 // the point.  The records of a point are assembled in LDS:
 // one 64-bit atomic-or per channel lane builds the masks, then lane j owns edge j.
@@ -729,15 +730,7 @@ __global__ __launch_bounds__(256) void edge_point_bwd_kernel(const float *__rest
         const float A = -sc * (c1 + c2 * rstd * (q - mean));
         float dsum;
         if (DENSE) {
-            float t0 = 0.0f, t1 = 0.0f;
-            const float *dp = dv + (size_t)pt * k * EC + lane;
-            int j = 0;
-            for (; j + 1 < k; j += 2) {
-                t0 += dp[(size_t)j * EC];
-                t1 += dp[(size_t)(j + 1) * EC];
-            }
-            if (j < k) t0 += dp[(size_t)j * EC];
-            dsum = sc * (t0 + t1);
+            dsum = sc * dv[o];  // dv = the per-point sums of dv1 over the k edges (edge_mlp_bwd_kernel)
         } else {
             const float yv = y[o];
             dsum = sc * gy[o] * (yv > 0.0f ? 1.0f : slope);
@@ -800,7 +793,8 @@ int launch_rev_build(const int32_t *idx, int B, int N, int k, int *cnt, int *ind
 
 int launch_edge_bwd_nogather(const float *TP, const float *TQ, int B, int N, int k, const float *stats, const float *cc,
                              float slope, const float *gy, const float *y, const uint8_t *hitj, const float *usum,
-                             const float *dv, const int *rowptr, const int32_t *rev, const int *extra, void *hits,
+                             const float *dv, const float *dvsum, const int *rowptr, const int32_t *rev, const int *extra,
+                             void *hits,
                              float *G, float *dR, float *dD, hipStream_t st)
 {
     const int P = B * N;
@@ -809,10 +803,10 @@ int launch_edge_bwd_nogather(const float *TP, const float *TQ, int B, int N, int
     const int2 *elist = reinterpret_cast<const int2 *>(extra + 2);
     if (dv)
         hipLaunchKernelGGL((edge_point_bwd_kernel<true>), grid, block, 0, st, TQ, N, k, P, stats, cc, slope, gy, y, hitj, usum,
-                           dv, (HitRec *)hits, G, dD);
+                           dvsum, (HitRec *)hits, G, dD);
     else
         hipLaunchKernelGGL((edge_point_bwd_kernel<false>), grid, block, 0, st, TQ, N, k, P, stats, cc, slope, gy, y, hitj, usum,
-                           dv, (HitRec *)hits, G, dD);
+                           nullptr, (HitRec *)hits, G, dD);
     prof_begin(PROF_EDGE_RGATHER, st);
     const dim3 xgrid(1024);  // extra segments: a few thousand at most, about one per wave
     if (dv) {

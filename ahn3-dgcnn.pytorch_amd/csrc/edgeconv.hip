@@ -77,7 +77,7 @@ static FwdWs fwd_ws(const dgcnn_edgeconv_desc *d, void *p)
 }
 
 struct BwdWs {
-    float *cc1, *cc2, *dR, *dD, *wg_partial, *wg_sum, *dv1, *dw2_partial;
+    float *cc1, *cc2, *dR, *dD, *wg_partial, *wg_sum, *dv1, *dvsum, *dw2_partial;
     double *partial, *bn1_partial;
     int *cnt, *indeg, *rowptr, *rev, *extra;  // reverse adjacency of the kNN graph (training mode)
     void *hits;
@@ -105,10 +105,12 @@ static BwdWs bwd_ws(const dgcnn_edgeconv_desc *d, void *p)
     w.G = d->n_stage == 1 ? c.take<float>(P * EC) : nullptr;
     if (d->n_stage == 2) {
         w.dv1 = c.take<float>(P * d->k * EC);
+        w.dvsum = c.take<float>(P * EC);
         w.dw2_partial = c.take<float>((size_t)PART_MAX * EC * EC);
         w.bn1_partial = c.take<double>((size_t)(PART_MAX + PART_FOLD) * 2 * 64);
     } else {
         w.dv1 = nullptr;
+        w.dvsum = nullptr;
         w.dw2_partial = nullptr;
         w.bn1_partial = nullptr;
     }
@@ -218,7 +220,7 @@ extern "C" int dgcnn_edgeconv_bwd(const dgcnn_edgeconv_desc *d, const float *x, 
         launch_bwd_point(gy, s.usel, s.stats1, d->slope, P, E, d->training, w.partial, g->gbn1_w, g->gbn1_b, w.cc1, st);
         if (d->training) {
             if (launch_edge_bwd_nogather(s.TP, s.TQ, d->B, N, k, s.stats1, w.cc1, d->slope, gy, y, s.hitj, s.usum, nullptr,
-                                         w.rowptr, w.rev, w.extra, w.hits, w.G, w.dR, w.dD, st))
+                                         nullptr, w.rowptr, w.rev, w.extra, w.hits, w.G, w.dR, w.dD, st))
                 return 1;
         } else {
             launch_edge_bwd(s.TP, s.TQ, idx, N, k, P, s.stats1, w.cc1, d->slope, d->training, gy, y, nullptr, w.dR, w.dD,
@@ -227,12 +229,12 @@ extern "C" int dgcnn_edgeconv_bwd(const dgcnn_edgeconv_desc *d, const float *x, 
     } else {
         launch_bwd_point(gy, s.usel, s.stats2, d->slope, P, E, d->training, w.partial, g->gbn2_w, g->gbn2_b, w.cc2, st);
         launch_edge_mlp_bwd(s.TP, s.TQ, idx, N, k, P, s.stats1, s.stats2, w.cc2, d->w2, d->slope, d->training, gy, y,
-                            w.dv1, w.dw2_partial, w.bn1_partial, st);
+                            w.dv1, w.dvsum, w.dw2_partial, w.bn1_partial, st);
         launch_sum_partials(w.dw2_partial, mlp_grid(P), EC * EC, g->gw2, st);
         launch_bn_bwd_finalize(w.bn1_partial, mlp_grid(P), E, d->training, g->gbn1_w, g->gbn1_b, w.cc1, st);
         if (d->training) {
             if (launch_edge_bwd_nogather(s.TP, s.TQ, d->B, N, k, s.stats1, w.cc1, d->slope, gy, y, nullptr, s.usum, w.dv1,
-                                         w.rowptr, w.rev, w.extra, nullptr, nullptr, w.dR, w.dD, st))
+                                         w.dvsum, w.rowptr, w.rev, w.extra, nullptr, nullptr, w.dR, w.dD, st))
                 return 1;
         } else {
             launch_edge_bwd(s.TP, s.TQ, idx, N, k, P, s.stats1, w.cc1, d->slope, d->training, gy, y, w.dv1, w.dR, w.dD, st);
