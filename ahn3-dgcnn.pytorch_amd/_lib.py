@@ -59,6 +59,7 @@ SIGNATURES = {
     "dgcnn_bn_lrelu_bwd": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_int, _c_f, _c_vp, _c_vp, _c_vp,
                                     _c_vp, _c_sz, _c_vp]),
     "dgcnn_profile_enable": (_c_int, [_c_int]),
+    "dgcnn_profile_resume": (_c_int, []),
     "dgcnn_profile_regions": (_c_int, []),
     "dgcnn_profile_region_name": (ctypes.c_char_p, [_c_int]),
     "dgcnn_profile_mean_ms": (_c_f, [_c_int]),

@@ -46,7 +46,15 @@ extern "C" int dgcnn_profile_enable(int on)
         g_prof.created = true;
     }
     g_prof.on = on != 0;
-    for (int g = 0; g < PROF_NREGION; ++g) g_prof.r[g].n = 0;
+    if (on)
+        for (int g = 0; g < PROF_NREGION; ++g) g_prof.r[g].n = 0;  // enable(0) keeps the samples
+    return 0;
+}
+
+extern "C" int dgcnn_profile_resume(void)
+{
+    if (!g_prof.created) return 1;
+    g_prof.on = true;  // the samples recorded so far are kept
     return 0;
 }
 

@@ -93,8 +93,10 @@ def cpu_baseline(B, N, k, C, n_stage, steps=4):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--profile-every", type=int, default=5,
+                    help="record the per-kernel HIP events on every n-th timed step (an event record costs GPU time)")
     ap.add_argument("--stages", type=int, default=1, choices=(1, 2),
                     help="1: conv5-shaped block (128->64); 2: conv3+conv4-shaped block (128->64->64)")
     ap.add_argument("--batch", type=int, default=8, help="batch elements per GPU")
@@ -133,19 +135,22 @@ def main():
     bn2 = stages[1][1] if args.stages == 2 else None
     knn_events = []
 
-    def step(timed):
+    def step(sampled):
         sync.zero()
         x_pm.grad = None
-        if timed:
+        if sampled:
+            lib.dgcnn_profile_resume()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         idx = ops.knn_pm(x_pm, k)
-        if timed:
+        if sampled:
             e1.record()
             knn_events.append((e0, e1))
         y = ops.edgeconv_pm(x_pm, idx, stages[0][0].weight, stages[0][1], w2, bn2, training=True, slope=0.2)
         y.backward(cot)
         sync.sync()
+        if sampled:
+            lib.dgcnn_profile_enable(0)
 
     def fence():
         torch.cuda.synchronize()
@@ -153,14 +158,15 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    lib = _lib.load()
     for _ in range(args.warmup):
         step(False)
     fence()
-    lib = _lib.load()
-    lib.dgcnn_profile_enable(1)
+    lib.dgcnn_profile_enable(1)  # reset the sample rings ...
+    lib.dgcnn_profile_enable(0)  # ... recording is switched on for the sampled steps only
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
+    for i in range(args.steps):
+        step(i % max(1, args.profile_every) == 0)
     fence()
     dt = time.perf_counter() - t0
     if dist.is_initialized():
@@ -171,7 +177,6 @@ def main():
     knn_ms = sum(a.elapsed_time(b) for a, b in knn_events) / max(1, len(knn_events))
     regions = {lib.dgcnn_profile_region_name(r).decode(): (float(lib.dgcnn_profile_mean_ms(r)), int(lib.dgcnn_profile_samples(r)))
                for r in range(lib.dgcnn_profile_regions())}
-    lib.dgcnn_profile_enable(0)
     if rank == 0:
         P, E = B * N, B * N * k
         knn_flops = 2.0 * B * N * N * C  # FLOPs_kNN = 2 B N^2 C

@@ -144,8 +144,11 @@ int dgcnn_bn_lrelu_bwd(const float *x, const float *y, const float *gy, const fl
  * (dgcnn_profile_region_name): the fp16 threshold pass, the fp16 filter and the exact refine of dgcnn_knn, the
  * forward gather/reduce pass and the backward reverse gather of dgcnn_edgeconv_*.  enable(1) resets the sample
  * rings; mean_ms(region) returns the mean time of the samples recorded since (call it after the stream has been
- * synchronised; at most 256 samples per region are kept).  No effect on results. */
+ * synchronised; at most 256 samples per region are kept).  enable(0) stops recording and keeps the samples,
+ * resume() continues without resetting them (bench.py samples every few steps: an event record costs a few
+ * microseconds of GPU time).  No effect on results. */
 int dgcnn_profile_enable(int on);
+int dgcnn_profile_resume(void);
 int dgcnn_profile_regions(void);
 const char *dgcnn_profile_region_name(int region);
 float dgcnn_profile_mean_ms(int region);
