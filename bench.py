@@ -29,9 +29,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-# keep rank 0's stdout to the one JSON line: RCCL's version banner is not an error
+# keep rank 0's stdout to the one JSON line: RCCL writes its version banner and its warnings (missing iommu=pt,
+# unreadable topology nodes in a container) to stdout unless told otherwise
 if os.environ.get("NCCL_DEBUG", "VERSION").upper() in ("VERSION", "INFO"):
     os.environ["NCCL_DEBUG"] = "WARN"
+os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
