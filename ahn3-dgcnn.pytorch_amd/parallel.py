@@ -28,6 +28,7 @@ class FlatGradAllReduce:
                 uniq.append(p)
         self.params = uniq
         self.group = group
+        self._avg = None
         if not self.params:
             raise ValueError("no parameters to synchronise")
         dev, dt = self.params[0].device, self.params[0].dtype
@@ -50,6 +51,14 @@ class FlatGradAllReduce:
         """sum over ranks, then divide by the world size (gradient of the mean loss over the global batch)."""
         ws = self.world_size
         if ws > 1:
+            if self._avg is None:
+                self._avg = dist.get_backend(self.group) == "nccl"  # RCCL averages inside the collective
+            if self._avg:
+                try:
+                    dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=self.group)
+                    return self.flat
+                except RuntimeError:  # a build without ncclAvg: sum and scale instead
+                    self._avg = False
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
             self.flat.div_(ws)
         return self.flat
