@@ -476,7 +476,7 @@ __global__ __launch_bounds__(REV_THREADS) void rev_scan_kernel(const int *__rest
 }
 
 // cnt[b][chunk][m] <- first slot of chunk's edges into m; also lists the extra segments of long lists:
-// (point, segment) pairs for segments 1 .. (deg - 1) / REV_SEG, allocated with one atomic per wave
+// (point, segment) pairs for segments 1 .. (deg - 1) / REV_SEG, allocated with one atomic per workgroup
 constexpr int REV_SEG = 128;
 __global__ __launch_bounds__(256) void rev_slots_kernel(const int *__restrict__ rowptr, int N, int chunks, int P,
                                                         int *__restrict__ cnt, int *__restrict__ nextra,
@@ -496,19 +496,29 @@ __global__ __launch_bounds__(256) void rev_slots_kernel(const int *__restrict__ 
             slot += n;
         }
     }
-    // wave-aggregated allocation: inclusive scan of nseg over the lanes, one atomicAdd by the last lane
-    const int lane = threadIdx.x & 63;
+    // workgroup-aggregated allocation (one atomicAdd on the global counter per workgroup: per-wave atomics on one
+    // address cost ~9 us here): inclusive scan of nseg over the lanes, wave totals through LDS
+    __shared__ int wtot[4], wbase[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int incl = nseg;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
         const int t = __shfl_up(incl, o);
         if (lane >= o) incl += t;
     }
-    const int total = __shfl(incl, 63);
-    if (total == 0) return;
-    int base = 0;
-    if (lane == 63) base = atomicAdd(nextra, total);
-    base = __shfl(base, 63) + incl - nseg;
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int t0 = wtot[0], t1 = wtot[1], t2 = wtot[2], t3 = wtot[3];
+        const int total = t0 + t1 + t2 + t3;
+        const int b0 = total ? atomicAdd(nextra, total) : 0;
+        wbase[0] = b0;
+        wbase[1] = b0 + t0;
+        wbase[2] = b0 + t0 + t1;
+        wbase[3] = b0 + t0 + t1 + t2;
+    }
+    __syncthreads();
+    const int base = wbase[wave] + incl - nseg;
     for (int sgm = 0; sgm < nseg; ++sgm) extra[base + sgm] = int2{g, sgm + 1};
 }
 
