@@ -356,11 +356,7 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(const float *__restrict__
                 for (int t = 0; t < 8; ++t)
                     if (j + t < kk) {
                         n[t] = __builtin_amdgcn_readlane(nv, j + t);
-#ifdef EDGE_BWD_ABLATE_GATHER  // timing experiment: no TP gather (results are garbage)
-                        p[t] = q;
-#else
                         p[t] = Pb[(size_t)n[t] * EC];
-#endif
                         if (DENSE) d[t] = dv[((size_t)pt * k + j0 + j + t) * EC + lane];
                     }
 #pragma unroll
@@ -375,11 +371,7 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(const float *__restrict__
                             const float uhat = (u - mean) * rstd;
                             const float du = sc * ((DENSE ? d[t] : 0.0f) - c1 - c2 * uhat);
                             dsum += du;
-#ifdef EDGE_BWD_ABLATE_ATOMICS  // timing experiment: no scatter (results are garbage)
-                            if (du == 123.456f) Rb[(size_t)n[t] * EC] = du;
-#else
                             atomicAdd(Rb + (size_t)n[t] * EC, du);
-#endif
                         }
                     }
             }
@@ -572,13 +564,11 @@ __device__ __forceinline__ void rgather_segment(const float *__restrict__ TQ, co
         // hit and not per (edge, channel)
         u64 hm = 0;
         float4 rec = float4{0.0f, 0.0f, 0.0f, 0.0f};
-#ifndef RG_ABLATE_HITS  // timing experiment: no hit records (results are wrong)
         if (!DENSE && lane < cnt) {
             const HitRec *h = hits + ev;
             hm = h->mask;
             rec = *reinterpret_cast<const float4 *>(h->v);
         }
-#endif
         // 8 rows in flight per wave (16, as two groups, measured slower: most lists are short)
         for (int t = 0; t < cnt; t += 8) {
             float q[8], d[8];

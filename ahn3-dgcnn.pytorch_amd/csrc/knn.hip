@@ -509,9 +509,6 @@ struct Stage16 {
     half8 reg[VPT];
     __device__ __forceinline__ void gload(const half8 *__restrict__ xbatch, int chunk, int tid)
     {
-#ifdef KNN_ABLATE_STAGE_LOADS  // timing experiment: always the same chunk (L1-resident)
-        chunk = 0;
-#endif
 #pragma unroll
         for (int i = 0; i < VPT; ++i) reg[i] = xbatch[(size_t)chunk * VEC_PER_CHUNK + i * KNN_ST_THREADS + tid];
     }
@@ -742,9 +739,6 @@ __global__ __launch_bounds__(64, 2) void knn_kernel(const float *__restrict__ xt
     const float *xxb = xx + (size_t)b * Npad;
 
     auto load_operand = [&](int tile, float(&dst)[CH]) {
-#ifdef KNN_ABLATE_L2  // timing experiment: every operand load hits the same (L1-resident) tile
-        tile = 0;
-#endif
         const vecf *p = reinterpret_cast<const vecf *>(xtb + (size_t)tile * 32 * CP) + lane;
 #pragma unroll
         for (int g = 0; g < G; ++g) {
@@ -779,10 +773,6 @@ __global__ __launch_bounds__(64, 2) void knn_kernel(const float *__restrict__ xt
         // pass 1 for accumulator register r: append where the row's buffer has room
         auto epi = [&](auto rtag) {
             constexpr int r = decltype(rtag)::value;
-#ifdef KNN_ABLATE_EPILOGUE  // timing experiment: MFMA stream only (results are garbage)
-            asm volatile("" ::"v"(acc[r]));
-            return;
-#endif
             const float pd = __builtin_fmaf(2.0f, acc[r], -xxc) - xxq[r];
             const bool pass = pd > taur[r];
             const u64 m = __ballot(pass);
@@ -887,23 +877,11 @@ __global__ __launch_bounds__(64, 2) void knn_kernel(const float *__restrict__ xt
             const bool more = t + 2 < ntiles;
             const float xcurA = xA, xcurB = xB;
             const int tA = more ? t + 2 : t, tB = more ? t + 3 : t + 1;
-#ifdef KNN_ABLATE_LOADS  // timing experiment: no operand traffic in the stream
-            if (t < 0) {
-#endif
             load_operand(tA, bA);
             xA = xxb[tA * 32 + j32];
-#ifdef KNN_ABLATE_LOADS
-            }
-#endif
             fused(std::true_type{}, bB, accB, accA, xcurA, t * 32 + j32);  // MFMA tile t+1 | select tile t
-#ifdef KNN_ABLATE_LOADS
-            if (t < 0) {
-#endif
             load_operand(tB, bB);
             xB = xxb[tB * 32 + j32];
-#ifdef KNN_ABLATE_LOADS
-            }
-#endif
             if (more)
                 fused(std::true_type{}, bA, accA, accB, xcurB, (t + 1) * 32 + j32);  // MFMA tile t+2 | select tile t+1
             else
@@ -1028,29 +1006,14 @@ __global__ __launch_bounds__(KNN_ST_THREADS) void knn_filter16_kernel(const half
         for (int r = 0; r < 16; ++r) c0[r] = c1[r] = 0.0f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-#if defined(KNN_ABLATE_LDSREAD)  // timing experiment
-            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks], a[(ks + 1) % KS], c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks], a[(ks + 2) % KS], c1, 0, 0, 0);
-#elif defined(KNN_ABLATE_MFMA)  // timing experiment
-            {
-                const half8 v0 = buf[(t0 * KS + ks) * 64 + lane], v1 = buf[((t0 + 1) * KS + ks) * 64 + lane];
-                c0[ks] += (float)v0[0];
-                c1[ks] += (float)v1[0];
-            }
-#else
             c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks], buf[(t0 * KS + ks) * 64 + lane], c0, 0, 0, 0);
             c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks], buf[((t0 + 1) * KS + ks) * 64 + lane], c1, 0, 0, 0);
-#endif
         }
     };
     // t > thr  <=>  sign(thr - t): the 16 sign bits of a lane are packed with one v_alignbit each (bit r =
     // accumulator register r): 8 v_pk_fma + 8 v_pk_add + 16 v_alignbit per tile, no per-register ballot/branch
     auto signs = [&](const f32x16 &acc, float y) {
         unsigned bits = 0u;
-#ifdef KNN_ABLATE_SIGNS  // timing experiment
-        asm volatile("" : "+v"(bits) : "v"(acc));
-        return bits;
-#endif
         // (plain fp32 fma / sub instead of the packed forms: 101 against 104 us -- not worth the doubled issue slots)
 #pragma unroll
         for (int i = 7; i >= 0; --i) {
@@ -1065,10 +1028,6 @@ __global__ __launch_bounds__(KNN_ST_THREADS) void knn_filter16_kernel(const half
     // four tiles handled in one iteration are extracted together (bit 16 t + r = tile t, register r; tile t holds
     // candidates cand + 32 t): ~24 survivors over 64 lanes need ~3 rounds, against ~2.3 per tile one by one.
     auto rounds = [&](u64 bits, int cand) {
-#ifdef KNN_ABLATE_ROUNDS  // timing experiment: no survivor extraction (results are garbage)
-        asm volatile("" ::"v"(bits));
-        return;
-#endif
         u64 m = __ballot(bits != 0ull);
         while (m != 0) {
             if (qn > KNN_QCAP - 64) {  // room for a full round of survivors (loose thresholds only)
@@ -1121,9 +1080,7 @@ __global__ __launch_bounds__(KNN_ST_THREADS) void knn_filter16_kernel(const half
         st.swrite(sbuf[(c - c0 + 1) & 1], tid);
 #pragma unroll
         for (int tt = 0; tt < KNN_ST_TILES; ++tt) ycur[tt] = ynext[tt];
-#ifndef KNN_ABLATE_BARRIER  // timing experiment: racy staging
         __syncthreads();
-#endif
     }
     {
         const int cand0 = c1 * KNN_ST_TILES * 32 + j32;
