@@ -224,3 +224,16 @@ def test_head_bn_lrelu_rows(P, C, train, device):
     if train:
         np.testing.assert_allclose(bn_d.running_mean.cpu().numpy(), bn.running_mean.numpy(), rtol=1e-5, atol=1e-6)
         np.testing.assert_allclose(bn_d.running_var.cpu().numpy(), bn.running_var.numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_step_is_graph_capturable(device):
+    """every C-ABI call only enqueues work on the current stream: a whole kNN + block forward + backward step can be
+    captured in a hipGraph and replayed.  Runs in a child process: a failed capture can
+    take the interpreter down, which must not take the rest of the suite with it."""
+    import os
+    import subprocess
+    import sys
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "graph_capture_child.py")
+    r = subprocess.run([sys.executable, child], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, "child failed (%d)\n%s\n%s" % (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+    assert "replay matches eager" in r.stdout
