@@ -1094,6 +1094,130 @@ __global__ __launch_bounds__(KNN_ST_THREADS) void knn_filter16_kernel(const half
     }
 }
 
+// The same filter for small C (CP = 4, 8: the raw coordinates of the first block), where fp16 is useless (the
+// rounding of coordinates of tens of metres exceeds neighbour distances): the distances are the exact fp32
+// MFMA values of knn_kernel, the threshold is tau0 of the fp32 pre-pass, and the operands (CP / 2 floats per lane
+// and tile) come straight from L2.  The survivors go through knn_refine_kernel like those of the fp16 filter;
+// knn_kernel did the selection inside the all-pairs loop and spent most of its time in the per-survivor path.
+template <int CP>
+__global__ __launch_bounds__(256) void knn_filter32_kernel(const float *__restrict__ xt, const float *__restrict__ xx,
+                                                           const float *__restrict__ tau0, int B, int Npad, int parts,
+                                                           unsigned *__restrict__ lists, int *__restrict__ lcount,
+                                                           int *__restrict__ rbflag)
+{
+    constexpr int CH = CP / 2;  // MFMA steps per tile = floats per lane and tile
+    typedef float vecf __attribute__((ext_vector_type(CH)));
+    __shared__ unsigned queues[4][KNN_QCAP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, j32 = lane & 31;
+    const int b = blockIdx.x % B, part = (blockIdx.x / B) % parts;
+    const int rb = (blockIdx.x / B / parts) * 4 + wave;  // this wave's row block
+    const int ntiles = Npad / 32, nchunks = ntiles / KNN_ST_TILES;
+    if (rb >= ntiles) return;
+    const int c0 = part * nchunks / parts, c1 = (part + 1) * nchunks / parts;
+    const int wid = b * ntiles + rb;
+    const int listcap = KNN_LISTCAP / parts;
+    const int q0 = rb * 32;
+    const vecf *xtb = reinterpret_cast<const vecf *>(xt + (size_t)b * Npad * CP);
+    const float *yb = xx + (size_t)b * Npad;
+    unsigned *list = lists + (size_t)wid * KNN_LISTCAP + part * listcap;
+    unsigned *queue = queues[wave];
+
+    const vecf a = xtb[(size_t)rb * 64 + lane];
+    // filter threshold on t = 2 dot - xx_l:  pd = t - xx_i > tau0  <=  t > tau0 + xx_i, lowered by the rounding of
+    // this very sum (a superset passes; the refine recomputes pd exactly)
+    f32x2 thrp[8];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = q0 + mfma32_row(r, h);
+        const float tau = tau0[(size_t)b * Npad + row], yy = yb[row];
+        const float v = tau + yy;
+        const float thr = v - (__builtin_fabsf(v) + __builtin_fabsf(tau) + yy) * 2.4e-7f;
+        thrp[r >> 1][r & 1] = thr != thr ? __builtin_inff() : thr;  // padding rows (yy = +inf): nothing passes
+    }
+
+    int qhead = 0, qn = 0, lpos = 0;
+    bool overflow = false;
+    auto flush = [&](int n) {  // move the oldest n (<= 64) staged entries to the list
+        if (lpos + n > listcap) {
+            overflow = true;
+        } else if (lane < n) {
+            list[lpos + lane] = queue[(qhead + lane) & (KNN_QCAP - 1)];
+        }
+        lpos += n;
+        qhead = (qhead + n) & (KNN_QCAP - 1);
+        qn -= n;
+    };
+    auto signs = [&](const f32x16 &acc, float y) {
+        unsigned bits = 0u;
+#pragma unroll
+        for (int i = 7; i >= 0; --i) {
+            const f32x2 t = __builtin_elementwise_fma(f32x2{acc[2 * i], acc[2 * i + 1]}, f32x2{2.0f, 2.0f}, f32x2{-y, -y});
+            const f32x2 d = thrp[i] - t;
+            bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(d[1]), 31);
+            bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(d[0]), 31);
+        }
+        return bits;
+    };
+    auto rounds = [&](u64 bits, int cand) {  // as in knn_filter16_kernel: bit 16 t + r = tile t, register r
+        u64 m = __ballot(bits != 0ull);
+        while (m != 0) {
+            if (qn > KNN_QCAP - 64) {
+                while (qn >= 64) flush(64);
+            }
+            if (bits != 0ull) {
+                const int pos = __builtin_ctzll(bits);
+                const int r = pos & 15;
+                const int off = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+                queue[(qhead + qn + off) & (KNN_QCAP - 1)] =
+                    ((unsigned)((r & 3) + 8 * (r >> 2) + 4 * h) << 27) | (unsigned)(cand + (pos >> 4) * 32);
+                bits &= bits - 1ull;
+            }
+            qn += __popcll(m);
+            m = __ballot(bits != 0ull);
+        }
+        if (qn >= 64) flush(64);
+    };
+
+    // four candidate tiles per iteration, the next four tiles' operands and norms in flight
+    vecf bn[KNN_ST_TILES];
+    float yn[KNN_ST_TILES];
+#pragma unroll
+    for (int tt = 0; tt < KNN_ST_TILES; ++tt) {
+        bn[tt] = xtb[(size_t)(c0 * KNN_ST_TILES + tt) * 64 + lane];
+        yn[tt] = yb[(c0 * KNN_ST_TILES + tt) * 32 + j32];
+    }
+    for (int c = c0; c < c1; ++c) {
+        vecf bc[KNN_ST_TILES];
+        float yc[KNN_ST_TILES];
+        const int cn = c + 1 < c1 ? c + 1 : c;  // clamped prefetch: no branch around the loads
+#pragma unroll
+        for (int tt = 0; tt < KNN_ST_TILES; ++tt) {
+            bc[tt] = bn[tt];
+            yc[tt] = yn[tt];
+            bn[tt] = xtb[(size_t)(cn * KNN_ST_TILES + tt) * 64 + lane];
+            yn[tt] = yb[(cn * KNN_ST_TILES + tt) * 32 + j32];
+        }
+        f32x16 acc[KNN_ST_TILES];
+#pragma unroll
+        for (int tt = 0; tt < KNN_ST_TILES; ++tt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tt][r] = 0.0f;
+#pragma unroll
+        for (int st = 0; st < CH; ++st)
+#pragma unroll
+            for (int tt = 0; tt < KNN_ST_TILES; ++tt)
+                acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[st], bc[tt][st], acc[tt], 0, 0, 0);
+        const unsigned b0 = signs(acc[0], yc[0]), b1 = signs(acc[1], yc[1]);
+        const unsigned b2 = signs(acc[2], yc[2]), b3 = signs(acc[3], yc[3]);
+        rounds(((u64)(b2 | (b3 << 16)) << 32) | (b0 | (b1 << 16)), c * KNN_ST_TILES * 32 + j32);
+    }
+    while (qn > 0) flush(qn < 64 ? qn : 64);
+    if (lane == 0) {
+        lcount[2 * wid + part] = overflow ? 0 : lpos;
+        if (overflow) rbflag[wid] = 1;
+    }
+}
+
 // One wave = one 32-row block: exact pd of every listed survivor, selection, output.
 template <int CP, int CAP>
 __global__ __launch_bounds__(64) void knn_refine_kernel(const float *__restrict__ x, const float *__restrict__ xx,
@@ -1344,7 +1468,7 @@ static KnnWs knn_ws(int B, int C, int N, void *base)
     w.bmax = (unsigned *)take((size_t)B * 2 * (npad / 32) * sizeof(unsigned));
     w.rbflag = (int *)take((size_t)B * (npad / 32) * sizeof(int));
     w.exch = (unsigned *)take(cp >= 16 ? (size_t)B * npad * 2 * 64 * sizeof(unsigned) : 0);
-    w.lists = (unsigned *)take(cp >= 16 ? (size_t)B * (npad / 32) * KNN_LISTCAP * sizeof(unsigned) : 0);
+    w.lists = (unsigned *)take((size_t)B * (npad / 32) * KNN_LISTCAP * sizeof(unsigned));
     w.bytes = off;
     return w;
 }
@@ -1447,6 +1571,36 @@ extern "C" int dgcnn_knn(const float *x, int B, int N, int C, int k, int32_t *id
         }
         DG_CHECK_LAUNCH("knn_bound_kernel");
         tau0 = w.tau0;
+    }
+    static const bool f32filter_off = getenv("DGCNN_KNN_NO_F32_FILTER") != nullptr;
+    if (prepass && CP < 16 && !f32filter_off) {
+        // small C: exact fp32 filter + exact refine (see knn_filter32_kernel); knn_kernel below only runs flagged blocks
+        if (hipMemsetAsync(w.rbflag, 0, (size_t)B * (Npad / 32) * sizeof(int), st) != hipSuccess)
+            DG_FAIL("dgcnn_knn: memset failed");
+        rbflag = w.rbflag;
+        const dim3 fgrid(B * parts * ceil_div(Npad / 32, 4)), rgrid(B * (Npad / 32));
+        prof_begin(PROF_KNN_FILTER, st);
+        if (CP == 4)
+            hipLaunchKernelGGL((knn_filter32_kernel<4>), fgrid, dim3(256), 0, st, xt, xx, w.tau0, B, Npad, parts, w.lists,
+                               w.lcount, w.rbflag);
+        else
+            hipLaunchKernelGGL((knn_filter32_kernel<8>), fgrid, dim3(256), 0, st, xt, xx, w.tau0, B, Npad, parts, w.lists,
+                               w.lcount, w.rbflag);
+        prof_end(PROF_KNN_FILTER, st);
+        prof_begin(PROF_KNN_REFINE, st);
+#define DG_REFINE(CP_, CAP_)                                                                                          \
+    hipLaunchKernelGGL((knn_refine_kernel<CP_, CAP_>), rgrid, dim3(64), 0, st, x, w.xx, w.lists, w.lcount, w.rbflag, B, \
+                       N, C, Npad, k, parts, idx)
+        if (CP == 4) {
+            if (cap == 64) DG_REFINE(4, 64);
+            else DG_REFINE(4, 128);
+        } else {
+            if (cap == 64) DG_REFINE(8, 64);
+            else DG_REFINE(8, 128);
+        }
+#undef DG_REFINE
+        prof_end(PROF_KNN_REFINE, st);
+        DG_CHECK_LAUNCH("knn_filter32_kernel / knn_refine_kernel");
     }
     if (f16path) {
         // fp16 filter + exact refine; the exact fp32 kernel below then only runs the row blocks these
