@@ -58,6 +58,11 @@ SIGNATURES = {
                                     _c_vp, _c_vp, _c_vp, _c_sz, _c_vp]),
     "dgcnn_bn_lrelu_bwd": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_int, _c_f, _c_vp, _c_vp, _c_vp,
                                     _c_vp, _c_sz, _c_vp]),
+    "dgcnn_bn_lrelu_max_workspace_bytes": (_c_sz, [_c_int, _c_int, _c_int]),
+    "dgcnn_bn_lrelu_max_fwd": (_c_int, [_c_vp, _c_int, _c_int, _c_int, ctypes.POINTER(BnParams), _c_int, _c_f, _c_f, _c_f,
+                                        _c_vp, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp]),
+    "dgcnn_bn_lrelu_max_bwd": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_int, _c_int, _c_f, _c_vp, _c_vp,
+                                        _c_vp, _c_vp, _c_sz, _c_vp]),
     "dgcnn_profile_enable": (_c_int, [_c_int]),
     "dgcnn_profile_resume": (_c_int, []),
     "dgcnn_profile_regions": (_c_int, []),

@@ -162,6 +162,118 @@ __global__ void bn_lrelu_bwd_apply_kernel(const float *__restrict__ x, const flo
     reinterpret_cast<float4 *>(gx)[t] = o;
 }
 
+// ---- BatchNorm1d + LeakyReLU + max over the N points of a batch element (conv6 -> bn6 -> max, model.py:172-175) ----
+// BN-affine + LeakyReLU is monotone per column (and so is every fp32 rounding in it), so the maximum of the
+// activation is the activation of the column's extreme pre-activation (maximum if sc >= 0, minimum otherwise): the
+// activated [P][C] tensor (229 MB at P = 56 000, C = 1024) is never written.  keys[b][c] = ordered(extreme) << 32 |
+// ~n (the first point attaining it wins), combined over the row slices with 64-bit atomic max; zero-filled first.
+typedef unsigned long long hkey;
+
+__device__ __forceinline__ unsigned head_ordered(float f)
+{
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float head_unordered(unsigned o)
+{
+    return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+}
+
+__global__ __launch_bounds__(256) void colmax_kernel(const float *__restrict__ x, const float *__restrict__ stats, int N,
+                                                     int C, hkey *__restrict__ keys)
+{
+    __shared__ hkey red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane, b = blockIdx.z;
+    const int r0 = blockIdx.y * HEAD_ROWS_PER_BLOCK;
+    const int r1 = r0 + HEAD_ROWS_PER_BLOCK < N ? r0 + HEAD_ROWS_PER_BLOCK : N;
+    hkey best = 0;
+    if (c < C) {
+        const unsigned flip = stats[2 * (size_t)C + c] < 0.0f ? 0x80000000u : 0u;  // sc < 0: track the minimum
+        const float *xb = x + (size_t)b * N * C + c;
+        for (int r = r0 + wave; r < r1; r += 4) {
+            const unsigned o = head_ordered(__uint_as_float(__float_as_uint(xb[(size_t)r * C]) ^ flip));
+            const hkey k = ((hkey)o << 32) | (hkey)(0xffffffffu - (unsigned)r);
+            best = k > best ? k : best;
+        }
+    }
+    red[wave][lane] = best;
+    __syncthreads();
+    if (wave == 0 && c < C) {
+        hkey k0 = red[0][lane], k1 = red[1][lane], k2 = red[2][lane], k3 = red[3][lane];
+        k0 = k0 > k1 ? k0 : k1;
+        k2 = k2 > k3 ? k2 : k3;
+        k0 = k0 > k2 ? k0 : k2;
+        atomicMax(keys + (size_t)b * C + c, k0);
+    }
+}
+
+// g[b][c] = LeakyReLU(sc ext + sh), arg[b][c] = the point that supplied the extreme
+__global__ void colmax_finish_kernel(const hkey *__restrict__ keys, const float *__restrict__ stats, int B, int C,
+                                     float slope, float *__restrict__ g, int32_t *__restrict__ arg)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * C) return;
+    const int c = t % C;
+    const float sc = stats[2 * (size_t)C + c], sh = stats[3 * (size_t)C + c];
+    const unsigned flip = sc < 0.0f ? 0x80000000u : 0u;
+    const hkey k = keys[t];
+    const float ext = __uint_as_float(__float_as_uint(head_unordered((unsigned)(k >> 32))) ^ flip);
+    g[t] = lrelu(__builtin_fmaf(ext, sc, sh), slope);
+    arg[t] = (int32_t)(0xffffffffu - (unsigned)k);
+}
+
+// backward sums over the B winners of a column: gbias = sum dv, gweight = sum dv xhat, cc = (c1, c2) = the means over
+// all P rows (training) or zero (eval); dvb[b][c] = dv of the winner = gg * LeakyReLU'(v)
+__global__ void colmax_bwd_sums_kernel(const float *__restrict__ x, const float *__restrict__ gg,
+                                       const int32_t *__restrict__ arg, const float *__restrict__ stats, int B, int N,
+                                       int C, int training, float slope, float *__restrict__ gweight,
+                                       float *__restrict__ gbias, float *__restrict__ cc, float *__restrict__ dvb)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float mean = stats[c], rstd = stats[(size_t)C + c], sc = stats[2 * (size_t)C + c], sh = stats[3 * (size_t)C + c];
+    double sb = 0.0, sg = 0.0;
+    for (int b = 0; b < B; ++b) {
+        const float xv = x[((size_t)b * N + arg[(size_t)b * C + c]) * C + c];
+        const float v = __builtin_fmaf(xv, sc, sh);
+        const float dv = gg[(size_t)b * C + c] * (v > 0.0f ? 1.0f : slope);
+        dvb[(size_t)b * C + c] = dv;
+        sb += (double)dv;
+        sg += (double)dv * (double)((xv - mean) * rstd);
+    }
+    gbias[c] = (float)sb;
+    gweight[c] = (float)sg;
+    const double P = (double)B * N;
+    cc[c] = training ? (float)(sb / P) : 0.0f;
+    cc[C + c] = training ? (float)(sg / P) : 0.0f;
+}
+
+// gx[p][c] = sc (dv[p][c] - c1 - c2 xhat), dv non-zero only in the winner's row; C is a multiple of 4
+__global__ void colmax_bwd_apply_kernel(const float *__restrict__ x, const int32_t *__restrict__ arg,
+                                        const float *__restrict__ stats, const float *__restrict__ cc,
+                                        const float *__restrict__ dvb, int N, int C, size_t n4, float *__restrict__ gx)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n4) return;
+    const size_t e = t * 4;
+    const int c = (int)(e % C);
+    const size_t p = e / C;
+    const int b = (int)(p / N), n = (int)(p - (size_t)b * N);
+    const float4 xv = reinterpret_cast<const float4 *>(x)[t];
+    const float4 mean = *reinterpret_cast<const float4 *>(stats + c), rstd = *reinterpret_cast<const float4 *>(stats + (size_t)C + c);
+    const float4 sc = *reinterpret_cast<const float4 *>(stats + 2 * (size_t)C + c);
+    const float4 c1 = *reinterpret_cast<const float4 *>(cc + c), c2 = *reinterpret_cast<const float4 *>(cc + C + c);
+    const int4 a = *reinterpret_cast<const int4 *>(arg + (size_t)b * C + c);
+    const float4 dv = *reinterpret_cast<const float4 *>(dvb + (size_t)b * C + c);
+    float4 o;
+    o.x = sc.x * ((a.x == n ? dv.x : 0.0f) - c1.x - c2.x * ((xv.x - mean.x) * rstd.x));
+    o.y = sc.y * ((a.y == n ? dv.y : 0.0f) - c1.y - c2.y * ((xv.y - mean.y) * rstd.y));
+    o.z = sc.z * ((a.z == n ? dv.z : 0.0f) - c1.z - c2.z * ((xv.z - mean.z) * rstd.z));
+    o.w = sc.w * ((a.w == n ? dv.w : 0.0f) - c1.w - c2.w * ((xv.w - mean.w) * rstd.w));
+    reinterpret_cast<float4 *>(gx)[t] = o;
+}
+
 static int head_chunks(int P) { return ceil_div(P, HEAD_ROWS_PER_BLOCK); }
 
 }  // namespace dgcnn
@@ -215,5 +327,59 @@ extern "C" int dgcnn_bn_lrelu_bwd(const float *x, const float *y, const float *g
     hipLaunchKernelGGL(bn_lrelu_bwd_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, x, y, gy, stats,
                        cc, C, slope, n4, gx);
     DG_CHECK_LAUNCH("dgcnn_bn_lrelu_bwd");
+    return 0;
+}
+
+extern "C" size_t dgcnn_bn_lrelu_max_workspace_bytes(int B, int N, int C)
+{
+    if (B <= 0 || N <= 0 || C <= 0) return 0;
+    return dgcnn_bn_lrelu_workspace_bytes(B * N, C) + align_up((size_t)B * C * sizeof(hkey), 256) +
+           align_up((size_t)B * C * sizeof(float), 256);
+}
+
+extern "C" int dgcnn_bn_lrelu_max_fwd(const float *x, int B, int N, int C, const dgcnn_bn_params *bn, int training,
+                                      float eps, float momentum, float slope, float *g, int32_t *arg, float *stats,
+                                      void *workspace, size_t workspace_bytes, void *stream)
+{
+    DG_REQUIRE(x && bn && g && arg && stats && workspace, "dgcnn_bn_lrelu_max_fwd: null pointer");
+    DG_REQUIRE(B > 0 && N > 0 && C > 0 && (C & 3) == 0, "dgcnn_bn_lrelu_max_fwd: bad shape B=%d N=%d C=%d", B, N, C);
+    DG_REQUIRE((size_t)B * N < ((size_t)1 << 31), "dgcnn_bn_lrelu_max_fwd: more than 2^31 rows");
+    DG_REQUIRE(bn->weight && bn->bias, "dgcnn_bn_lrelu_max_fwd: BatchNorm parameters missing");
+    DG_REQUIRE(training || (bn->running_mean && bn->running_var), "dgcnn_bn_lrelu_max_fwd: eval mode needs running statistics");
+    DG_REQUIRE(workspace_bytes >= dgcnn_bn_lrelu_max_workspace_bytes(B, N, C), "dgcnn_bn_lrelu_max_fwd: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int P = B * N;
+    double *partial = (double *)workspace;
+    hkey *keys = (hkey *)((char *)workspace + dgcnn_bn_lrelu_workspace_bytes(P, C));
+    const int nchunk = head_chunks(P);
+    if (training)
+        hipLaunchKernelGGL(colstats_kernel, dim3(ceil_div(C, 64), nchunk), dim3(256), 0, st, x, P, C, partial);
+    hipLaunchKernelGGL(colstats_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, partial, nchunk, P, C, training,
+                       bn->weight, bn->bias, bn->running_mean, bn->running_var, eps, momentum, stats);
+    if (hipMemsetAsync(keys, 0, (size_t)B * C * sizeof(hkey), st) != hipSuccess) DG_FAIL("dgcnn_bn_lrelu_max_fwd: memset failed");
+    hipLaunchKernelGGL(colmax_kernel, dim3(ceil_div(C, 64), head_chunks(N), B), dim3(256), 0, st, x, stats, N, C, keys);
+    hipLaunchKernelGGL(colmax_finish_kernel, dim3(ceil_div(B * C, 256)), dim3(256), 0, st, keys, stats, B, C, slope, g, arg);
+    DG_CHECK_LAUNCH("dgcnn_bn_lrelu_max_fwd");
+    return 0;
+}
+
+extern "C" int dgcnn_bn_lrelu_max_bwd(const float *x, const float *gg, const int32_t *arg, const float *stats, int B, int N,
+                                      int C, int training, float slope, float *gx, float *gweight, float *gbias,
+                                      void *workspace, size_t workspace_bytes, void *stream)
+{
+    DG_REQUIRE(x && gg && arg && stats && gx && gweight && gbias && workspace, "dgcnn_bn_lrelu_max_bwd: null pointer");
+    DG_REQUIRE(B > 0 && N > 0 && C > 0 && (C & 3) == 0, "dgcnn_bn_lrelu_max_bwd: bad shape B=%d N=%d C=%d", B, N, C);
+    DG_REQUIRE(workspace_bytes >= dgcnn_bn_lrelu_max_workspace_bytes(B, N, C), "dgcnn_bn_lrelu_max_bwd: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int P = B * N;
+    char *base = (char *)workspace;
+    float *cc = (float *)base;  // the statistics partials are not needed here: c1, c2 take their place
+    float *dvb = (float *)(base + dgcnn_bn_lrelu_workspace_bytes(P, C) + align_up((size_t)B * C * sizeof(hkey), 256));
+    hipLaunchKernelGGL(colmax_bwd_sums_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, x, gg, arg, stats, B, N, C, training,
+                       slope, gweight, gbias, cc, dvb);
+    const size_t n4 = (size_t)P * C / 4;
+    hipLaunchKernelGGL(colmax_bwd_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, x, arg, stats, cc, dvb,
+                       N, C, n4, gx);
+    DG_CHECK_LAUNCH("dgcnn_bn_lrelu_max_bwd");
     return 0;
 }

@@ -135,12 +135,15 @@ class DGCNN(nn.Module):
             if depth == 4:
                 out = ops.from_point_major_autograd(cat)
             else:
-                z = self._head_stage(cat.reshape(P, 192), 6)          # [P, emb]      (model.py:172)
-                emb = z.shape[1]
+                emb = self.conv6[0].weight.shape[0]
                 if depth == 5:
+                    z = self._head_stage(cat.reshape(P, 192), 6)      # [P, emb]      (model.py:172)
                     out = ops.from_point_major_autograd(z.view(B, N, emb))
                 else:
-                    g = z.view(B, N, emb).max(dim=1, keepdim=True)[0]  # [B, 1, emb]  (model.py:175)
+                    # conv6 -> bn6 -> LeakyReLU -> max over the points (model.py:172-175): the activated [P, emb]
+                    # tensor is never written (BN + LeakyReLU is monotone per column, see dgcnn_bn_lrelu_max_fwd)
+                    u6 = F.linear(cat.reshape(P, 192), self.conv6[0].weight.squeeze(-1))
+                    g = ops.bn_lrelu_max_rows(u6, self.bn6, B, N, self.training, NEG_SLOPE).view(B, 1, emb)
                     if depth == 6:
                         out = g.transpose(1, 2).contiguous()
                     else:

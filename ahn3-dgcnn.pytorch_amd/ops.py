@@ -262,6 +262,64 @@ def bn_lrelu_rows(x, bn, training, slope=0.2):
     return y
 
 
+class _BNLReLUMax(torch.autograd.Function):
+    """max over the N points of LeakyReLU(BatchNorm1d(x)) for point-major rows [B*N, C] (conv6 -> bn6 -> max of the
+    reference, model.py:172-175) without materialising the activated tensor."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, rmean, rvar, B, N, training, eps, momentum, slope):
+        P, C = x.shape
+        lib = _lib.load()
+        dev = x.device
+        wc, bc = weight.detach().contiguous(), bias.detach().contiguous()
+        bn = _bn_struct(wc, bc, rmean, rvar)
+        g = torch.empty((B, C), dtype=torch.float32, device=dev)
+        arg = torch.empty((B, C), dtype=torch.int32, device=dev)
+        stats = torch.empty((4, C), dtype=torch.float32, device=dev)
+        ws_bytes = lib.dgcnn_bn_lrelu_max_workspace_bytes(B, N, C)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        _lib.check(lib.dgcnn_bn_lrelu_max_fwd(_lib.ptr(x), B, N, C, ctypes.byref(bn), 1 if training else 0, eps, momentum,
+                                              slope, _lib.ptr(g), _lib.ptr(arg), _lib.ptr(stats), _lib.ptr(ws), ws_bytes,
+                                              _lib.stream_ptr(dev)), "dgcnn_bn_lrelu_max_fwd")
+        ctx.save_for_backward(x, arg, stats)
+        ctx.cfg = (B, N, training, slope)
+        ctx.mark_non_differentiable(arg)
+        return g, arg
+
+    @staticmethod
+    def backward(ctx, gg, _garg):
+        x, arg, stats = ctx.saved_tensors
+        B, N, training, slope = ctx.cfg
+        P, C = x.shape
+        lib = _lib.load()
+        dev = x.device
+        gg = gg.contiguous()
+        gx = torch.empty_like(x)
+        gw = torch.empty((C,), dtype=torch.float32, device=dev)
+        gb = torch.empty((C,), dtype=torch.float32, device=dev)
+        ws_bytes = lib.dgcnn_bn_lrelu_max_workspace_bytes(B, N, C)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        _lib.check(lib.dgcnn_bn_lrelu_max_bwd(_lib.ptr(x), _lib.ptr(gg), _lib.ptr(arg), _lib.ptr(stats), B, N, C,
+                                              1 if training else 0, slope, _lib.ptr(gx), _lib.ptr(gw), _lib.ptr(gb),
+                                              _lib.ptr(ws), ws_bytes, _lib.stream_ptr(dev)), "dgcnn_bn_lrelu_max_bwd")
+        return gx, gw, gb, None, None, None, None, None, None, None, None
+
+
+def bn_lrelu_max_rows(x, bn, B, N, training, slope=0.2):
+    """g[b] = max over the N rows of batch element b of LeakyReLU(BatchNorm1d(x)); x point-major rows [B*N, C] -> [B, C]
+    (`bn` is the nn.BatchNorm1d module; running statistics updated in place when training)."""
+    x = _f32c(x, "x")
+    if x.shape[0] != B * N:
+        raise ValueError("x must have B*N rows")
+    use_batch_stats = training or bn.running_mean is None
+    momentum = bn.momentum if bn.momentum is not None else 0.1
+    g, _ = _BNLReLUMax.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, int(B), int(N),
+                             bool(use_batch_stats), float(bn.eps), float(momentum), float(slope))
+    if training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    return g
+
+
 # ------------------------------------------------------------------------------------------------
 class _ToPointMajor(torch.autograd.Function):
     @staticmethod

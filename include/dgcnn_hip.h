@@ -139,6 +139,18 @@ int dgcnn_bn_lrelu_bwd(const float *x, const float *y, const float *gy, const fl
                        int training, float slope, float *gx, float *gweight, float *gbias, void *workspace,
                        size_t workspace_bytes, void *stream);
 
+/* The same BatchNorm1d + LeakyReLU followed by the maximum over the N points of each batch element: conv6 -> bn6 ->
+ * LeakyReLU -> max (model.py:172-175) without writing the activated [B*N][C] tensor.  x rows [B*N][C] (point-major,
+ * batch element b = rows b*N .. b*N+N-1), g [B][C], arg [B][C] = the winning point of every (b, column) (first
+ * point attaining the extreme), stats as above.  The backward takes gg = dL/dg [B][C] and returns dL/dx dense. */
+size_t dgcnn_bn_lrelu_max_workspace_bytes(int B, int N, int C);
+int dgcnn_bn_lrelu_max_fwd(const float *x, int B, int N, int C, const dgcnn_bn_params *bn, int training, float eps,
+                           float momentum, float slope, float *g, int32_t *arg, float *stats, void *workspace,
+                           size_t workspace_bytes, void *stream);
+int dgcnn_bn_lrelu_max_bwd(const float *x, const float *gg, const int32_t *arg, const float *stats, int B, int N, int C,
+                           int training, float slope, float *gx, float *gweight, float *gbias, void *workspace,
+                           size_t workspace_bytes, void *stream);
+
 /* ---- measurement hook (bench.py) ----------------------------------------------------------------------
  * HIP events around the large kernels of the path, recorded on the stream each kernel is launched on.  Regions
  * (dgcnn_profile_region_name): the fp16 threshold pass, the fp16 filter and the exact refine of dgcnn_knn, the

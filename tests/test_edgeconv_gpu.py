@@ -226,6 +226,37 @@ def test_head_bn_lrelu_rows(P, C, train, device):
         np.testing.assert_allclose(bn_d.running_var.cpu().numpy(), bn.running_var.numpy(), rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("train", [True, False])
+@pytest.mark.parametrize("B,N,C", [(3, 700, 64), (2, 1030, 256), (1, 130, 1024)])
+def test_head_bn_lrelu_max_rows(B, N, C, train, device):
+    # conv6 -> bn6 -> LeakyReLU -> max over the points (model.py:172-175) fused: vs PyTorch-CPU on the same rows
+    from ahn3_dgcnn_pytorch_amd import ops
+    import copy
+    g = torch.Generator().manual_seed(B * N + C)
+    x = torch.randn(B * N, C, generator=g) * 2.0 + 3.0
+    R = cotangent((B, C), tag="headmax")
+    bn = torch.nn.BatchNorm1d(C)
+    bn.load_state_dict({n: fill_tensor("head." + n, v) for n, v in bn.state_dict().items()})
+    with torch.no_grad():
+        bn.weight[::3] *= -1.0  # both monotone directions
+    bn.train(train)
+    bn_d = copy.deepcopy(bn).to(device)
+    xr = x.clone().requires_grad_(True)
+    yr = torch.nn.functional.leaky_relu(bn(xr), 0.2).view(B, N, C).max(dim=1)[0]
+    (yr * R).sum().backward()
+    xd = x.to(device).requires_grad_(True)
+    yd = ops.bn_lrelu_max_rows(xd, bn_d, B, N, train, 0.2)
+    (yd * R.to(device)).sum().backward()
+    np.testing.assert_allclose(yd.detach().cpu().numpy(), yr.detach().numpy(), rtol=0, atol=1e-4)
+    for got, want, what in ((xd.grad, xr.grad, "gx"), (bn_d.weight.grad, bn.weight.grad, "gweight"), (bn_d.bias.grad, bn.bias.grad, "gbias")):
+        got, want = got.cpu().numpy(), want.numpy()
+        assert np.abs(got - want).max() <= 1e-4 * max(1e-6, np.abs(want).max()), what
+    if train:
+        np.testing.assert_allclose(bn_d.running_mean.cpu().numpy(), bn.running_mean.numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(bn_d.running_var.cpu().numpy(), bn.running_var.numpy(), rtol=1e-5, atol=1e-6)
+        assert int(bn_d.num_batches_tracked) == int(bn.num_batches_tracked) == 1
+
+
 def test_step_is_graph_capturable(device):
     """every C-ABI call only enqueues work on the current stream: a whole kNN + block forward + backward step can be
     captured in a hipGraph and replayed.  Runs in a child process: a failed capture can
