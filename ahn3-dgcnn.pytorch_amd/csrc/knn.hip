@@ -1233,7 +1233,9 @@ __global__ __launch_bounds__(64) void knn_refine_kernel(const float *__restrict_
     constexpr int STORE = CAP == 64 ? 48 : CAP;
     __shared__ u64 keys[32][STORE];
     __shared__ int cnts[32];
-    __shared__ float taus[32];
+    __shared__ u64 tkeys[32];  // key of the k-th best of a compacted row: later offers must beat it as KEYS (the list
+                               // is not index-ordered inside a chunk of four tiles, so an equal pd with a lower
+                               // index can arrive after the compaction and must still win)
     __shared__ float xq[32][XS];
     __shared__ float xxq[32];
 
@@ -1257,7 +1259,7 @@ __global__ __launch_bounds__(64) void knn_refine_kernel(const float *__restrict_
     if (lane < 32) {
         xxq[lane] = xxb[q0 + lane];
         cnts[lane] = 0;
-        taus[lane] = -__builtin_inff();
+        tkeys[lane] = 0ull;
     }
 
     // The chain list entry -> candidate row -> arithmetic is two dependent loads deep and a wave has little
@@ -1310,7 +1312,7 @@ __global__ __launch_bounds__(64) void knn_refine_kernel(const float *__restrict_
         const u64 key = make_key(pd, cand);
         bool pending = act;
         for (;;) {
-            const bool want = pending && (pd > taus[row]);
+            const bool want = pending && (key > tkeys[row]);
             int slot = -1;
             if (want) slot = atomicAdd(&cnts[row], 1);
             if (want && slot < STORE) keys[row][slot] = key;
@@ -1322,10 +1324,10 @@ __global__ __launch_bounds__(64) void knn_refine_kernel(const float *__restrict_
             while (todo) {
                 const int l0 = __ffsll((long long)todo) - 1;
                 const int ru = __builtin_amdgcn_readlane(row, l0);
-                const float tnew = compact_row<CAP, STORE>(&keys[ru][0], STORE, k, lane);
+                (void)compact_row<CAP, STORE>(&keys[ru][0], STORE, k, lane);
                 if (lane == 0) {
                     cnts[ru] = k;
-                    taus[ru] = tnew;
+                    tkeys[ru] = keys[ru][k - 1];  // (written by this wave just above)
                 }
                 todo &= ~__ballot(over && row == ru);
             }

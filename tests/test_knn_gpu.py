@@ -91,6 +91,10 @@ def _feature_cases():
         "duplicates": np.concatenate([base[:, :, :450], base[:, :, :450]], axis=2),
         "clustered": (base * 0.01 + rng.integers(0, 4, size=(B, 1, N)).astype(np.float32) * 5.0),
         "constant": np.full((B, C, N), 2.5, np.float32),
+        # few distinct coordinate values: the distances take few distinct values, so many exact ties sit on the k-th
+        # boundary and the survivor lists are long (rows are compacted while later, lower-index ties still arrive)
+        "quantized_ties": np.round(base[:, :, :] * 0.6).astype(np.float32) * 0.5 + rng.integers(0, 2, size=(B, 1, N)).astype(np.float32),
+        "quantized_ties_sparse": (np.abs(base) > 1.8).astype(np.float32),
     }
     mixed = base.copy()
     mixed[0] *= 1e-3
@@ -111,6 +115,33 @@ def test_knn_f16_path_c16_c32_c128(device):
     for C in (16, 24, 32, 100, 128):
         x = (rng.standard_normal((2, C, 700)) * rng.uniform(0.1, 10.0, size=(1, C, 1)) + 2.0).astype(np.float32)
         np.testing.assert_array_equal(_run(x, 20, device), ke.knn_exact(x, 20), err_msg="C=%d" % C)
+
+
+def test_knn_small_c_filter_path_is_exact(device):
+    # C <= 8 (raw coordinates of the first block): fp32 pre-pass + fp32 filter + refine; offsets, scales, duplicates
+    rng = np.random.default_rng(21)
+    for C in (3, 4, 8):
+        base = rng.standard_normal((2, C, 1200)).astype(np.float32)
+        cases = {
+            "plain": base,
+            "offset_1000": base + 1000.0,
+            "utm_like": base * 10.0 + np.array([5.0e5, 4.0e6, 50.0, 3.0, 0, 0, 0, 0], np.float32)[None, :C, None],
+            "tiny": base * 1e-5,
+            "duplicates": np.concatenate([base[:, :, :600], base[:, :, :600]], axis=2),
+            "clustered": base * 0.01 + rng.integers(0, 3, size=(2, 1, 1200)).astype(np.float32) * 7.0,
+        }
+        for name, x in cases.items():
+            x = np.ascontiguousarray(x, dtype=np.float32)
+            for k in (8, 30, 40):
+                np.testing.assert_array_equal(_run(x, k, device), ke.knn_exact(x, k), err_msg="C=%d %s k=%d" % (C, name, k))
+
+
+@pytest.mark.parametrize("C", [4, 64])
+def test_knn_large_n_bit_exact(C, device):
+    # one big block: N = 20 000 (157 row groups, both candidate halves, list segments)
+    rng = np.random.default_rng(3 + C)
+    x = rng.standard_normal((1, C, 20000)).astype(np.float32)
+    np.testing.assert_array_equal(_run(x, 30, device), ke.knn_exact(x, 30))
 
 
 def test_knn_k_out_of_range(device):
