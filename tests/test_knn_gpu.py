@@ -144,6 +144,39 @@ def test_knn_large_n_bit_exact(C, device):
     np.testing.assert_array_equal(_run(x, 30, device), ke.knn_exact(x, 30))
 
 
+def _random_case(rng):
+    C = int(rng.choice([3, 4, 5, 8, 9, 16, 24, 32, 64, 100, 128]))
+    N = int(rng.choice([257, 300, 512, 777, 1000, 1500, 2048]))
+    B = int(rng.choice([1, 2, 3]))
+    k = min(int(rng.choice([1, 8, 20, 30, 32, 33, 40, 41, 64])), N)
+    x = rng.standard_normal((B, C, N)).astype(np.float32)
+    mode = str(rng.choice(["plain", "scale", "offset", "quant", "cluster", "sparse", "dups", "chanscale"]))
+    if mode == "scale":
+        x *= np.float32(10.0 ** rng.uniform(-4, 4))
+    elif mode == "offset":
+        x += np.float32(10.0 ** rng.uniform(0, 4))
+    elif mode == "quant":  # exact ties
+        x = np.round(x * rng.uniform(0.3, 2.0)).astype(np.float32) * np.float32(rng.choice([0.25, 0.5, 1.0]))
+    elif mode == "cluster":
+        x = x * np.float32(10.0 ** rng.uniform(-3, -1)) + rng.integers(0, rng.integers(2, 6), size=(B, 1, N)).astype(np.float32) * np.float32(rng.uniform(1, 10))
+    elif mode == "sparse":
+        x = (np.abs(x) > rng.uniform(1.0, 2.2)).astype(np.float32) * np.float32(rng.uniform(0.5, 3))
+    elif mode == "dups":
+        x[:, :, N // 2:] = x[:, :, : N - N // 2]
+    elif mode == "chanscale":
+        x *= (10.0 ** rng.uniform(-2, 2, size=(1, C, 1))).astype(np.float32)
+    return np.ascontiguousarray(x, dtype=np.float32), k, "B=%d C=%d N=%d k=%d %s" % (B, C, N, k, mode)
+
+
+def test_knn_randomised_shapes_scales_and_ties(device):
+    # 150 random configurations (every kernel path: fp32 / fp16 filters, both refine capacities, the in-loop kernel for
+    # k > 40) against the oracle; scripts/fuzz_knn.py runs the same generator for thousands of cases
+    rng = np.random.default_rng(2026)
+    for it in range(150):
+        x, k, what = _random_case(rng)
+        np.testing.assert_array_equal(_run(x, k, device), ke.knn_exact(x, k), err_msg="case %d: %s" % (it, what))
+
+
 def test_knn_k_out_of_range(device):
     from ahn3_dgcnn_pytorch_amd import ops
     x = torch.zeros((1, 10, 4), device=device)
