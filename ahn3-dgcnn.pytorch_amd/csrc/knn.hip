@@ -935,6 +935,7 @@ __global__ __launch_bounds__(64, 2) void knn_kernel(const float *__restrict__ xt
 // with fewer than k candidates is flagged and recomputed by the exact fp32 kernel (knn_kernel), so the
 // result never depends on the filter.
 constexpr int KNN_QCAP = 256;     // LDS staging ring of the filter kernel (entries: row << 27 | candidate)
+constexpr int KNN_MAXPARTS = 4;   // candidate parts of the filter (list segments per row block)
 constexpr int KNN_LISTCAP = 4096;  // survivor list per 32-row block in HBM (128 per row on average)
 
 template <int CP>
@@ -961,7 +962,7 @@ __global__ __launch_bounds__(KNN_ST_THREADS) void knn_filter16_kernel(const half
     if (!(batch_max(bmax, b, 0, Npad / 32) < 1.0e9f)) {  // uniform over the workgroup
         if (lane == 0) {
             rbflag[wid] = 1;
-            lcount[2 * wid + part] = 0;
+            lcount[KNN_MAXPARTS * wid + part] = 0;
         }
         return;
     }
@@ -1089,7 +1090,7 @@ __global__ __launch_bounds__(KNN_ST_THREADS) void knn_filter16_kernel(const half
     }
     while (qn > 0) flush(qn < 64 ? qn : 64);
     if (lane == 0) {
-        lcount[2 * wid + part] = overflow ? 0 : lpos;
+        lcount[KNN_MAXPARTS * wid + part] = overflow ? 0 : lpos;
         if (overflow) rbflag[wid] = 1;
     }
 }
@@ -1213,7 +1214,7 @@ __global__ __launch_bounds__(256) void knn_filter32_kernel(const float *__restri
     }
     while (qn > 0) flush(qn < 64 ? qn : 64);
     if (lane == 0) {
-        lcount[2 * wid + part] = overflow ? 0 : lpos;
+        lcount[KNN_MAXPARTS * wid + part] = overflow ? 0 : lpos;
         if (overflow) rbflag[wid] = 1;
     }
 }
@@ -1249,8 +1250,13 @@ __global__ __launch_bounds__(64) void knn_refine_kernel(const float *__restrict_
     const float *xraw = x + (size_t)b * N * C;
     // the survivor list comes in `parts` segments (one per candidate part of the filter)
     const unsigned *list = lists + (size_t)wid * KNN_LISTCAP;
-    const int n0 = lcount[2 * wid], n = n0 + (parts == 2 ? lcount[2 * wid + 1] : 0);
-    const int seg1 = KNN_LISTCAP / 2 - n0;  // entry e >= n0 lives at list[seg1 + e]
+    // (entry e of the concatenation lives in segment p at list[p * listcap + e - (entries before segment p)])
+    const int listcap = KNN_LISTCAP / parts;
+    int ncum[KNN_MAXPARTS + 1];
+    ncum[0] = 0;
+#pragma unroll
+    for (int pp = 0; pp < KNN_MAXPARTS; ++pp) ncum[pp + 1] = ncum[pp] + (pp < parts ? lcount[KNN_MAXPARTS * wid + pp] : 0);
+    const int n = ncum[KNN_MAXPARTS];
 
     for (int e = lane; e < 32 * CP; e += 64) {
         const int r = e / CP, c = e % CP;
@@ -1268,7 +1274,14 @@ __global__ __launch_bounds__(64) void knn_refine_kernel(const float *__restrict_
     constexpr int NV = CP / 4;  // float4 per candidate row
     auto entry = [&](int base) -> unsigned {
         const int e = base + lane;
-        return e < n ? list[e < n0 ? e : seg1 + e] : 0u;
+        if (e >= n) return 0u;
+        int pp = 0;
+#pragma unroll
+        for (int q = 1; q < KNN_MAXPARTS; ++q) pp += e >= ncum[q] ? 1 : 0;
+        int before = 0;
+#pragma unroll
+        for (int q = 1; q < KNN_MAXPARTS; ++q) before = e >= ncum[q] ? ncum[q] : before;
+        return list[pp * listcap + (e - before)];
     };
     auto fetch = [&](unsigned qe, float4(&v)[NV], float &yy) {
         const float *xl = xraw + (size_t)(qe & 0x7ffffffu) * C;
@@ -1466,7 +1479,7 @@ static KnnWs knn_ws(int B, int C, int N, void *base)
     w.eps = (float *)take((size_t)B * npad * sizeof(float));
     w.mu = (float *)take((size_t)B * cp * sizeof(float));
     w.xh = (half8 *)take((size_t)B * npad * cp * sizeof(_Float16));
-    w.lcount = (int *)take((size_t)B * (npad / 32) * 2 * sizeof(int));
+    w.lcount = (int *)take((size_t)B * (npad / 32) * KNN_MAXPARTS * sizeof(int));
     w.bmax = (unsigned *)take((size_t)B * 2 * (npad / 32) * sizeof(unsigned));
     w.rbflag = (int *)take((size_t)B * (npad / 32) * sizeof(int));
     w.exch = (unsigned *)take(cp >= 16 ? (size_t)B * npad * 2 * 64 * sizeof(unsigned) : 0);
@@ -1547,6 +1560,11 @@ extern "C" int dgcnn_knn(const float *x, int B, int N, int C, int k, int32_t *id
     // the fp16 streams split the candidates of a row group over two workgroups when there are enough chunks:
     // twice the waves per SIMD (the streams are latency-bound at 1.7) and 128 instead of 64 threshold classes
     const int parts = Npad / (32 * KNN_ST_TILES) >= 8 ? 2 : 1;
+    // the filter cuts finer (up to KNN_MAXPARTS candidate parts): its workgroups are the unit of load balance, and
+    // 3.4 of them per CU (two parts) leave 14 % of the chip idle at the end
+    static const int fparts_env = getenv("DGCNN_KNN_FPARTS") ? atoi(getenv("DGCNN_KNN_FPARTS")) : 0;  // experiments
+    int fparts = Npad / (32 * KNN_ST_TILES) >= 16 ? KNN_MAXPARTS : parts;
+    if (fparts_env >= 1 && fparts_env <= KNN_MAXPARTS && Npad / (32 * KNN_ST_TILES) >= fparts_env) fparts = fparts_env;
     if (prepass) {
         // (knn_bound_kernel writes tau0 for every row, padded rows included)
         if (CP >= 16) {
@@ -1580,19 +1598,19 @@ extern "C" int dgcnn_knn(const float *x, int B, int N, int C, int k, int32_t *id
         if (hipMemsetAsync(w.rbflag, 0, (size_t)B * (Npad / 32) * sizeof(int), st) != hipSuccess)
             DG_FAIL("dgcnn_knn: memset failed");
         rbflag = w.rbflag;
-        const dim3 fgrid(B * parts * ceil_div(Npad / 32, 4)), rgrid(B * (Npad / 32));
+        const dim3 fgrid(B * fparts * ceil_div(Npad / 32, 4)), rgrid(B * (Npad / 32));
         prof_begin(PROF_KNN_FILTER, st);
         if (CP == 4)
-            hipLaunchKernelGGL((knn_filter32_kernel<4>), fgrid, dim3(256), 0, st, xt, xx, w.tau0, B, Npad, parts, w.lists,
+            hipLaunchKernelGGL((knn_filter32_kernel<4>), fgrid, dim3(256), 0, st, xt, xx, w.tau0, B, Npad, fparts, w.lists,
                                w.lcount, w.rbflag);
         else
-            hipLaunchKernelGGL((knn_filter32_kernel<8>), fgrid, dim3(256), 0, st, xt, xx, w.tau0, B, Npad, parts, w.lists,
+            hipLaunchKernelGGL((knn_filter32_kernel<8>), fgrid, dim3(256), 0, st, xt, xx, w.tau0, B, Npad, fparts, w.lists,
                                w.lcount, w.rbflag);
         prof_end(PROF_KNN_FILTER, st);
         prof_begin(PROF_KNN_REFINE, st);
 #define DG_REFINE(CP_, CAP_)                                                                                          \
     hipLaunchKernelGGL((knn_refine_kernel<CP_, CAP_>), rgrid, dim3(64), 0, st, x, w.xx, w.lists, w.lcount, w.rbflag, B, \
-                       N, C, Npad, k, parts, idx)
+                       N, C, Npad, k, fparts, idx)
         if (CP == 4) {
             if (cap == 64) DG_REFINE(4, 64);
             else DG_REFINE(4, 128);
@@ -1609,10 +1627,10 @@ extern "C" int dgcnn_knn(const float *x, int B, int N, int C, int k, int32_t *id
         // kernels flagged (it returns at once for the others)
         rbflag = w.rbflag;
         switch (CP) {
-            case 16: knn_f16_launch<16>(cap, parts, w, x, B, N, C, Npad, k, idx, st); break;
-            case 32: knn_f16_launch<32>(cap, parts, w, x, B, N, C, Npad, k, idx, st); break;
-            case 64: knn_f16_launch<64>(cap, parts, w, x, B, N, C, Npad, k, idx, st); break;
-            default: knn_f16_launch<128>(cap, parts, w, x, B, N, C, Npad, k, idx, st); break;
+            case 16: knn_f16_launch<16>(cap, fparts, w, x, B, N, C, Npad, k, idx, st); break;
+            case 32: knn_f16_launch<32>(cap, fparts, w, x, B, N, C, Npad, k, idx, st); break;
+            case 64: knn_f16_launch<64>(cap, fparts, w, x, B, N, C, Npad, k, idx, st); break;
+            default: knn_f16_launch<128>(cap, fparts, w, x, B, N, C, Npad, k, idx, st); break;
         }
         DG_CHECK_LAUNCH("knn_filter16_kernel / knn_refine_kernel");
     }

@@ -17,8 +17,8 @@ cp = 4 if C <= 4 else 8 if C <= 8 else (C + 15) // 16 * 16
 al = lambda v: (v + 255) // 256 * 256
 off = al(B * npad * cp * 4) + 4 * al(B * npad * 4) + al(B * cp * 4) + al(B * npad * cp * 2)
 nrb = B * (npad // 32)
-lcount = ws[off:off + nrb * 8].view(torch.int32).reshape(nrb, 2).sum(1)
-off += al(nrb * 8) + al(nrb * 8)
+lcount = ws[off:off + nrb * 16].view(torch.int32).reshape(nrb, 4).sum(1)
+off += al(nrb * 16) + al(nrb * 8)
 rbflag = ws[off:off + nrb * 4].view(torch.int32)
 print("row blocks", nrb, "flagged", int(rbflag.sum()), "lcount mean %.1f max %d (per row %.1f)" % (
     lcount.float().mean(), int(lcount.max()), lcount.float().mean() / 32))
