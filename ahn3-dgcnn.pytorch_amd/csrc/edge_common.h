@@ -41,6 +41,9 @@ __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.0f ?
 // in the same buffer by PART_FOLD records of scratch for the folding step of the finalize kernels
 constexpr int PART_MAX = 4096, PART_FOLD = 32;
 
+// in-edge lists longer than this are cut into segments (edge_stream.hip: hub points of the kNN graph)
+constexpr int REV_SEG = 64;
+
 // stats block of one BatchNorm stage inside `saved`: 4 rows of 64 floats
 enum { ST_MEAN = 0, ST_RSTD = 64, ST_SC = 128, ST_SH = 192, ST_SIZE = 256 };
 

@@ -469,7 +469,6 @@ __global__ __launch_bounds__(REV_THREADS) void rev_scan_kernel(const int *__rest
 
 // cnt[b][chunk][m] <- first slot of chunk's edges into m; also lists the extra segments of long lists:
 // (point, segment) pairs for segments 1 .. (deg - 1) / REV_SEG, allocated with one atomic per workgroup
-constexpr int REV_SEG = 128;
 __global__ __launch_bounds__(256) void rev_slots_kernel(const int *__restrict__ rowptr, int N, int chunks, int P,
                                                         int *__restrict__ cnt, int *__restrict__ nextra,
                                                         int2 *__restrict__ extra)
@@ -543,9 +542,10 @@ static_assert(sizeof(HitRec) == 32, "HitRec is one 32-byte sector");
 
 // kNN graphs in feature space have hubs (at B = 8, N = 7000, k = 30 on Gaussian features: median in-degree 12,
 // maximum 1372), and one wave walking a hub's list alone would set the kernel time.  A point's list is therefore
-// cut into segments of REV_SEG in-edges: edge_rgather_kernel<., false> does segment 0 of every point and writes
-// dR, rev_slots_kernel lists the remaining (point, segment) pairs, and edge_rgather_kernel<., true> adds those
-// with one 256-byte wave-atomic each.
+// cut into segments of REV_SEG in-edges (64: measured 76 / 69 / 67 / 70 us at 32 / 48 / 64 / 96): rev_slots_kernel lists
+// the (point, segment) pairs beyond segment 0, and edge_rgather_kernel runs workgroups for the points (segment 0) and
+// for those pairs side by side; a point with more than one segment is assembled with one 256-byte wave-atomic per
+// segment (its row is zeroed beforehand).
 // sums over the list entries [beg, end) (at most REV_SEG; ev_first = entries beg .. beg + 63 in the lanes):
 // sq = sum of the sources' TQ rows, sd = sum of their dv rows (DENSE); sparse hits go to sacc[channel]
 template <bool DENSE>
@@ -613,7 +613,7 @@ __device__ __forceinline__ void rgather_segment(const float *__restrict__ TQ, co
     sd = d0 + d1;
 }
 
-template <bool DENSE, bool EXTRA>
+template <bool DENSE>
 __global__ __launch_bounds__(256) void edge_rgather_kernel(const float *__restrict__ TP, const float *__restrict__ TQ,
                                                            const int *__restrict__ rowptr,
                                                            const int32_t *__restrict__ rev, int k, int P,
@@ -621,8 +621,13 @@ __global__ __launch_bounds__(256) void edge_rgather_kernel(const float *__restri
                                                            const float *__restrict__ cc, const float *__restrict__ dv,
                                                            const HitRec *__restrict__ hits,
                                                            const float *__restrict__ G, const int *__restrict__ nextra,
-                                                           const int2 *__restrict__ extra, float *__restrict__ dR)
+                                                           const int2 *__restrict__ extra, int main_blocks,
+                                                           float *__restrict__ dR)
 {
+    // Workgroups 0 .. main_blocks - 1 walk the points (segment 0 of every list), the others the extra segments of
+    // the long lists, concurrently (one launch; dispatching the extra workgroups first was measured slower): every
+    // contribution to a point with more than one segment is an atomic add into its row of dR, which
+    // edge_point_bwd_kernel has zeroed.
     // DENSE: dv [E][64] rows by edge id.  Sparse: hits[e] by edge id and G [P][64] = sc dL/dv of the centre's
     // surviving edge per channel, both written by edge_point_bwd_kernel.
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -632,9 +637,10 @@ __global__ __launch_bounds__(256) void edge_rgather_kernel(const float *__restri
     __shared__ float sacc_all[EDGE_WAVES][64];  // sparse dv: hit gradients of the current point, by channel
     float *sacc = sacc_all[wave];
     if (!DENSE) sacc[lane] = 0.0f;
-    if (EXTRA) {
+    if ((int)blockIdx.x >= main_blocks) {
         const int n = *nextra;
-        for (int w = blockIdx.x * EDGE_WAVES + wave; w < n; w += gridDim.x * EDGE_WAVES) {
+        for (int w = ((int)blockIdx.x - main_blocks) * EDGE_WAVES + wave; w < n;
+             w += ((int)gridDim.x - main_blocks) * EDGE_WAVES) {
             const int2 ps = extra[w];
             const int pbeg = __builtin_amdgcn_readfirstlane(rowptr[ps.x]), pend = __builtin_amdgcn_readfirstlane(rowptr[ps.x + 1]);
             const int beg = pbeg + __builtin_amdgcn_readfirstlane(ps.y) * REV_SEG;
@@ -655,7 +661,14 @@ __global__ __launch_bounds__(256) void edge_rgather_kernel(const float *__restri
         }
         return;
     }
-    const PointIter it = point_iter(P, wave, EDGE_WAVES);
+    PointIter it;  // point_iter() over the first main_blocks workgroups only
+    {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = main_blocks >> 3;
+        const int per = (P + 7) >> 3, first = xcd * per;
+        it.end = first + per < P ? first + per : P;
+        it.cur = first + slot * EDGE_WAVES + wave;
+        it.step = nslots * EDGE_WAVES;
+    }
     // The chain list bounds -> list entries -> rows is three dependent loads deep, so it is software-pipelined
     // across the points of a wave: the bounds are fetched two points ahead, the first 64 list entries one.
     int pt = it.cur;
@@ -696,7 +709,8 @@ __global__ __launch_bounds__(256) void edge_rgather_kernel(const float *__restri
             sacc[lane] = 0.0f;
             __builtin_amdgcn_wave_barrier();
         }
-        dR[(size_t)pt * EC + lane] = r;
+        if (end - beg > REV_SEG) atomicAdd(dR + (size_t)pt * EC + lane, r);  // shared with the extra segments
+        else dR[(size_t)pt * EC + lane] = r;
     }
 }
 
@@ -714,6 +728,7 @@ __global__ __launch_bounds__(256) void edge_point_bwd_kernel(const float *__rest
                                                              const float *__restrict__ usum,
                                                              const float *__restrict__ dv,
                                                              HitRec *__restrict__ hits, float *__restrict__ G,
+                                                             const int *__restrict__ rowptr, float *__restrict__ dR,
                                                              float *__restrict__ dD)
 {
     __shared__ u64 smask[EDGE_WAVES][128];          // by slot (k <= 96)
@@ -757,6 +772,8 @@ __global__ __launch_bounds__(256) void edge_point_bwd_kernel(const float *__rest
             __builtin_amdgcn_wave_barrier();
         }
         dD[o] = dsum + (float)k * A - alpha * (usum[o] - (float)k * q);
+        // rows of dR that edge_rgather_kernel assembles with atomics (lists of more than one segment) start at zero
+        if (rowptr[pt + 1] - rowptr[pt] > REV_SEG) dR[o] = 0.0f;
     }
 }
 
@@ -803,23 +820,20 @@ int launch_edge_bwd_nogather(const float *TP, const float *TQ, int B, int N, int
     const int2 *elist = reinterpret_cast<const int2 *>(extra + 2);
     if (dv)
         hipLaunchKernelGGL((edge_point_bwd_kernel<true>), grid, block, 0, st, TQ, N, k, P, stats, cc, slope, gy, y, hitj, usum,
-                           dvsum, (HitRec *)hits, G, dD);
+                           dvsum, (HitRec *)hits, G, rowptr, dR, dD);
     else
         hipLaunchKernelGGL((edge_point_bwd_kernel<false>), grid, block, 0, st, TQ, N, k, P, stats, cc, slope, gy, y, hitj, usum,
-                           nullptr, (HitRec *)hits, G, dD);
+                           nullptr, (HitRec *)hits, G, rowptr, dR, dD);
     prof_begin(PROF_EDGE_RGATHER, st);
-    const dim3 xgrid(1024);  // extra segments: a few thousand at most, about one per wave
-    if (dv) {
-        hipLaunchKernelGGL((edge_rgather_kernel<true, false>), grid, block, 0, st, TP, TQ, rowptr, rev, k, P, stats, cc, dv,
-                           (const HitRec *)hits, G, nextra, elist, dR);
-        hipLaunchKernelGGL((edge_rgather_kernel<true, true>), xgrid, block, 0, st, TP, TQ, rowptr, rev, k, P, stats, cc, dv,
-                           (const HitRec *)hits, G, nextra, elist, dR);
-    } else {
-        hipLaunchKernelGGL((edge_rgather_kernel<false, false>), grid, block, 0, st, TP, TQ, rowptr, rev, k, P, stats, cc, dv,
-                           (const HitRec *)hits, G, nextra, elist, dR);
-        hipLaunchKernelGGL((edge_rgather_kernel<false, true>), xgrid, block, 0, st, TP, TQ, rowptr, rev, k, P, stats, cc, dv,
-                           (const HitRec *)hits, G, nextra, elist, dR);
-    }
+    // one launch: the point workgroups and, behind them, workgroups for the extra segments of the long lists
+    const int main_blocks = (int)grid.x, extra_blocks = main_blocks / 2;
+    const dim3 ggrid(main_blocks + extra_blocks);
+    if (dv)
+        hipLaunchKernelGGL((edge_rgather_kernel<true>), ggrid, block, 0, st, TP, TQ, rowptr, rev, k, P, stats, cc, dv,
+                           (const HitRec *)hits, G, nextra, elist, main_blocks, dR);
+    else
+        hipLaunchKernelGGL((edge_rgather_kernel<false>), ggrid, block, 0, st, TP, TQ, rowptr, rev, k, P, stats, cc, dv,
+                           (const HitRec *)hits, G, nextra, elist, main_blocks, dR);
     prof_end(PROF_EDGE_RGATHER, st);
     return 0;
 }

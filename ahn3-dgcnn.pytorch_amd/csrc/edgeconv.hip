@@ -100,7 +100,7 @@ static BwdWs bwd_ws(const dgcnn_edgeconv_desc *d, void *p)
     w.indeg = c.take<int>(P);
     w.rowptr = c.take<int>(P + 1);
     w.rev = c.take<int>(P * d->k);
-    w.extra = c.take<int>(2 + 2 * (P * d->k / 128 + 1));  // counter + (point, segment) pairs of long in-edge lists
+    w.extra = c.take<int>(2 + 2 * (P * d->k / REV_SEG + 1));  // counter + (point, segment) pairs of long in-edge lists
     w.hits = d->n_stage == 1 ? (void *)c.take<u64>(P * d->k * 4) : nullptr;  // 32 bytes per edge
     w.G = d->n_stage == 1 ? c.take<float>(P * EC) : nullptr;
     if (d->n_stage == 2) {
