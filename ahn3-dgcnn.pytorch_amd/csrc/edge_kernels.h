@@ -71,7 +71,7 @@ void launch_edge_mlp_fwd(const float *TP, const float *TQ, const int32_t *idx, i
 // [grid][2][64] doubles (sum dv1, sum dv1 * uhat1)
 void launch_edge_mlp_bwd(const float *TP, const float *TQ, const int32_t *idx, int N, int k, int P,
                          const float *stats1, const float *stats2, const float *cc2, const float *w2, float slope,
-                         int training, const float *gy, const float *y, float *dv1, float *dvsum, float *partial_dw2,
-                         double *partial_bn1, hipStream_t st);
+                         int training, const float *gy, const float *y, const float *usel2, float *dv1, float *dvsum,
+                         float *partial_dw2, double *partial_bn1, hipStream_t st);
 
 }  // namespace dgcnn

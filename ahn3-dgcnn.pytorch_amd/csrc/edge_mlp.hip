@@ -199,8 +199,8 @@ __global__ __launch_bounds__(256) void edge_mlp_bwd_kernel(
     const float *__restrict__ TP, const float *__restrict__ TQ, const int32_t *__restrict__ idx, int N, int k, int P,
     const float *__restrict__ stats1, const float *__restrict__ stats2, const float *__restrict__ cc2,
     const float *__restrict__ w2, float slope, int training, const float *__restrict__ gy,
-    const float *__restrict__ y, float *__restrict__ dv1, float *__restrict__ dvsum,
-    float *__restrict__ partial_dw2, double *__restrict__ partial_bn1)
+    const float *__restrict__ y, const float *__restrict__ usel2, float *__restrict__ dv1,
+    float *__restrict__ dvsum, float *__restrict__ partial_dw2, double *__restrict__ partial_bn1)
 {
     // W2 as the B operand of the two products that contract over a channel index:
     //   imgU[nt][s][lane (n, h)] = W2[co = nt 32 + n][ci = 32 h + s]     (u2  = a1 . W2^T)
@@ -222,18 +222,16 @@ __global__ __launch_bounds__(256) void edge_mlp_bwd_kernel(
 
     // gather-phase constants (lane = channel) and accumulator-layout constants (lane (n, h) = channel nt 32 + n)
     const float sc1g = stats1[ST_SC + lane], sh1g = stats1[ST_SH + lane];
-    float mean1[2], rstd1[2], mean2[2], rstd2[2], sc2[2], sh2[2], c1[2], c2[2];
+    // du2 = cA + cB u2 + (dL/dy at the winning edge): the BatchNorm mean terms are affine in u2 (zero in eval mode)
+    float mean1[2], rstd1[2], sc2[2], cA[2], cB[2];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int c = nt * 32 + i32;
         mean1[nt] = stats1[ST_MEAN + c];
         rstd1[nt] = stats1[ST_RSTD + c];
-        mean2[nt] = stats2[ST_MEAN + c];
-        rstd2[nt] = stats2[ST_RSTD + c];
         sc2[nt] = stats2[ST_SC + c];
-        sh2[nt] = stats2[ST_SH + c];
-        c1[nt] = cc2[c];
-        c2[nt] = cc2[64 + c];
+        cB[nt] = training ? -sc2[nt] * cc2[64 + c] * stats2[ST_RSTD + c] : 0.0f;
+        cA[nt] = training ? -sc2[nt] * cc2[c] - cB[nt] * stats2[ST_MEAN + c] : 0.0f;
     }
 
     f32x16 accW[2][2];  // gW2 tile [co tile][ci tile]
@@ -261,13 +259,14 @@ __global__ __launch_bounds__(256) void edge_mlp_bwd_kernel(
         const float *Pb = TP + (size_t)b * N * EC;
         const float q = qn;
         const int32_t *ip = idx + (size_t)pt * k;
-        float yv[2], dvs[2];
+        float uv[2], dvs[2];
         float dcol[2] = {0.0f, 0.0f};  // sum over the point's edges of dv1, per channel (for the centre term dD)
         bool found[2] = {false, false};
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-            yv[nt] = y[(size_t)pt * EC + nt * 32 + i32];
-            dvs[nt] = gy[(size_t)pt * EC + nt * 32 + i32] * (yv[nt] > 0.0f ? 1.0f : slope);
+            uv[nt] = usel2[(size_t)pt * EC + nt * 32 + i32];
+            dvs[nt] = sc2[nt] * gy[(size_t)pt * EC + nt * 32 + i32] *
+                      (y[(size_t)pt * EC + nt * 32 + i32] > 0.0f ? 1.0f : slope);
         }
         for (int j0 = 0; j0 < k; j0 += 32) {
             const int kk = k - j0 < 32 ? k - j0 : 32;
@@ -301,16 +300,16 @@ __global__ __launch_bounds__(256) void edge_mlp_bwd_kernel(
                 acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], imgU[1][s][lane], acc[1], 0, 0, 0);
             }
 
-            // ---- du2 (in place of u2).  The whole dL/dy goes to the FIRST edge whose activation
-            // equals y (PyTorch's max semantics); the rest of du2 are the dense BatchNorm mean terms.
+            // ---- du2 (in place of u2).  The whole dL/dy goes to the FIRST edge whose pre-activation is the extreme
+            // the forward selected (the recomputed u2 is bit-identical to the forward's: same operands, same MFMA
+            // order); the rest of du2 are the dense BatchNorm mean terms.
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 int first = 1000;
 #pragma unroll
                 for (int r = 15; r >= 0; --r) {
                     const int row = mfma32_row(r, h);
-                    const float a2 = lrelu(__builtin_fmaf(acc[nt][r], sc2[nt], sh2[nt]), slope);
-                    if (row < kk && a2 == yv[nt]) first = row;
+                    if (row < kk && acc[nt][r] == uv[nt]) first = row;
                 }
                 const int other = __shfl_xor(first, 32);
                 first = first < other ? first : other;
@@ -320,11 +319,7 @@ __global__ __launch_bounds__(256) void edge_mlp_bwd_kernel(
                 for (int r = 0; r < 16; ++r) {
                     const int row = mfma32_row(r, h);
                     float du = 0.0f;
-                    if (row < kk) {
-                        const float uhat = (acc[nt][r] - mean2[nt]) * rstd2[nt];
-                        const float dv = (row == hitrow) ? dvs[nt] : 0.0f;
-                        du = training ? sc2[nt] * (dv - c1[nt] - c2[nt] * uhat) : sc2[nt] * dv;
-                    }
+                    if (row < kk) du = __builtin_fmaf(cB[nt], acc[nt][r], cA[nt]) + (row == hitrow ? dvs[nt] : 0.0f);
                     acc[nt][r] = du;
                     tileD[row][nt * 32 + i32] = du;
                 }
@@ -427,11 +422,11 @@ void launch_edge_mlp_fwd(const float *TP, const float *TQ, const int32_t *idx, i
 
 void launch_edge_mlp_bwd(const float *TP, const float *TQ, const int32_t *idx, int N, int k, int P,
                          const float *stats1, const float *stats2, const float *cc2, const float *w2, float slope,
-                         int training, const float *gy, const float *y, float *dv1, float *dvsum, float *partial_dw2,
-                         double *partial_bn1, hipStream_t st)
+                         int training, const float *gy, const float *y, const float *usel2, float *dv1, float *dvsum,
+                         float *partial_dw2, double *partial_bn1, hipStream_t st)
 {
     hipLaunchKernelGGL(edge_mlp_bwd_kernel, dim3(mlp_grid(P)), dim3(256), 0, st, TP, TQ, idx, N, k, P, stats1, stats2,
-                       cc2, w2, slope, training, gy, y, dv1, dvsum, partial_dw2, partial_bn1);
+                       cc2, w2, slope, training, gy, y, usel2, dv1, dvsum, partial_dw2, partial_bn1);
 }
 
 }  // namespace dgcnn

@@ -229,7 +229,7 @@ extern "C" int dgcnn_edgeconv_bwd(const dgcnn_edgeconv_desc *d, const float *x, 
     } else {
         launch_bwd_point(gy, s.usel, s.stats2, d->slope, P, E, d->training, w.partial, g->gbn2_w, g->gbn2_b, w.cc2, st);
         launch_edge_mlp_bwd(s.TP, s.TQ, idx, N, k, P, s.stats1, s.stats2, w.cc2, d->w2, d->slope, d->training, gy, y,
-                            w.dv1, w.dvsum, w.dw2_partial, w.bn1_partial, st);
+                            s.usel, w.dv1, w.dvsum, w.dw2_partial, w.bn1_partial, st);
         launch_sum_partials(w.dw2_partial, mlp_grid(P), EC * EC, g->gw2, st);
         launch_bn_bwd_finalize(w.bn1_partial, mlp_grid(P), E, d->training, g->gbn1_w, g->gbn1_b, w.cc1, st);
         if (d->training) {

@@ -12,6 +12,7 @@ dev = torch.device("cuda:0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 7000
 k = int(sys.argv[3]) if len(sys.argv) > 3 else 30
+mode = sys.argv[4] if len(sys.argv) > 4 else "all"   # all | eval | train (to profile one of them)
 m = DGCNN(5, 4, k, dropout=0.5, emb_dims=1024, cuda=True)
 g = torch.Generator().manual_seed(0)
 x = (torch.rand(B, N, 4, generator=g) * torch.tensor([30.0, 30.0, 20.0, 20.0])).to(dev).permute(0, 2, 1)  # strided, as train.py:176
@@ -29,13 +30,16 @@ def timeit(fn, n=10, warm=3):
     return (time.perf_counter() - t0) / n
 
 
-m.eval()
-with torch.no_grad():
-    t = timeit(lambda: m(x))
-print("eval forward  B=%d N=%d k=%d: %.2f ms  (%.2f M points/s)" % (B, N, k, t * 1e3, B * N / t / 1e6), flush=True)
-with torch.no_grad():
-    t3 = timeit(lambda: m(x, depth=3))
-print("  of which the three EdgeConv blocks (depth=3 exit): %.2f ms" % (t3 * 1e3), flush=True)
+if mode in ("all", "eval"):
+    m.eval()
+    with torch.no_grad():
+        t = timeit(lambda: m(x))
+    print("eval forward  B=%d N=%d k=%d: %.2f ms  (%.2f M points/s)" % (B, N, k, t * 1e3, B * N / t / 1e6), flush=True)
+    with torch.no_grad():
+        t3 = timeit(lambda: m(x, depth=3))
+    print("  of which the three EdgeConv blocks (depth=3 exit): %.2f ms" % (t3 * 1e3), flush=True)
+if mode == "eval":
+    sys.exit(0)
 
 m.train()
 opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=1e-4)  # train.py:118
