@@ -86,7 +86,7 @@ __device__ __forceinline__ void load_a_operand(const float (*tile)[TSTR], int i3
 }
 
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void edge_mlp_fwd_kernel(const float *__restrict__ TP, const float *__restrict__ TQ,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void edge_mlp_fwd_kernel(const float *__restrict__ TP, const float *__restrict__ TQ,
                                                            const int32_t *__restrict__ idx, int N, int k, int P,
                                                            const float *__restrict__ stats1,
                                                            const float *__restrict__ w2,
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void edge_mlp_fwd_kernel(const float *__restri
         const float *Pb = TP + (size_t)b * N * EC;
         const float q = TQ[(size_t)pt * EC + lane];
         const int32_t *ip = idx + (size_t)pt * k;
-        float ext[2];
+        float ext[2], ps[2] = {0.0f, 0.0f}, pq[2] = {0.0f, 0.0f};  // fp32 over the <= 32 values of a lane, fp64 across points
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) ext[nt] = neg[nt] ? __builtin_inff() : -__builtin_inff();
         for (int j0 = 0; j0 < k; j0 += 32) {
@@ -160,13 +160,15 @@ __global__ __launch_bounds__(256) void edge_mlp_fwd_kernel(const float *__restri
                 for (int r = 0; r < 16; ++r)
                     if (mfma32_row(r, h) < kk) {
                         const float u = acc[nt][r];
-                        sum[nt] += (double)u;
-                        sq[nt] = __builtin_fma((double)u, (double)u, sq[nt]);
+                        ps[nt] += u;
+                        pq[nt] = __builtin_fmaf(u, u, pq[nt]);
                         ext[nt] = neg[nt] ? fminf(ext[nt], u) : fmaxf(ext[nt], u);
                     }
         }
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
+            sum[nt] += (double)ps[nt];
+            sq[nt] += (double)pq[nt];
             const float o = __shfl_xor(ext[nt], 32);
             const float e = neg[nt] ? fminf(ext[nt], o) : fmaxf(ext[nt], o);
             if (h == 0) usel2[(size_t)pt * EC + nt * 32 + i32] = e;
@@ -261,6 +263,7 @@ __global__ __launch_bounds__(256) void edge_mlp_bwd_kernel(
         const int32_t *ip = idx + (size_t)pt * k;
         float uv[2], dvs[2];
         float dcol[2] = {0.0f, 0.0f};  // sum over the point's edges of dv1, per channel (for the centre term dD)
+        float dhat[2] = {0.0f, 0.0f};  // ... and of dv1 * uhat1 (fp32 over the <= 32 values of a lane, fp64 across points)
         bool found[2] = {false, false};
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
@@ -363,13 +366,14 @@ __global__ __launch_bounds__(256) void edge_mlp_bwd_kernel(
                         const float uhat = (tileU[row][nt * 32 + i32] - mean1[nt]) * rstd1[nt];
                         dv1[((size_t)pt * k + j0 + row) * EC + nt * 32 + i32] = d;
                         dcol[nt] += d;
-                        sb[nt] += (double)d;
-                        sg[nt] = __builtin_fma((double)d, (double)uhat, sg[nt]);
+                        dhat[nt] = __builtin_fmaf(d, uhat, dhat[nt]);
                     }
                 }
         }
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
+            sb[nt] += (double)dcol[nt];
+            sg[nt] += (double)dhat[nt];
             const float t = dcol[nt] + __shfl_xor(dcol[nt], 32);
             if (h == 0) dvsum[(size_t)pt * EC + nt * 32 + i32] = t;
         }
