@@ -20,17 +20,18 @@
 
 namespace dgcnn {
 
-constexpr int MLP_WAVES = 4;
+constexpr int MLP_WAVES = 4;      // forward
+constexpr int MLP_BWD_WAVES = 8;  // backward: two waves per SIMD, one in its MFMA phases while the other gathers / stages
 constexpr int TSTR = 68;  // LDS tile row stride in floats (64 + 4: conflict-free b128 rows)
 
-// workgroups: the backward holds 136 KB of LDS (one workgroup per CU); the forward 39 KB, so three per CU hide
+// workgroups: the backward holds 156 KB of LDS (one workgroup of eight waves per CU); the forward 39 KB, so three per CU hide
 // each other's gather and LDS latencies (measured: 304 us at 32 slots per XCD)
 static int mlp_slots_fwd()
 {
     static const int v = getenv("DGCNN_MLP_SLOTS") ? atoi(getenv("DGCNN_MLP_SLOTS")) : 96;  // experiments
     return v;
 }
-int mlp_grid(int P) { return point_grid(P, MLP_WAVES, 32); }
+int mlp_grid(int P) { return point_grid(P, MLP_BWD_WAVES, 32); }
 int mlp_grid_fwd(int P) { return point_grid(P, MLP_WAVES, mlp_slots_fwd()); }
 
 __device__ __forceinline__ double shfl_xor_d(double v, int m)
@@ -197,29 +198,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 }
 
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void edge_mlp_bwd_kernel(
+__global__ __launch_bounds__(512) void edge_mlp_bwd_kernel(
     const float *__restrict__ TP, const float *__restrict__ TQ, const int32_t *__restrict__ idx, int N, int k, int P,
     const float *__restrict__ stats1, const float *__restrict__ stats2, const float *__restrict__ cc2,
     const float *__restrict__ w2, float slope, int training, const float *__restrict__ gy,
     const float *__restrict__ y, const float *__restrict__ usel2, float *__restrict__ dv1,
     float *__restrict__ dvsum, float *__restrict__ partial_dw2, double *__restrict__ partial_bn1)
 {
-    // W2 as the B operand of the two products that contract over a channel index:
-    //   imgU[nt][s][lane (n, h)] = W2[co = nt 32 + n][ci = 32 h + s]     (u2  = a1 . W2^T)
-    //   imgD[nt][s][lane (n, h)] = W2[co = 32 h + s][ci = nt 32 + n]     (da1 = du2 . W2)
-    __shared__ float imgU[2][32][64], imgD[2][32][64];
-    __shared__ __attribute__((aligned(16))) float tiles[MLP_WAVES][3][32][TSTR];
+    // W2 [co][ci] once, rows padded to 65 floats, serves as the B operand of both products that contract over a
+    // channel index without bank conflicts:
+    //   u2  = a1 . W2^T :  B[k = ci = 32 h + s][n = co] = w2s[nt 32 + n][32 h + s]   (lanes n: stride 65)
+    //   da1 = du2 . W2  :  B[k = co = 32 h + s][n = ci] = w2s[32 h + s][nt 32 + n]   (lanes n: consecutive)
+    // Two tiles per wave: du2 overwrites a1 once a1 sits in registers (A operand and accumulator layout).
+    __shared__ float w2s[64][65];
+    __shared__ __attribute__((aligned(16))) float tiles[MLP_BWD_WAVES][2][32][TSTR];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, i32 = lane & 31;
-    float(*tileA)[TSTR] = tiles[wave][0];  // a1 [edge][ci]
+    float(*tileA)[TSTR] = tiles[wave][0];  // a1 [edge][ci], then du2 [edge][co]
     float(*tileU)[TSTR] = tiles[wave][1];  // u1 [edge][ci]
-    float(*tileD)[TSTR] = tiles[wave][2];  // du2 [edge][co]
+    float(*tileD)[TSTR] = tileA;
 
-    for (int t = threadIdx.x; t < 2 * 32 * 64; t += 256) {
-        const int l = t & 63, s = (t >> 6) & 31, nt = t >> 11;
-        const int n = l & 31, hh = l >> 5;
-        imgU[nt][s][l] = w2[(size_t)(nt * 32 + n) * EC + 32 * hh + s];
-        imgD[nt][s][l] = w2[(size_t)(32 * hh + s) * EC + nt * 32 + n];
-    }
+    for (int t = threadIdx.x; t < 4096; t += 512) w2s[t >> 6][t & 63] = w2[t];
     __syncthreads();
 
     // gather-phase constants (lane = channel) and accumulator-layout constants (lane (n, h) = channel nt 32 + n)
@@ -245,7 +243,7 @@ __global__ __launch_bounds__(256) void edge_mlp_bwd_kernel(
             for (int r = 0; r < 16; ++r) accW[a_][b_][r] = 0.0f;
     double sb[2] = {0.0, 0.0}, sg[2] = {0.0, 0.0};  // BN1: sum dv1, sum dv1 * uhat1
 
-    const PointIter it = point_iter(P, wave, MLP_WAVES);
+    const PointIter it = point_iter(P, wave, MLP_BWD_WAVES);
     // index rows two points ahead, table rows one point ahead (see the forward)
     const int kk0 = k < 32 ? k : 32;
     float pn[32], qn = 0.0f;
@@ -299,9 +297,15 @@ __global__ __launch_bounds__(256) void edge_mlp_bwd_kernel(
                 for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
 #pragma unroll
             for (int s = 0; s < 32; ++s) {
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], imgU[0][s][lane], acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], imgU[1][s][lane], acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], w2s[i32][32 * h + s], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], w2s[32 + i32][32 * h + s], acc[1], 0, 0, 0);
             }
+            // a1 in the accumulator layout (B operand of the weight gradient, LReLU' mask of dv1) before du2 overwrites it
+            float ba[2][16];
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ba[ct][r] = tileA[mfma32_row(r, h)][ct * 32 + i32];
 
             // ---- du2 (in place of u2).  The whole dL/dy goes to the FIRST edge whose pre-activation is the extreme
             // the forward selected (the recomputed u2 is bit-identical to the forward's: same operands, same MFMA
@@ -329,12 +333,7 @@ __global__ __launch_bounds__(256) void edge_mlp_bwd_kernel(
             }
 
             // ---- gW2[co][ci] += sum_edges du2[edge][co] a1[edge][ci]: the du2 accumulators are the
-            // A operand as they stand (k = edge row of register r), a1 comes back from LDS as B.
-            float ba[2][16];
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) ba[ct][r] = tileA[mfma32_row(r, h)][ct * 32 + i32];
+            // A operand as they stand (k = edge row of register r), a1 (read above) is B.
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
 #pragma unroll
@@ -353,8 +352,8 @@ __global__ __launch_bounds__(256) void edge_mlp_bwd_kernel(
                 for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
 #pragma unroll
             for (int s = 0; s < 32; ++s) {
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], imgD[0][s][lane], acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], imgD[1][s][lane], acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], w2s[32 * h + s][i32], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], w2s[32 * h + s][32 + i32], acc[1], 0, 0, 0);
             }
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
@@ -381,7 +380,7 @@ __global__ __launch_bounds__(256) void edge_mlp_bwd_kernel(
 
     // ---- workgroup reduction of gW2 and of the BN1 sums (tile memory is free now)
     __syncthreads();
-    float *scr = &tiles[0][0][0][0];  // 4 waves x 4096 floats fit in the tile area
+    float *scr = &tiles[0][0][0][0];  // 8 waves x 4096 floats fit in the tile area
 #pragma unroll
     for (int cot = 0; cot < 2; ++cot)
 #pragma unroll
@@ -390,8 +389,12 @@ __global__ __launch_bounds__(256) void edge_mlp_bwd_kernel(
             for (int r = 0; r < 16; ++r)
                 scr[wave * 4096 + (cot * 32 + mfma32_row(r, h)) * 64 + cit * 32 + i32] = accW[cot][cit][r];
     __syncthreads();
-    for (int e = threadIdx.x; e < 4096; e += 256)
-        partial_dw2[(size_t)blockIdx.x * 4096 + e] = (scr[e] + scr[4096 + e]) + (scr[8192 + e] + scr[12288 + e]);
+    for (int e = threadIdx.x; e < 4096; e += 512) {
+        float t = 0.0f;
+#pragma unroll
+        for (int w = 0; w < MLP_BWD_WAVES; ++w) t += scr[w * 4096 + e];
+        partial_dw2[(size_t)blockIdx.x * 4096 + e] = t;
+    }
     __syncthreads();
     double *red = reinterpret_cast<double *>(scr);  // [wave][2][64]
 #pragma unroll
@@ -409,7 +412,7 @@ __global__ __launch_bounds__(256) void edge_mlp_bwd_kernel(
         for (int i = 0; i < 2; ++i) {
             double s = red[(0 * 2 + i) * 64 + lane];
 #pragma unroll
-            for (int w = 1; w < MLP_WAVES; ++w) s += red[(w * 2 + i) * 64 + lane];
+            for (int w = 1; w < MLP_BWD_WAVES; ++w) s += red[(w * 2 + i) * 64 + lane];
             partial_bn1[((size_t)blockIdx.x * 2 + i) * 64 + lane] = s;
         }
     }
@@ -429,7 +432,7 @@ void launch_edge_mlp_bwd(const float *TP, const float *TQ, const int32_t *idx, i
                          int training, const float *gy, const float *y, const float *usel2, float *dv1, float *dvsum,
                          float *partial_dw2, double *partial_bn1, hipStream_t st)
 {
-    hipLaunchKernelGGL(edge_mlp_bwd_kernel, dim3(mlp_grid(P)), dim3(256), 0, st, TP, TQ, idx, N, k, P, stats1, stats2,
+    hipLaunchKernelGGL(edge_mlp_bwd_kernel, dim3(mlp_grid(P)), dim3(64 * MLP_BWD_WAVES), 0, st, TP, TQ, idx, N, k, P, stats1, stats2,
                        cc2, w2, slope, training, gy, y, usel2, dv1, dvsum, partial_dw2, partial_bn1);
 }
 
