@@ -244,20 +244,13 @@ __global__ __launch_bounds__(512) void edge_mlp_bwd_kernel(
     double sb[2] = {0.0, 0.0}, sg[2] = {0.0, 0.0};  // BN1: sum dv1, sum dv1 * uhat1
 
     const PointIter it = point_iter(P, wave, MLP_BWD_WAVES);
-    // index rows two points ahead, table rows one point ahead (see the forward)
+    // index row one point ahead; the other wave of the SIMD covers the latency of the table rows
     const int kk0 = k < 32 ? k : 32;
-    float pn[32], qn = 0.0f;
-    int nvnn = 0;
-    if (it.cur < it.end) {
-        const int nv0 = lane < kk0 ? idx[(size_t)it.cur * k + lane] : 0;
-        qn = TQ[(size_t)it.cur * EC + lane];
-        gather_rows(TP + (size_t)(it.cur / N) * N * EC, nv0, kk0, lane, pn);
-        if (it.cur + it.step < it.end) nvnn = lane < kk0 ? idx[(size_t)(it.cur + it.step) * k + lane] : 0;
-    }
+    int nvn = it.cur < it.end && lane < kk0 ? idx[(size_t)it.cur * k + lane] : 0;
     for (int pt = it.cur; pt < it.end; pt += it.step) {
         const int b = pt / N;
         const float *Pb = TP + (size_t)b * N * EC;
-        const float q = qn;
+        const float q = TQ[(size_t)pt * EC + lane];
         const int32_t *ip = idx + (size_t)pt * k;
         float uv[2], dvs[2];
         float dcol[2] = {0.0f, 0.0f};  // sum over the point's edges of dv1, per channel (for the centre term dD)
@@ -271,19 +264,11 @@ __global__ __launch_bounds__(512) void edge_mlp_bwd_kernel(
         }
         for (int j0 = 0; j0 < k; j0 += 32) {
             const int kk = k - j0 < 32 ? k - j0 : 32;
-            if (j0 == 0) {
-                stage_tile<true>(pn, q, kk, sc1g, sh1g, slope, tileA, tileU, lane);
-                const int ptn = pt + it.step;
-                if (ptn < it.end) {
-                    const int nvn = nvnn;
-                    qn = TQ[(size_t)ptn * EC + lane];
-                    gather_rows(TP + (size_t)(ptn / N) * N * EC, nvn, kk0, lane, pn);
-                    if (ptn + it.step < it.end) nvnn = lane < kk0 ? idx[(size_t)(ptn + it.step) * k + lane] : 0;
-                }
-            } else {
+            {
                 float p2[32];
-                const int nv = lane < kk ? ip[j0 + lane] : 0;
+                const int nv = j0 == 0 ? nvn : (lane < kk ? ip[j0 + lane] : 0);
                 gather_rows(Pb, nv, kk, lane, p2);
+                if (j0 == 0 && pt + it.step < it.end) nvn = lane < kk0 ? idx[(size_t)(pt + it.step) * k + lane] : 0;
                 stage_tile<true>(p2, q, kk, sc1g, sh1g, slope, tileA, tileU, lane);
             }
 
