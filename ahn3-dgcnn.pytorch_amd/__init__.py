@@ -8,5 +8,6 @@ The directory name is not a valid Python identifier; import it through the shim 
 from . import _lib  # noqa: F401
 from . import ops  # noqa: F401
 from .model import DGCNN, get_graph_feature, knn  # noqa: F401
+from . import blocks, optim  # noqa: F401,E402
 
-__all__ = ["DGCNN", "get_graph_feature", "knn", "ops"]
+__all__ = ["DGCNN", "get_graph_feature", "knn", "ops", "blocks", "optim"]

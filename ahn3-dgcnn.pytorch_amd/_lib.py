@@ -63,6 +63,12 @@ SIGNATURES = {
                                         _c_vp, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp]),
     "dgcnn_bn_lrelu_max_bwd": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_int, _c_int, _c_f, _c_vp, _c_vp,
                                         _c_vp, _c_vp, _c_sz, _c_vp]),
+    "dgcnn_seg_loss_workspace_bytes": (_c_sz, [_c_int, _c_int]),
+    "dgcnn_seg_loss": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_i64, _c_i64, _c_i64, _c_vp, _c_vp, _c_f, _c_vp, _c_vp,
+                                _c_vp, _c_vp, _c_sz, _c_vp]),
+    "dgcnn_seg_predict": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_i64, _c_i64, _c_i64, _c_f, _c_int, _c_vp, _c_vp, _c_vp]),
+    "dgcnn_adam_step": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_sz, _c_f, _c_f, _c_f, _c_f, _c_f, _c_int, _c_vp]),
+    "dgcnn_cast_f64_f32": (_c_int, [_c_vp, _c_sz, _c_vp]),
     "dgcnn_profile_enable": (_c_int, [_c_int]),
     "dgcnn_profile_resume": (_c_int, []),
     "dgcnn_profile_regions": (_c_int, []),

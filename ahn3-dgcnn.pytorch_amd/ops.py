@@ -347,3 +347,96 @@ def to_point_major_autograd(x):
 
 def from_point_major_autograd(x_pm):
     return _FromPointMajor.apply(x_pm) if x_pm.requires_grad else from_point_major(x_pm)
+
+
+# ------------------------------------------------------------------------------------------------
+# The steps either side of DGCNN.forward in the reference's loops
+def _logit_strides(logits):
+    if logits.dim() != 3:
+        raise ValueError("logits must be [B, num_classes, N] (what DGCNN.forward returns)")
+    _lib.require_device(logits, "logits")
+    if logits.dtype != torch.float32:
+        raise TypeError("logits must be float32, got %s" % logits.dtype)
+    return logits.stride()
+
+
+class _SegLoss(torch.autograd.Function):
+    """softmax -> (training mask) -> cal_loss -> arg-max in one pass; the pass also leaves d loss / d logits."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, mask, smoothing):
+        B, C, N = logits.shape
+        sb, sc, sn = _logit_strides(logits)
+        lib = _lib.load()
+        dev = logits.device
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        grad = torch.empty_strided(logits.shape, logits.stride(), dtype=torch.float32, device=dev)
+        pred = torch.empty((B, N), dtype=torch.int64, device=dev)
+        ws_bytes = lib.dgcnn_seg_loss_workspace_bytes(B, N)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        _lib.check(lib.dgcnn_seg_loss(_lib.ptr(logits), B, N, C, sb, sc, sn, _lib.ptr(labels),
+                                      _lib.ptr(mask) if mask is not None else None, smoothing, _lib.ptr(loss),
+                                      _lib.ptr(grad), _lib.ptr(pred), _lib.ptr(ws), ws_bytes, _lib.stream_ptr(dev)),
+                   "dgcnn_seg_loss")
+        ctx.save_for_backward(grad)
+        ctx.mark_non_differentiable(pred)
+        return loss, pred
+
+    @staticmethod
+    def backward(ctx, gloss, _gpred):
+        (grad,) = ctx.saved_tensors
+        return grad * gloss, None, None, None
+
+
+def seg_loss(logits, labels, mask=None, smoothing=0.2):
+    """Loss and prediction of one training / validation step of the reference, from the logits DGCNN.forward
+    returns ([B, num_classes, N], any dense strides):
+
+        p = softmax(logits, dim=1)                                   train.py:180 / :267
+        (mask given) rows (p, 0) with the label where mask != 0, (0, .., 0, 1) with label num_classes elsewhere
+                                                                     train.py:182-196
+        loss = cal_loss(rows, labels, smoothing=True)                util.py:17-34 (eps = `smoothing`; 0 = cross entropy)
+        pred = rows.max(dim=-1)[1]                                   train.py:201 / :271
+
+    labels: integer (or the reference's float64) [B, N]; mask: bool / uint8 / float [B, N] or None.
+    Returns (loss: 0-d tensor with autograd to the logits, pred: int64 [B, N])."""
+    B, C, N = logits.shape
+    dev = logits.device
+    labels = labels.to(device=dev, dtype=torch.int64).reshape(B, N).contiguous()
+    if mask is not None:
+        mask = (mask.to(device=dev) != 0).to(torch.uint8).reshape(B, N).contiguous()
+    # overlapping / broadcast strides cannot hold a gradient of the same layout
+    if not (logits.is_contiguous() or logits.permute(0, 2, 1).is_contiguous()):
+        logits = logits.contiguous()
+    return _SegLoss.apply(logits, labels, mask, float(smoothing))
+
+
+def seg_predict(logits, min_class_confidence=0.0, unclassified=31):
+    """Inference post-step (test.py:123-127, :308-311): softmax over the classes, maximum, arg-max, and the label
+    `unclassified` wherever the maximum probability is below `min_class_confidence`.
+    logits [B, num_classes, N] -> (pred int64 [B, N], prob float32 [B, N])."""
+    B, C, N = logits.shape
+    logits = logits.detach()
+    sb, sc, sn = _logit_strides(logits)
+    lib = _lib.load()
+    dev = logits.device
+    pred = torch.empty((B, N), dtype=torch.int64, device=dev)
+    prob = torch.empty((B, N), dtype=torch.float32, device=dev)
+    _lib.check(lib.dgcnn_seg_predict(_lib.ptr(logits), B, N, C, sb, sc, sn, float(min_class_confidence),
+                                     int(unclassified), _lib.ptr(pred), _lib.ptr(prob), _lib.stream_ptr(dev)),
+               "dgcnn_seg_predict")
+    return pred, prob
+
+
+def points_to_float(points):
+    """float64 point block(s) on the HIP device -> float32, same shape (the `.float()` of train.py:176 / test.py:119;
+    the permute around it is a view and stays one)."""
+    _lib.require_device(points, "points")
+    if points.dtype != torch.float64:
+        raise TypeError("points must be float64, got %s" % points.dtype)
+    src = points if points.is_contiguous() else points.contiguous()
+    out = torch.empty(src.shape, dtype=torch.float32, device=src.device)
+    lib = _lib.load()
+    _lib.check(lib.dgcnn_cast_f64_f32(_lib.ptr(src), src.numel(), _lib.ptr(out), _lib.stream_ptr(src.device)),
+               "dgcnn_cast_f64_f32")
+    return out

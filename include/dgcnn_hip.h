@@ -151,6 +151,37 @@ int dgcnn_bn_lrelu_max_bwd(const float *x, const float *gg, const int32_t *arg, 
                            int training, float slope, float *gx, float *gweight, float *gbias, void *workspace,
                            size_t workspace_bytes, void *stream);
 
+/* ---- the steps either side of DGCNN.forward in the reference's loops ("next") -------
+ * Logits are addressed by element strides, (b, c, n) at b*stride_b + c*stride_c + n*stride_n, so both the
+ * [B, classes, N] tensor DGCNN.forward returns and a point-major [B, N, classes] buffer are read in place.
+ *
+ * dgcnn_seg_loss: one training / validation loss evaluation of the reference -- softmax over the classes
+ * (train.py:180, :267), cal_loss(pred = the PROBABILITIES, gold, smoothing) = label-smoothed cross entropy through a
+ * second log_softmax (util.py:17-34; smoothing = 0.2 there, 0 gives plain cross entropy) averaged over all B*N
+ * points, and the arg-max prediction (train.py:201, :271).  mask (optional, uint8 [B*N]) selects the points that
+ * take part, as train.py:182-196 does it: rows get one extra column, (p, 0) with the point's label where mask != 0
+ * and (0, ..., 0, 1) with label `classes` elsewhere.  loss: one float; grad_logits (same strides as logits) =
+ * d loss / d logits, computed in the same pass; pred int64 [B*N].  classes <= 32. */
+size_t dgcnn_seg_loss_workspace_bytes(int B, int N);
+int dgcnn_seg_loss(const float *logits, int B, int N, int classes, int64_t stride_b, int64_t stride_c,
+                   int64_t stride_n, const int64_t *labels, const uint8_t *mask, float smoothing, float *loss,
+                   float *grad_logits, int64_t *pred, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Inference post-step (test.py:123-127, :308-311): softmax over the classes, maximum and arg-max; points whose
+ * maximum probability is below min_confidence get the label `unclassified` (31 in the reference).  pred int64
+ * [B*N]; prob (optional) fp32 [B*N] = the maximum probability. */
+int dgcnn_seg_predict(const float *logits, int B, int N, int classes, int64_t stride_b, int64_t stride_c,
+                      int64_t stride_n, float min_confidence, int unclassified, int64_t *pred, float *prob,
+                      void *stream);
+
+/* One torch.optim.Adam step (train.py:118: lr, betas, eps, L2 weight_decay added to the gradient, no amsgrad) on flat
+ * fp32 buffers of n elements; step counts from 1. */
+int dgcnn_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n, float lr, float beta1,
+                    float beta2, float eps, float weight_decay, int step, void *stream);
+
+/* float64 -> float32 of a point block (the `.float()` of train.py:176 / test.py:119 on the device). */
+int dgcnn_cast_f64_f32(const double *x, size_t n, float *y, void *stream);
+
 /* ---- measurement hook (bench.py) ----------------------------------------------------------------------
  * HIP events around the large kernels of the path, recorded on the stream each kernel is launched on.  Regions
  * (dgcnn_profile_region_name): the fp16 threshold pass, the fp16 filter and the exact refine of dgcnn_knn, the

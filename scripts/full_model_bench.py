@@ -5,7 +5,6 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import torch
-import torch.nn.functional as F
 from ahn3_dgcnn_pytorch_amd import DGCNN
 
 dev = torch.device("cuda:0")
@@ -42,17 +41,14 @@ if mode == "eval":
     sys.exit(0)
 
 m.train()
-opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=1e-4)  # train.py:118
+from ahn3_dgcnn_pytorch_amd import ops
+from ahn3_dgcnn_pytorch_amd.optim import FlatAdam
+opt = FlatAdam(m.parameters(), lr=1e-3, weight_decay=1e-4)  # train.py:118 on one flat buffer
 
 
 def step():
-    opt.zero_grad(set_to_none=True)
-    logits = m(x)                                  # [B, 5, N]
-    pred = F.softmax(logits, dim=1).permute(0, 2, 1).reshape(-1, 5)   # the reference's softmax-then-cal_loss (train.py:180,197)
-    gold = labels.reshape(-1)
-    one_hot = torch.zeros_like(pred).scatter(1, gold.view(-1, 1), 1)
-    one_hot = one_hot * 0.8 + (1 - one_hot) * 0.2 / 4
-    loss = -(one_hot * F.log_softmax(pred, dim=1)).sum(dim=1).mean()  # util.py:17-34
+    opt.zero_grad()
+    loss, _pred = ops.seg_loss(m(x), labels)       # softmax -> cal_loss -> arg-max (train.py:267-271) in one kernel
     loss.backward()
     opt.step()
 

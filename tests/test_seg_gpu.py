@@ -1,0 +1,185 @@
+"""Parity of the steps either side of DGCNN.forward with their CPU restatement
+(oracle/seg_ref.py): loss within 1e-6, d loss / d logits within 1e-5 of its scale 1 / (B N), predictions exact,
+Adam within 1e-6 after ten steps, float64 -> float32 exact."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _case(B, C, N, seed, scale=3.0):
+    g = torch.Generator().manual_seed(seed)
+    z = torch.randn(B, C, N, generator=g) * scale
+    lab = torch.randint(0, C, (B, N), generator=g)
+    msk = (torch.rand(B, N, generator=g) < 0.3)
+    return z, lab, msk
+
+
+@pytest.mark.parametrize("B,C,N", [(2, 5, 1000), (1, 5, 257), (3, 8, 64), (2, 13, 300), (1, 32, 130), (2, 2, 77)])
+@pytest.mark.parametrize("masked", [False, True])
+@pytest.mark.parametrize("eps", [0.2, 0.0])
+def test_seg_loss_matches_reference_ops(B, C, N, masked, eps):
+    from ahn3_dgcnn_pytorch_amd import ops
+    from oracle import seg_ref
+    z, lab, msk = _case(B, C, N, 11 * B + C + N)
+    zr = z.clone().requires_grad_(True)
+    loss_r, pred_r = seg_ref.step_loss(zr, lab, msk if masked else None, eps=eps)
+    loss_r.backward()
+    zd = z.to(_dev()).requires_grad_(True)
+    loss, pred = ops.seg_loss(zd, lab.double().to(_dev()), msk.to(_dev()) if masked else None, smoothing=eps)
+    (loss * 1.0).backward()
+    assert abs(loss.item() - loss_r.item()) <= 1e-6 * max(1.0, abs(loss_r.item()))
+    assert torch.equal(pred.cpu(), pred_r)
+    scale = 1.0 / (B * N)
+    assert (zd.grad.cpu() - zr.grad).abs().max().item() <= 1e-5 * scale
+
+
+def test_seg_loss_reads_point_major_logits_in_place():
+    from ahn3_dgcnn_pytorch_amd import ops
+    from oracle import seg_ref
+    z, lab, _ = _case(2, 5, 500, 3)
+    z_pm = z.permute(0, 2, 1).contiguous().to(_dev())          # [B, N, C] memory
+    view = z_pm.permute(0, 2, 1).requires_grad_(True)           # [B, C, N] view of it
+    loss, pred = ops.seg_loss(view, lab.to(_dev()))
+    loss.backward()
+    zr = z.clone().requires_grad_(True)
+    loss_r, pred_r = seg_ref.step_loss(zr, lab)
+    loss_r.backward()
+    assert abs(loss.item() - loss_r.item()) <= 1e-6
+    assert torch.equal(pred.cpu(), pred_r)
+    assert (view.grad.cpu() - zr.grad).abs().max().item() <= 1e-5 / 1000
+
+
+def test_seg_loss_scales_with_upstream_gradient():
+    from ahn3_dgcnn_pytorch_amd import ops
+    z, lab, _ = _case(1, 5, 300, 5)
+    a = z.to(_dev()).requires_grad_(True)
+    b = z.to(_dev()).requires_grad_(True)
+    ops.seg_loss(a, lab.to(_dev()))[0].backward()
+    (ops.seg_loss(b, lab.to(_dev()))[0] * 4.0).backward()
+    assert torch.allclose(b.grad, 4.0 * a.grad, rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("C,conf", [(5, 0.0), (5, 0.6), (13, 0.3)])
+def test_seg_predict_matches_reference_ops(C, conf):
+    from ahn3_dgcnn_pytorch_amd import ops
+    from oracle import seg_ref
+    z, _, _ = _case(2, C, 700, 21 + C, scale=1.5)
+    pred_r, val_r = seg_ref.predict_step(z, conf)
+    pred, prob = ops.seg_predict(z.to(_dev()), conf, unclassified=seg_ref.UNCLASSIFIED)
+    # a probability within rounding of the threshold may fall either side: exclude those points
+    safe = (val_r - conf).abs() > 1e-6
+    assert torch.equal(pred.cpu()[safe], pred_r[safe])
+    assert (prob.cpu() - val_r).abs().max().item() <= 1e-6
+    if conf > 0:
+        assert (pred.cpu() == seg_ref.UNCLASSIFIED).any()
+
+
+def test_bad_arguments_raise():
+    from ahn3_dgcnn_pytorch_amd import _lib, ops
+    z = torch.randn(1, 40, 10, device=_dev())
+    with pytest.raises(_lib.HipExtensionError):
+        ops.seg_predict(z)                                   # more than 32 classes
+    with pytest.raises(_lib.HipExtensionError):
+        ops.seg_loss(torch.randn(1, 5, 10), torch.zeros(1, 10))   # CPU tensor: no fallback
+
+
+def test_flat_adam_matches_torch_adam():
+    from ahn3_dgcnn_pytorch_amd.optim import FlatAdam
+    g = torch.Generator().manual_seed(0)
+    shapes = [(64, 8, 1, 1), (64,), (64,), (5, 256, 1), (1000, 3)]
+    ref = [torch.nn.Parameter(torch.randn(s, generator=g)) for s in shapes]
+    mine = [torch.nn.Parameter(p.detach().clone().to(_dev())) for p in ref]
+    opt_r = torch.optim.Adam(ref, lr=1e-3, weight_decay=1e-4)          # train.py:118
+    opt = FlatAdam(mine, lr=1e-3, weight_decay=1e-4)
+    for step in range(10):
+        opt_r.zero_grad()
+        opt.zero_grad()
+        for pr, pm in zip(ref, mine):
+            gr = torch.randn(pr.shape, generator=g) * (10.0 ** (step % 3 - 1))
+            pr.grad = gr.clone()
+            pm.grad.copy_(gr.to(_dev()))
+        opt_r.step()
+        opt.step()
+    for pr, pm in zip(ref, mine):
+        assert (pm.detach().cpu() - pr.detach()).abs().max().item() <= 1e-6
+    assert all(pm.data_ptr() >= opt.flat.data_ptr() for pm in mine)     # the parameters are views of the flat buffer
+
+
+def test_points_to_float_is_exact():
+    from ahn3_dgcnn_pytorch_amd import ops
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(3, 1001, 4, generator=g, dtype=torch.float64) * 30.0
+    y = ops.points_to_float(x.to(_dev()))
+    assert torch.equal(y.cpu(), x.float())
+
+
+def test_training_step_with_device_loss_and_flat_adam():
+    """fwd -> seg_loss -> bwd -> FlatAdam.step on a small model equals the same step with the reference's loss ops
+    and torch.optim.Adam (both on the HIP model: the point is the loss + optimizer path)."""
+    import copy
+    from ahn3_dgcnn_pytorch_amd import DGCNN, ops
+    from ahn3_dgcnn_pytorch_amd.optim import FlatAdam
+    from oracle import seg_ref
+    from param_fill import fill_module
+    torch.manual_seed(0)
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(2, 4, 300, generator=g).to(_dev())
+    lab = torch.randint(0, 5, (2, 300), generator=g).to(_dev())
+    a = DGCNN(5, 4, 8, dropout=0.0, emb_dims=1024, cuda=True)   # conv7 fixes emb_dims at 1024 (model.py:134)
+    fill_module(a)
+    b = copy.deepcopy(a)
+    a.train()
+    b.train()
+    opt_a = torch.optim.Adam(a.parameters(), lr=1e-3, weight_decay=1e-4)
+    opt_b = FlatAdam(b.parameters(), lr=1e-3, weight_decay=1e-4)
+    for _ in range(2):
+        opt_a.zero_grad()
+        la, _ = seg_ref.step_loss(a(x), lab)
+        la.backward()
+        opt_a.step()
+        opt_b.zero_grad()
+        lb, _ = ops.seg_loss(b(x), lab)
+        lb.backward()
+        opt_b.step()
+        assert abs(la.item() - lb.item()) <= 1e-5
+    for (na, pa), (nb, pb) in zip(a.named_parameters(), b.named_parameters()):
+        assert na == nb
+        # Adam's first steps move every weight by ~lr whatever the size of its gradient, so a weight whose gradient is
+        # rounding noise may differ by up to 2 lr per step: compare the mean
+        assert (pa - pb).abs().mean().item() <= 2e-5, na
+
+
+def test_model_input_is_a_view_of_point_major_memory():
+    from ahn3_dgcnn_pytorch_amd import blocks
+    pts = torch.rand(2, 100, 4, dtype=torch.float64)
+    x = blocks.to_model_input(pts)
+    assert x.shape == (2, 4, 100) and x.dtype == torch.float32 and x.is_cuda
+    assert x.permute(0, 2, 1).is_contiguous()
+    assert torch.equal(x.cpu(), pts.permute(0, 2, 1).float())
+
+
+def test_classify_block_matches_reference_steps():
+    import numpy as np
+    from ahn3_dgcnn_pytorch_amd import DGCNN, blocks
+    from oracle import seg_ref
+    from param_fill import fill_module
+    m = DGCNN(5, 4, 8, dropout=0.5, emb_dims=1024, cuda=True)
+    fill_module(m)
+    rs = np.random.RandomState(3)
+    X = rs.rand(400, 4) * np.array([30.0, 30.0, 20.0, 20.0]) + np.array([1000.0, 2000.0, 0.0, 0.0])
+    X0 = X.copy()
+    pred = blocks.classify_block(m, X, min_class_confidence=0.3)
+    assert np.array_equal(X, X0) and pred.shape == (400, 1)
+    # the same steps with the reference's tensor ops on the model's logits
+    Xl = X - np.array([X[:, 0].min(), X[:, 1].min(), 0.0, 0.0])
+    m.eval()
+    with torch.no_grad():
+        logits = m(torch.tensor(Xl[:, :, np.newaxis]).permute(2, 1, 0).float().cuda()).cpu()
+    pred_r, val_r = seg_ref.predict_step(logits, 0.3)
+    safe = ((val_r - 0.3).abs() > 1e-5).reshape(-1).numpy()
+    assert np.array_equal(pred.reshape(-1)[safe], pred_r.reshape(-1).numpy()[safe])
