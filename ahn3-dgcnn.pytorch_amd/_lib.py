@@ -63,6 +63,9 @@ SIGNATURES = {
                                         _c_vp, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp]),
     "dgcnn_bn_lrelu_max_bwd": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_int, _c_int, _c_f, _c_vp, _c_vp,
                                         _c_vp, _c_vp, _c_sz, _c_vp]),
+    "dgcnn_embed_max_bwd_prepare": (_c_int, [_c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_int, _c_int, _c_f, _c_vp, _c_vp, _c_vp,
+                                             _c_vp, _c_vp, _c_vp]),
+    "dgcnn_embed_max_bwd_scatter": (_c_int, [_c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_int, _c_int, _c_vp, _c_vp]),
     "dgcnn_seg_loss_workspace_bytes": (_c_sz, [_c_int, _c_int]),
     "dgcnn_seg_loss": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_i64, _c_i64, _c_i64, _c_vp, _c_vp, _c_f, _c_vp, _c_vp,
                                 _c_vp, _c_vp, _c_sz, _c_vp]),

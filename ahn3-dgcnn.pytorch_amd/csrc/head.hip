@@ -37,22 +37,39 @@ __global__ __launch_bounds__(256) void colstats_kernel(const float *__restrict__
     }
 }
 
+// sum over the chunks of partial[chunk][2][C] for column c: the four waves of the workgroup take every fourth chunk
+// (independent loads in flight instead of one serial chain of `nchunk` dependent adds), then fold in a fixed order
+__device__ __forceinline__ void fold_chunks(const double *__restrict__ partial, int nchunk, int C, int c, bool live,
+                                            double (*red)[2][64], double &s0, double &s1)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double a = 0.0, b = 0.0;
+    if (live)
+        for (int g = wave; g < nchunk; g += 4) {
+            a += partial[((size_t)g * 2 + 0) * C + c];
+            b += partial[((size_t)g * 2 + 1) * C + c];
+        }
+    red[wave][0][lane] = a;
+    red[wave][1][lane] = b;
+    __syncthreads();
+    s0 = (red[0][0][lane] + red[1][0][lane]) + (red[2][0][lane] + red[3][0][lane]);
+    s1 = (red[0][1][lane] + red[1][1][lane]) + (red[2][1][lane] + red[3][1][lane]);
+}
+
 // stats[4][C] = mean, rstd, sc = gamma rstd, sh = beta - mean sc; running statistics updated when training.
-// One thread per column; the chunk partials are added in index order (deterministic).
-__global__ void colstats_finalize_kernel(const double *__restrict__ partial, int nchunk, int P, int C, int training,
+// One workgroup of four waves per 64 columns (lane = column); fixed summation order (deterministic).
+__global__ __launch_bounds__(256) void colstats_finalize_kernel(const double *__restrict__ partial, int nchunk, int P, int C, int training,
                                          const float *__restrict__ gamma, const float *__restrict__ beta,
                                          float *__restrict__ rmean, float *__restrict__ rvar, float eps,
                                          float momentum, float *__restrict__ stats)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    __shared__ double red[4][2][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    double s = 0.0, ss = 0.0;
+    if (training) fold_chunks(partial, nchunk, C, c, c < C, red, s, ss);
+    if (c >= C || threadIdx.x >= 64) return;
     float mean, var;
     if (training) {
-        double s = 0.0, ss = 0.0;
-        for (int g = 0; g < nchunk; ++g) {
-            s += partial[((size_t)g * 2 + 0) * C + c];
-            ss += partial[((size_t)g * 2 + 1) * C + c];
-        }
         const double m = s / P;
         double v = ss / P - m * m;
         if (v < 0.0) v = 0.0;
@@ -125,16 +142,14 @@ __global__ __launch_bounds__(256) void bn_lrelu_bwd_reduce_kernel(const float *_
 }
 
 // gbeta, ggamma and the two mean terms cc[2][C] (zero in eval mode)
-__global__ void bn_bwd_finalize_cols_kernel(const double *__restrict__ partial, int nchunk, int P, int C, int training,
+__global__ __launch_bounds__(256) void bn_bwd_finalize_cols_kernel(const double *__restrict__ partial, int nchunk, int P, int C, int training,
                                             float *__restrict__ ggamma, float *__restrict__ gbeta, float *__restrict__ cc)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double sb = 0.0, sg = 0.0;
-    for (int g = 0; g < nchunk; ++g) {
-        sb += partial[((size_t)g * 2 + 0) * C + c];
-        sg += partial[((size_t)g * 2 + 1) * C + c];
-    }
+    __shared__ double red[4][2][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    double sb, sg;
+    fold_chunks(partial, nchunk, C, c, c < C, red, sb, sg);
+    if (c >= C || threadIdx.x >= 64) return;
     gbeta[c] = (float)sb;
     ggamma[c] = (float)sg;
     cc[c] = training ? (float)(sb / P) : 0.0f;
@@ -274,6 +289,83 @@ __global__ void colmax_bwd_apply_kernel(const float *__restrict__ x, const int32
     reinterpret_cast<float4 *>(gx)[t] = o;
 }
 
+
+// ---- conv6 -> bn6 -> LeakyReLU -> max, backward WITHOUT the dense [P][C] gradient -------------------------------
+// dL/du[p][c] = A_c + B_c u[p][c] + (s[b][c] at the winning point of (b, c)): the BatchNorm mean terms are affine in
+// u = cat . W^T, so the two 1024-wide products of the backward collapse to 192-wide ones (ops.py: _EmbedMax):
+//   dcat = 1 (A W)^T + cat (W^T diag(B) W) + [winners]      dW = A (sum cat)^T + diag(B) W (cat^T cat) + [winners]
+// This kernel turns the winners' pre-activations uwin [B][C] and dL/dg into gbias, gweight, A, B and s = sc dv.
+__global__ void embed_bwd_coef_kernel(const float *__restrict__ uwin, const float *__restrict__ gg,
+                                      const float *__restrict__ stats, int B, int N, int C, int training, float slope,
+                                      float *__restrict__ gweight, float *__restrict__ gbias, float *__restrict__ coefA,
+                                      float *__restrict__ coefB, float *__restrict__ s)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float mean = stats[c], rstd = stats[(size_t)C + c], sc = stats[2 * (size_t)C + c], sh = stats[3 * (size_t)C + c];
+    double sb = 0.0, sg = 0.0;
+    for (int b = 0; b < B; ++b) {
+        const float u = uwin[(size_t)b * C + c];
+        const float dv = gg[(size_t)b * C + c] * (__builtin_fmaf(u, sc, sh) > 0.0f ? 1.0f : slope);
+        s[(size_t)b * C + c] = sc * dv;
+        sb += (double)dv;
+        sg += (double)dv * (double)((u - mean) * rstd);
+    }
+    gbias[c] = (float)sb;
+    gweight[c] = (float)sg;
+    const double P = (double)B * N;
+    const double Bc = training ? -(double)sc * (sg / P) * (double)rstd : 0.0;
+    coefB[c] = (float)Bc;
+    coefA[c] = training ? (float)(-(double)sc * (sb / P) - Bc * (double)mean) : 0.0f;
+}
+
+// dcat[b N + arg[b][c]][f] += s[b][c] W[c][f] over the C winners of batch element b, race-free and in a fixed order:
+// every workgroup sorts the (point, channel) keys of its batch element in LDS, takes a contiguous share of the sorted
+// list moved to the next point boundary at both ends, and walks it with one thread per column f.
+constexpr int EMB_SHARES = 8;
+__global__ __launch_bounds__(256) void embed_bwd_scatter_kernel(const int32_t *__restrict__ arg, const float *__restrict__ s,
+                                                                const float *__restrict__ W, int N, int C, int F, int C2,
+                                                                float *__restrict__ dcat)
+{
+    extern __shared__ unsigned long long keys[];  // C2 = C rounded up to a power of two
+    const int b = blockIdx.y;
+    for (int i = threadIdx.x; i < C2; i += 256)
+        keys[i] = i < C ? ((unsigned long long)(unsigned)arg[(size_t)b * C + i] << 32) | (unsigned)i : ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= C2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < C2; i += 256) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const unsigned long long a = keys[i], c = keys[l];
+                    const bool up = (i & k) == 0;
+                    if ((a > c) == up) {
+                        keys[i] = c;
+                        keys[l] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    const int per = (C + EMB_SHARES - 1) / EMB_SHARES;
+    int i0 = blockIdx.x * per, i1 = i0 + per < C ? i0 + per : C;
+    // a point's run belongs to the share it starts in
+    while (i0 > 0 && i0 < C && (keys[i0] >> 32) == (keys[i0 - 1] >> 32)) ++i0;
+    while (i1 > 0 && i1 < C && (keys[i1] >> 32) == (keys[i1 - 1] >> 32)) ++i1;
+    for (int f = threadIdx.x; f < F; f += 256) {
+        float acc = 0.0f;
+        for (int i = i0; i < i1; ++i) {
+            const unsigned long long key = keys[i];
+            const int c = (int)(unsigned)key, n = (int)(key >> 32);
+            acc = __builtin_fmaf(s[(size_t)b * C + c], W[(size_t)c * F + f], acc);
+            if (i + 1 == i1 || (int)(keys[i + 1] >> 32) != n) {
+                dcat[((size_t)b * N + n) * F + f] += acc;
+                acc = 0.0f;
+            }
+        }
+    }
+}
+
 static int head_chunks(int P) { return ceil_div(P, HEAD_ROWS_PER_BLOCK); }
 
 }  // namespace dgcnn
@@ -300,7 +392,7 @@ extern "C" int dgcnn_bn_lrelu_fwd(const float *x, int P, int C, const dgcnn_bn_p
     const int nchunk = head_chunks(P);
     if (training)
         hipLaunchKernelGGL(colstats_kernel, dim3(ceil_div(C, 64), nchunk), dim3(256), 0, st, x, P, C, partial);
-    hipLaunchKernelGGL(colstats_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, partial, nchunk, P, C, training,
+    hipLaunchKernelGGL(colstats_finalize_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, st, partial, nchunk, P, C, training,
                        bn->weight, bn->bias, bn->running_mean, bn->running_var, eps, momentum, stats);
     const size_t n4 = (size_t)P * C / 4;
     hipLaunchKernelGGL(bn_lrelu_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, x, stats, C, slope, n4, y);
@@ -321,7 +413,7 @@ extern "C" int dgcnn_bn_lrelu_bwd(const float *x, const float *y, const float *g
     float *cc = (float *)((char *)workspace + align_up((size_t)nchunk * 2 * C * sizeof(double), 256));
     hipLaunchKernelGGL(bn_lrelu_bwd_reduce_kernel, dim3(ceil_div(C, 64), nchunk), dim3(256), 0, st, x, y, gy, stats, P, C,
                        slope, partial);
-    hipLaunchKernelGGL(bn_bwd_finalize_cols_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, partial, nchunk, P, C,
+    hipLaunchKernelGGL(bn_bwd_finalize_cols_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, st, partial, nchunk, P, C,
                        training, gweight, gbias, cc);
     const size_t n4 = (size_t)P * C / 4;
     hipLaunchKernelGGL(bn_lrelu_bwd_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, x, y, gy, stats,
@@ -354,7 +446,7 @@ extern "C" int dgcnn_bn_lrelu_max_fwd(const float *x, int B, int N, int C, const
     const int nchunk = head_chunks(P);
     if (training)
         hipLaunchKernelGGL(colstats_kernel, dim3(ceil_div(C, 64), nchunk), dim3(256), 0, st, x, P, C, partial);
-    hipLaunchKernelGGL(colstats_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, partial, nchunk, P, C, training,
+    hipLaunchKernelGGL(colstats_finalize_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, st, partial, nchunk, P, C, training,
                        bn->weight, bn->bias, bn->running_mean, bn->running_var, eps, momentum, stats);
     if (hipMemsetAsync(keys, 0, (size_t)B * C * sizeof(hkey), st) != hipSuccess) DG_FAIL("dgcnn_bn_lrelu_max_fwd: memset failed");
     hipLaunchKernelGGL(colmax_kernel, dim3(ceil_div(C, 64), head_chunks(N), B), dim3(256), 0, st, x, stats, N, C, keys);
@@ -381,5 +473,31 @@ extern "C" int dgcnn_bn_lrelu_max_bwd(const float *x, const float *gg, const int
     hipLaunchKernelGGL(colmax_bwd_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, x, arg, stats, cc, dvb,
                        N, C, n4, gx);
     DG_CHECK_LAUNCH("dgcnn_bn_lrelu_max_bwd");
+    return 0;
+}
+
+extern "C" int dgcnn_embed_max_bwd_prepare(const float *uwin, const float *gg, const float *stats, int B, int N, int C,
+                                           int training, float slope, float *gweight, float *gbias, float *coef_a,
+                                           float *coef_b, float *s, void *stream)
+{
+    DG_REQUIRE(uwin && gg && stats && gweight && gbias && coef_a && coef_b && s, "dgcnn_embed_max_bwd_prepare: null pointer");
+    DG_REQUIRE(B > 0 && N > 0 && C > 0, "dgcnn_embed_max_bwd_prepare: bad shape B=%d N=%d C=%d", B, N, C);
+    hipLaunchKernelGGL(embed_bwd_coef_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, (hipStream_t)stream, uwin, gg, stats, B, N,
+                       C, training, slope, gweight, gbias, coef_a, coef_b, s);
+    DG_CHECK_LAUNCH("dgcnn_embed_max_bwd_prepare");
+    return 0;
+}
+
+extern "C" int dgcnn_embed_max_bwd_scatter(const int32_t *arg, const float *s, const float *w, int B, int N, int C, int F,
+                                           float *dcat, void *stream)
+{
+    DG_REQUIRE(arg && s && w && dcat, "dgcnn_embed_max_bwd_scatter: null pointer");
+    DG_REQUIRE(B > 0 && N > 0 && C > 0 && F > 0, "dgcnn_embed_max_bwd_scatter: bad shape B=%d N=%d C=%d F=%d", B, N, C, F);
+    DG_REQUIRE(C <= 8192, "dgcnn_embed_max_bwd_scatter: C=%d > 8192 unsupported", C);
+    int C2 = 1;
+    while (C2 < C) C2 <<= 1;
+    hipLaunchKernelGGL(embed_bwd_scatter_kernel, dim3(EMB_SHARES, B), dim3(256), (size_t)C2 * sizeof(unsigned long long),
+                       (hipStream_t)stream, arg, s, w, N, C, F, C2, dcat);
+    DG_CHECK_LAUNCH("dgcnn_embed_max_bwd_scatter");
     return 0;
 }

@@ -142,8 +142,9 @@ class DGCNN(nn.Module):
                 else:
                     # conv6 -> bn6 -> LeakyReLU -> max over the points (model.py:172-175): the activated [P, emb]
                     # tensor is never written (BN + LeakyReLU is monotone per column, see dgcnn_bn_lrelu_max_fwd)
-                    u6 = F.linear(cat.reshape(P, 192), self.conv6[0].weight.squeeze(-1))
-                    g = ops.bn_lrelu_max_rows(u6, self.bn6, B, N, self.training, NEG_SLOPE).view(B, 1, emb)
+                    # and its backward runs on 192-wide products only (ops._EmbedMax)
+                    g = ops.embed_max_rows(cat.reshape(P, 192), self.conv6[0].weight.squeeze(-1), self.bn6, B, N,
+                                           self.training, NEG_SLOPE).view(B, 1, emb)
                     if depth == 6:
                         out = g.transpose(1, 2).contiguous()
                     else:

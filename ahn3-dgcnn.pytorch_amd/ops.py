@@ -320,6 +320,92 @@ def bn_lrelu_max_rows(x, bn, B, N, training, slope=0.2):
     return g
 
 
+class _EmbedMax(torch.autograd.Function):
+    """conv6 -> bn6 -> LeakyReLU -> max over the points (model.py:172-175) as ONE autograd node, so that the backward
+    never forms the dense [B*N, emb] gradient: with u = cat W^T, dL/du[p, c] = A_c + B_c u[p, c] + (s[b, c] at the
+    winning point of (b, c)) -- the BatchNorm mean terms are affine in u -- hence
+
+        dcat = 1 (A W)^T + cat (W^T diag(B) W) + [winners: s W rows]
+        dW   = A (sum_p cat)^T + diag(B) W (cat^T cat) + [winners: s cat rows]
+
+    i.e. two 192 x 192 library products over the points instead of two 1024-wide ones (44 -> 8 GFLOP at B = 8,
+    N = 7000), and the pre-activation u ([B*N, emb], 229 MB there) is dropped right after the forward."""
+
+    @staticmethod
+    def forward(ctx, cat, w, weight, bias, rmean, rvar, B, N, training, eps, momentum, slope):
+        P, F_ = cat.shape
+        C = w.shape[0]
+        lib = _lib.load()
+        dev = cat.device
+        wd = w.detach()
+        u = torch.mm(cat.detach(), wd.t())                                   # plain library GEMM
+        wc, bc = weight.detach().contiguous(), bias.detach().contiguous()
+        bn = _bn_struct(wc, bc, rmean, rvar)
+        g = torch.empty((B, C), dtype=torch.float32, device=dev)
+        arg = torch.empty((B, C), dtype=torch.int32, device=dev)
+        stats = torch.empty((4, C), dtype=torch.float32, device=dev)
+        ws_bytes = lib.dgcnn_bn_lrelu_max_workspace_bytes(B, N, C)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        _lib.check(lib.dgcnn_bn_lrelu_max_fwd(_lib.ptr(u), B, N, C, ctypes.byref(bn), 1 if training else 0, eps, momentum,
+                                              slope, _lib.ptr(g), _lib.ptr(arg), _lib.ptr(stats), _lib.ptr(ws), ws_bytes,
+                                              _lib.stream_ptr(dev)), "dgcnn_bn_lrelu_max_fwd")
+        uwin = torch.gather(u.view(B, N, C), 1, arg.long().unsqueeze(1)).squeeze(1).contiguous()   # [B, C]
+        ctx.save_for_backward(cat, w, arg, stats, uwin)
+        ctx.cfg = (B, N, training, slope)
+        return g
+
+    @staticmethod
+    def backward(ctx, gg):
+        cat, w, arg, stats, uwin = ctx.saved_tensors
+        B, N, training, slope = ctx.cfg
+        P, F_ = cat.shape
+        C = w.shape[0]
+        lib = _lib.load()
+        dev = cat.device
+        st = _lib.stream_ptr(dev)
+        gg = gg.contiguous()
+        gw_bn = torch.empty((C,), dtype=torch.float32, device=dev)
+        gb_bn = torch.empty((C,), dtype=torch.float32, device=dev)
+        coef_a = torch.empty((C,), dtype=torch.float32, device=dev)
+        coef_b = torch.empty((C,), dtype=torch.float32, device=dev)
+        s = torch.empty((B, C), dtype=torch.float32, device=dev)
+        _lib.check(lib.dgcnn_embed_max_bwd_prepare(_lib.ptr(uwin), _lib.ptr(gg), _lib.ptr(stats), B, N, C,
+                                                   1 if training else 0, slope, _lib.ptr(gw_bn), _lib.ptr(gb_bn),
+                                                   _lib.ptr(coef_a), _lib.ptr(coef_b), _lib.ptr(s), st),
+                   "dgcnn_embed_max_bwd_prepare")
+        wd = w.detach().contiguous()
+        catd = cat.detach()
+        rows = (arg.long() + (torch.arange(B, device=dev) * N).unsqueeze(1)).reshape(-1)     # [B*C] global points
+        win_rows = catd.index_select(0, rows).view(B, C, F_)                                 # cat at the winners
+        dw = (s.unsqueeze(2) * win_rows).sum(0)                                              # [C, F], fixed order
+        if training:
+            wb = wd * coef_b.unsqueeze(1)                                                    # diag(B) W
+            dcat = torch.addmm(torch.mv(wd.t(), coef_a), catd, torch.mm(wd.t(), wb))         # 1 (A W)^T + cat M
+            dw.addmm_(wb, torch.mm(catd.t(), catd))                                          # + diag(B) W (cat^T cat)
+            dw.addr_(coef_a, catd.sum(0))                                                    # + A (sum cat)^T
+        else:
+            dcat = torch.zeros_like(catd)
+        _lib.check(lib.dgcnn_embed_max_bwd_scatter(_lib.ptr(arg), _lib.ptr(s), _lib.ptr(wd), B, N, C, F_, _lib.ptr(dcat), st),
+                   "dgcnn_embed_max_bwd_scatter")
+        return dcat, dw.view_as(w), gw_bn, gb_bn, None, None, None, None, None, None, None, None
+
+
+def embed_max_rows(cat, w, bn, B, N, training, slope=0.2):
+    """g[b] = max over the N points of batch element b of LeakyReLU(BatchNorm1d(cat W^T)): cat point-major rows
+    [B*N, F], w [emb, F] (conv6's weight) -> [B, emb]; `bn` is the nn.BatchNorm1d module (running statistics updated
+    in place when training)."""
+    cat = _f32c(cat, "cat")
+    if cat.shape[0] != B * N:
+        raise ValueError("cat must have B*N rows")
+    use_batch_stats = training or bn.running_mean is None
+    momentum = bn.momentum if bn.momentum is not None else 0.1
+    g = _EmbedMax.apply(cat, w, bn.weight, bn.bias, bn.running_mean, bn.running_var, int(B), int(N),
+                        bool(use_batch_stats), float(bn.eps), float(momentum), float(slope))
+    if training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    return g
+
+
 # ------------------------------------------------------------------------------------------------
 class _ToPointMajor(torch.autograd.Function):
     @staticmethod

@@ -151,6 +151,18 @@ int dgcnn_bn_lrelu_max_bwd(const float *x, const float *gg, const int32_t *arg, 
                            int training, float slope, float *gx, float *gweight, float *gbias, void *workspace,
                            size_t workspace_bytes, void *stream);
 
+/* Backward of conv6 -> bn6 -> LeakyReLU -> max without the dense [B*N][C] gradient (model.py:172-175; host side in
+ * ops.py, _EmbedMax).  With u = cat . W^T the BatchNorm mean terms of dL/du are affine in u, dL/du[p][c] = A_c +
+ * B_c u[p][c] + (s[b][c] at the winning point), so the backward needs 192-wide library products only.
+ * prepare: uwin [B][C] = u at the winners, gg = dL/dg [B][C], stats of the forward -> gweight, gbias [C] (BatchNorm
+ * gradients), coef_a, coef_b [C] (zero in eval mode), s [B][C].
+ * scatter: dcat[b*N + arg[b][c]][f] += s[b][c] * w[c][f] for every (b, c), w [C][F]; race-free, fixed order. */
+int dgcnn_embed_max_bwd_prepare(const float *uwin, const float *gg, const float *stats, int B, int N, int C, int training,
+                                float slope, float *gweight, float *gbias, float *coef_a, float *coef_b, float *s,
+                                void *stream);
+int dgcnn_embed_max_bwd_scatter(const int32_t *arg, const float *s, const float *w, int B, int N, int C, int F,
+                                float *dcat, void *stream);
+
 /* ---- the steps either side of DGCNN.forward in the reference's loops ("next") -------
  * Logits are addressed by element strides, (b, c, n) at b*stride_b + c*stride_c + n*stride_n, so both the
  * [B, classes, N] tensor DGCNN.forward returns and a point-major [B, N, classes] buffer are read in place.

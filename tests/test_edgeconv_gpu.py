@@ -284,6 +284,45 @@ def test_head_bn_lrelu_max_rows(B, N, C, train, device):
         assert int(bn_d.num_batches_tracked) == int(bn.num_batches_tracked) == 1
 
 
+@pytest.mark.parametrize("train", [True, False])
+@pytest.mark.parametrize("B,N,F,C", [(3, 700, 192, 64), (2, 1030, 192, 1024), (1, 130, 48, 200), (4, 257, 192, 1024)])
+def test_head_embed_max_rows(B, N, F, C, train, device):
+    # conv6 (1x1) -> bn6 -> LeakyReLU -> max over the points (model.py:172-175) as one node whose backward stays
+    # 192-wide: vs the PyTorch-CPU op sequence on the same rows
+    from ahn3_dgcnn_pytorch_amd import ops
+    import copy
+    g = torch.Generator().manual_seed(B * N + C + F)
+    cat = torch.randn(B * N, F, generator=g) * 1.5 + 0.5
+    w = torch.randn(C, F, generator=g) / F ** 0.5
+    R = cotangent((B, C), tag="embedmax")
+    bn = torch.nn.BatchNorm1d(C)
+    bn.load_state_dict({n: fill_tensor("head." + n, v) for n, v in bn.state_dict().items()})
+    with torch.no_grad():
+        bn.weight[::3] *= -1.0  # both monotone directions
+    bn.train(train)
+    bn_d = copy.deepcopy(bn).to(device)
+    cr, wr = cat.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = torch.nn.functional.leaky_relu(bn(torch.nn.functional.linear(cr, wr)), 0.2).view(B, N, C).max(dim=1)[0]
+    (yr * R).sum().backward()
+    cd, wd = cat.to(device).requires_grad_(True), w.to(device).requires_grad_(True)
+    yd = ops.embed_max_rows(cd, wd, bn_d, B, N, train, 0.2)
+    (yd * R.to(device)).sum().backward()
+    np.testing.assert_allclose(yd.detach().cpu().numpy(), yr.detach().numpy(), rtol=0, atol=1e-4)
+    for got, want, what in ((cd.grad, cr.grad, "gcat"), (wd.grad, wr.grad, "gw"), (bn_d.weight.grad, bn.weight.grad, "gweight"),
+                            (bn_d.bias.grad, bn.bias.grad, "gbias")):
+        got, want = got.cpu().numpy(), want.numpy()
+        assert np.abs(got - want).max() <= 1e-4 * max(1e-6, np.abs(want).max()), what
+    if train:
+        np.testing.assert_allclose(bn_d.running_mean.cpu().numpy(), bn.running_mean.numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(bn_d.running_var.cpu().numpy(), bn.running_var.numpy(), rtol=1e-5, atol=1e-6)
+        assert int(bn_d.num_batches_tracked) == int(bn.num_batches_tracked) == 1
+    # fixed order: a second backward gives the same bits
+    cd2, wd2 = cat.to(device).requires_grad_(True), w.to(device).requires_grad_(True)
+    bn_d2 = copy.deepcopy(bn).to(device)
+    (ops.embed_max_rows(cd2, wd2, bn_d2, B, N, train, 0.2) * R.to(device)).sum().backward()
+    assert torch.equal(cd2.grad, cd.grad)
+
+
 def test_step_is_graph_capturable(device):
     """every C-ABI call only enqueues work on the current stream: a whole kNN + block forward + backward step can be
     captured in a hipGraph and replayed.  Runs in a child process: a failed capture can
