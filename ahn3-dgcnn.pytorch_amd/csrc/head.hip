@@ -5,7 +5,7 @@
 // kernels are slow in this layout (945 + 689 us per layer at P = 56 000, C = 1024).
 //
 // Same statistics discipline as the EdgeConv kernels: fp64 partial sums, fixed reduction order.
-#include "edge_common.h"
+#include "edge_kernels.h"
 
 namespace dgcnn {
 
@@ -366,6 +366,158 @@ __global__ __launch_bounds__(256) void embed_bwd_scatter_kernel(const int32_t *_
     }
 }
 
+// ---- weight gradient of a 1x1 convolution on point-major rows: dW[M][Nn] = sum_p A[p][m] B[p][n] --------------------
+// (A = dL/d(conv output) [P][M], B = the conv input [P][Nn]).  The contraction runs over the P points and the output
+// is small, which library GEMMs handle poorly here (measured: 29 TFLOP/s for [256 x P] x [P x 512]); so split the
+// points: workgroup (tile, chunk) accumulates a 128 x 64 tile over its chunk of points on v_mfma_f32_32x32x2_f32 --
+// four waves take a quarter of the chunk each, operands straight from global memory (128-byte row segments, the next
+// step's loads in flight under the current MFMAs) -- folds its waves through LDS in a fixed order and writes one
+// partial tile; the partials are added in chunk order.  The tiles of one chunk read the same rows: workgroups are
+// dealt round-robin over the 8 XCDs, so the grid index is remapped to give every XCD a contiguous range of
+// (chunk, tile) pairs -- the tiles of a chunk then run side by side on ONE XCD and share its L2 (otherwise every XCD
+// pulls every row through the fabric: measured 233 -> see DESIGN.md).
+// VEC: lane i of the A operand takes columns 4 i .. 4 i + 3 of the tile with one 16-byte load (they become the four
+// M-tiles: a tile is any 32 columns, here every fourth), lane j of B columns 2 j, 2 j + 1 -- a quarter of the load
+// instructions, 512 contiguous bytes per half wave.  Needs 16-byte aligned rows and M % 4 == N % 2 == 0.
+constexpr int RW_MT = 4, RW_NT = 2, RW_UN = 8;
+template <bool VEC>
+__global__ __launch_bounds__(256) void rows_wgrad_kernel(const float *__restrict__ A, int lda, int M,
+                                                         const float *__restrict__ Bm, int ldb, int Nn, int P, int chunk,
+                                                         int ntiles_n, float *__restrict__ partial)
+{
+    __shared__ float fold[2][RW_MT * 32][RW_NT * 32 + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, i32 = lane & 31;
+    const int tiles = ntiles_n * ((M + RW_MT * 32 - 1) / (RW_MT * 32));
+    const int v = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);  // gridDim.x is a multiple of 8
+    const int cidx = v / tiles, tile = v - cidx * tiles;
+    if (cidx * chunk >= P) return;  // padding workgroups
+    const int tm = tile / ntiles_n, tn = tile - tm * ntiles_n;
+    const int m0 = tm * RW_MT * 32, n0 = tn * RW_NT * 32;
+    const int cbeg = cidx * chunk, cend = cbeg + chunk < P ? cbeg + chunk : P;
+    const int quarter = ((cend - cbeg + 3) / 4 + 1) & ~1;  // even: the two lane halves take alternate points
+    const int pbeg = cbeg + wave * quarter;
+    const int pend = pbeg + quarter < cend ? pbeg + quarter : cend;
+    int acol[RW_MT], bcol[RW_NT];
+    bool aval[RW_MT], bval[RW_NT];
+#pragma unroll
+    for (int mt = 0; mt < RW_MT; ++mt) {
+        const int col = VEC ? m0 + 4 * i32 + mt : m0 + mt * 32 + i32;
+        aval[mt] = col < M;
+        acol[mt] = aval[mt] ? col : 0;
+    }
+#pragma unroll
+    for (int nt = 0; nt < RW_NT; ++nt) {
+        const int col = VEC ? n0 + 2 * i32 + nt : n0 + nt * 32 + i32;
+        bval[nt] = col < Nn;
+        bcol[nt] = bval[nt] ? col : 0;
+    }
+    f32x16 acc[RW_MT][RW_NT];
+#pragma unroll
+    for (int mt = 0; mt < RW_MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < RW_NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+    float a[RW_UN][RW_MT], b[RW_UN][RW_NT], an[RW_UN][RW_MT], bn[RW_UN][RW_NT];
+    auto fetch = [&](int p, float(&fa)[RW_UN][RW_MT], float(&fb)[RW_UN][RW_NT]) {
+#pragma unroll
+        for (int u = 0; u < RW_UN; ++u) {
+            const int pp = p + 2 * u + h;
+            const bool pv = pp < pend;
+            const size_t row = (size_t)(pv ? pp : cbeg);  // clamped row: unconditional loads, masked values
+            if (VEC) {
+                const float4 va = *reinterpret_cast<const float4 *>(A + row * lda + acol[0]);
+                const float2 vb = *reinterpret_cast<const float2 *>(Bm + row * ldb + bcol[0]);
+                const bool av = pv && aval[0], bv = pv && bval[0];
+                fa[u][0] = av ? va.x : 0.0f;
+                fa[u][1] = av ? va.y : 0.0f;
+                fa[u][2] = av ? va.z : 0.0f;
+                fa[u][3] = av ? va.w : 0.0f;
+                fb[u][0] = bv ? vb.x : 0.0f;
+                fb[u][1] = bv ? vb.y : 0.0f;
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < RW_MT; ++mt) {
+                    const float v = A[row * lda + acol[mt]];
+                    fa[u][mt] = pv && aval[mt] ? v : 0.0f;
+                }
+#pragma unroll
+                for (int nt = 0; nt < RW_NT; ++nt) {
+                    const float v = Bm[row * ldb + bcol[nt]];
+                    fb[u][nt] = pv && bval[nt] ? v : 0.0f;
+                }
+            }
+        }
+    };
+    if (pbeg < pend) {
+        fetch(pbeg, a, b);
+        for (int p = pbeg; p < pend; p += 2 * RW_UN) {
+            fetch(p + 2 * RW_UN, an, bn);  // past the end: all rows masked
+#pragma unroll
+            for (int u = 0; u < RW_UN; ++u)
+#pragma unroll
+                for (int mt = 0; mt < RW_MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < RW_NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][mt], b[u][nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < RW_UN; ++u) {
+#pragma unroll
+                for (int mt = 0; mt < RW_MT; ++mt) a[u][mt] = an[u][mt];
+#pragma unroll
+                for (int nt = 0; nt < RW_NT; ++nt) b[u][nt] = bn[u][nt];
+            }
+        }
+    }
+    // fold the four waves: (2, 3) -> LDS, (0, 1) add; 1 -> LDS, 0 adds and stores
+    auto put = [&](int slot) {
+#pragma unroll
+        for (int mt = 0; mt < RW_MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < RW_NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) fold[slot][mt * 32 + mfma32_row(r, h)][nt * 32 + i32] = acc[mt][nt][r];
+    };
+    auto add = [&](int slot) {
+#pragma unroll
+        for (int mt = 0; mt < RW_MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < RW_NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][nt][r] += fold[slot][mt * 32 + mfma32_row(r, h)][nt * 32 + i32];
+    };
+    if (wave >= 2) put(wave - 2);
+    __syncthreads();
+    if (wave < 2) add(wave);
+    __syncthreads();
+    if (wave == 1) put(0);
+    __syncthreads();
+    if (wave == 0) {
+        add(0);
+        float *out = partial + (size_t)cidx * M * Nn;
+#pragma unroll
+        for (int mt = 0; mt < RW_MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < RW_NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int i = mfma32_row(r, h);
+                    const int m = VEC ? m0 + 4 * i + mt : m0 + mt * 32 + i, n = VEC ? n0 + 2 * i32 + nt : n0 + nt * 32 + i32;
+                    if (m < M && n < Nn) out[(size_t)m * Nn + n] = acc[mt][nt][r];
+                }
+    }
+}
+
+static int rows_wgrad_chunks(int M, int Nn, int P)
+{
+    const int tiles = ceil_div(M, RW_MT * 32) * ceil_div(Nn, RW_NT * 32);
+    int chunks = 1024 / tiles;  // about four workgroups per CU
+    if (chunks < 8) chunks = 8;
+    const int most = ceil_div(P, 64);
+    if (chunks > most) chunks = most;
+    return chunks < 1 ? 1 : chunks;
+}
+
 static int head_chunks(int P) { return ceil_div(P, HEAD_ROWS_PER_BLOCK); }
 
 }  // namespace dgcnn
@@ -499,5 +651,37 @@ extern "C" int dgcnn_embed_max_bwd_scatter(const int32_t *arg, const float *s, c
     hipLaunchKernelGGL(embed_bwd_scatter_kernel, dim3(EMB_SHARES, B), dim3(256), (size_t)C2 * sizeof(unsigned long long),
                        (hipStream_t)stream, arg, s, w, N, C, F, C2, dcat);
     DG_CHECK_LAUNCH("dgcnn_embed_max_bwd_scatter");
+    return 0;
+}
+
+extern "C" size_t dgcnn_rows_wgrad_workspace_bytes(int M, int Nn, int P)
+{
+    if (M <= 0 || Nn <= 0 || P <= 0) return 0;
+    return align_up((size_t)rows_wgrad_chunks(M, Nn, P) * M * Nn * sizeof(float), 256);
+}
+
+extern "C" int dgcnn_rows_wgrad(const float *a, int lda, int M, const float *b, int ldb, int Nn, int P, float *dw,
+                                void *workspace, size_t workspace_bytes, void *stream)
+{
+    DG_REQUIRE(a && b && dw && workspace, "dgcnn_rows_wgrad: null pointer");
+    DG_REQUIRE(M > 0 && Nn > 0 && P > 0 && lda >= M && ldb >= Nn, "dgcnn_rows_wgrad: bad shape M=%d N=%d P=%d lda=%d ldb=%d", M,
+               Nn, P, lda, ldb);
+    DG_REQUIRE((size_t)M * Nn < ((size_t)1 << 31), "dgcnn_rows_wgrad: output too large");
+    DG_REQUIRE(workspace_bytes >= dgcnn_rows_wgrad_workspace_bytes(M, Nn, P), "dgcnn_rows_wgrad: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int chunks = rows_wgrad_chunks(M, Nn, P);
+    const int chunk = ceil_div(P, chunks);
+    const int tn = ceil_div(Nn, RW_NT * 32), tm = ceil_div(M, RW_MT * 32);
+    const bool vec = (M & 3) == 0 && (Nn & 1) == 0 && (lda & 3) == 0 && (ldb & 1) == 0 && ((uintptr_t)a & 15) == 0 &&
+                     ((uintptr_t)b & 7) == 0;
+    const dim3 grid((unsigned)align_up((size_t)tm * tn * ceil_div(P, chunk), 8));
+    if (vec)
+        hipLaunchKernelGGL(rows_wgrad_kernel<true>, grid, dim3(256), 0, st, a, lda, M, b, ldb, Nn, P, chunk, tn,
+                           (float *)workspace);
+    else
+        hipLaunchKernelGGL(rows_wgrad_kernel<false>, grid, dim3(256), 0, st, a, lda, M, b, ldb, Nn, P, chunk, tn,
+                           (float *)workspace);
+    launch_sum_partials((const float *)workspace, ceil_div(P, chunk), M * Nn, dw, st);
+    DG_CHECK_LAUNCH("dgcnn_rows_wgrad");
     return 0;
 }

@@ -107,7 +107,7 @@ class DGCNN(nn.Module):
     def _head_stage(self, z, i):
         """conv_i (1x1 Conv1d) + bn_i + LeakyReLU on point-major rows z [P, C_in]."""
         conv = getattr(self, "conv%d" % i)[0]
-        u = F.linear(z, conv.weight.squeeze(-1))              # plain library GEMM on point-major rows
+        u = ops.linear_rows(z, conv.weight.squeeze(-1))       # library GEMMs; the weight gradient is split over the points
         return ops.bn_lrelu_rows(u, getattr(self, "bn%d" % i), self.training, NEG_SLOPE)
 
     def forward(self, x, depth=10, idx=None, return_idx=False):
@@ -157,7 +157,7 @@ class DGCNN(nn.Module):
                             # (one [B, emb] x [emb, 512] product per batch element + a 192-wide per-point GEMM:
                             # 84 % fewer FLOPs than the 1216-wide one)
                             w7 = self.conv7[0].weight.squeeze(-1)
-                            u7 = F.linear(cat, w7[:, emb:]) + F.linear(g, w7[:, :emb])      # [B, N, 512] + [B, 1, 512]
+                            u7 = ops.linear_rows(cat.reshape(P, 192), w7[:, emb:]).view(B, N, -1) + F.linear(g, w7[:, :emb])
                             z = ops.bn_lrelu_rows(u7.reshape(P, -1), self.bn7, self.training, NEG_SLOPE)
                             if depth == 8:
                                 out = ops.from_point_major_autograd(z.view(B, N, -1))

@@ -320,6 +320,52 @@ def bn_lrelu_max_rows(x, bn, B, N, training, slope=0.2):
     return g
 
 
+def rows_wgrad(a, b):
+    """sum over the rows p of a[p, :]^T b[p, :]:  a [P, M], b [P, N] (rows may be strided views) -> [M, N].
+    The weight-gradient product of a 1x1 convolution on point-major rows, split over the points (dgcnn_rows_wgrad)."""
+    _lib.require_device(a, "a")
+    _lib.require_device(b, "b")
+    if a.dtype != torch.float32 or b.dtype != torch.float32:
+        raise TypeError("rows_wgrad needs float32 operands")
+    if a.stride(1) != 1:
+        a = a.contiguous()
+    if b.stride(1) != 1:
+        b = b.contiguous()
+    P, M = a.shape
+    N = b.shape[1]
+    if b.shape[0] != P:
+        raise ValueError("a and b must have the same number of rows")
+    lib = _lib.load()
+    dw = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    ws_bytes = lib.dgcnn_rows_wgrad_workspace_bytes(M, N, P)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=a.device)
+    _lib.check(lib.dgcnn_rows_wgrad(_lib.ptr(a), a.stride(0), M, _lib.ptr(b), b.stride(0), N, P, _lib.ptr(dw), _lib.ptr(ws),
+                                    ws_bytes, _lib.stream_ptr(a.device)), "dgcnn_rows_wgrad")
+    return dw
+
+
+class _LinearRows(torch.autograd.Function):
+    """y = x W^T on point-major rows (a 1x1 Conv1d without bias, model.py:132-141): forward and dL/dx are plain
+    library GEMMs; dL/dW, a contraction over the points with a small output, goes through rows_wgrad."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return torch.mm(x, w.t())
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gx = torch.mm(gy, w) if ctx.needs_input_grad[0] else None
+        gw = rows_wgrad(gy, x) if ctx.needs_input_grad[1] else None
+        return gx, gw
+
+
+def linear_rows(x, w):
+    """x [P, C_in] point-major rows, w [C_out, C_in] -> [P, C_out]."""
+    return _LinearRows.apply(x, w)
+
+
 class _EmbedMax(torch.autograd.Function):
     """conv6 -> bn6 -> LeakyReLU -> max over the points (model.py:172-175) as ONE autograd node, so that the backward
     never forms the dense [B*N, emb] gradient: with u = cat W^T, dL/du[p, c] = A_c + B_c u[p, c] + (s[b, c] at the
@@ -381,7 +427,7 @@ class _EmbedMax(torch.autograd.Function):
         if training:
             wb = wd * coef_b.unsqueeze(1)                                                    # diag(B) W
             dcat = torch.addmm(torch.mv(wd.t(), coef_a), catd, torch.mm(wd.t(), wb))         # 1 (A W)^T + cat M
-            dw.addmm_(wb, torch.mm(catd.t(), catd))                                          # + diag(B) W (cat^T cat)
+            dw.addmm_(wb, rows_wgrad(catd, catd))                                            # + diag(B) W (cat^T cat)
             dw.addr_(coef_a, catd.sum(0))                                                    # + A (sum cat)^T
         else:
             dcat = torch.zeros_like(catd)

@@ -151,6 +151,13 @@ int dgcnn_bn_lrelu_max_bwd(const float *x, const float *gg, const int32_t *arg, 
                            int training, float slope, float *gx, float *gweight, float *gbias, void *workspace,
                            size_t workspace_bytes, void *stream);
 
+/* Weight gradient of a 1x1 convolution on point-major rows: dw[M][N] = sum over the P rows of a[p][m] * b[p][n]
+ * (a = dL/d(output) rows with leading dimension lda >= M, b = the convolution's input rows, ldb >= N).  The
+ * contraction over the points is split across workgroups (fp32 MFMA) and folded in a fixed order. */
+size_t dgcnn_rows_wgrad_workspace_bytes(int M, int N, int P);
+int dgcnn_rows_wgrad(const float *a, int lda, int M, const float *b, int ldb, int N, int P, float *dw, void *workspace,
+                     size_t workspace_bytes, void *stream);
+
 /* Backward of conv6 -> bn6 -> LeakyReLU -> max without the dense [B*N][C] gradient (model.py:172-175; host side in
  * ops.py, _EmbedMax).  With u = cat . W^T the BatchNorm mean terms of dL/du are affine in u, dL/du[p][c] = A_c +
  * B_c u[p][c] + (s[b][c] at the winning point), so the backward needs 192-wide library products only.

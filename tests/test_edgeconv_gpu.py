@@ -323,6 +323,20 @@ def test_head_embed_max_rows(B, N, F, C, train, device):
     assert torch.equal(cd2.grad, cd.grad)
 
 
+@pytest.mark.parametrize("P,M,N", [(5000, 256, 512), (1031, 5, 256), (777, 192, 192), (64, 130, 70), (20000, 512, 192)])
+def test_rows_wgrad(P, M, N, device):
+    # weight gradient of a 1x1 convolution on point-major rows (split over the points) vs a float64 product
+    from ahn3_dgcnn_pytorch_amd import ops
+    g = torch.Generator().manual_seed(P + M + N)
+    a = torch.randn(P, M + 3, generator=g)[:, :M]        # strided rows
+    b = torch.randn(P, N, generator=g) + 0.5
+    want = (a.double().t() @ b.double())
+    got = ops.rows_wgrad(a.to(device), b.to(device)).cpu().double()
+    scale = (a.double().abs().t() @ b.double().abs())    # fp32 accumulation error scales with the sum of magnitudes
+    assert ((got - want).abs() / scale).max().item() <= 2e-6
+    assert torch.equal(ops.rows_wgrad(a.to(device), b.to(device)).cpu().double(), got)   # fixed order
+
+
 def test_step_is_graph_capturable(device):
     """every C-ABI call only enqueues work on the current stream: a whole kNN + block forward + backward step can be
     captured in a hipGraph and replayed.  Runs in a child process: a failed capture can
