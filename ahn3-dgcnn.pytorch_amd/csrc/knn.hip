@@ -426,7 +426,7 @@ __global__ __launch_bounds__(64) void knn_bound_kernel(const void *__restrict__ 
         constexpr int G = CH / VEC;
         typedef float vecf __attribute__((ext_vector_type(VEC)));
         const vecf *xb = reinterpret_cast<const vecf *>(reinterpret_cast<const float *>(xop) + (size_t)b * Npad * CP) + lane;
-        float a[RT][CH], bop[CH];
+        float a[RT][CH];
         auto load = [&](int t, float(&dst)[CH]) {
 #pragma unroll
             for (int g = 0; g < G; ++g) {
@@ -437,23 +437,46 @@ __global__ __launch_bounds__(64) void knn_bound_kernel(const void *__restrict__ 
         };
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) load(rb0 + rt, a[rt]);
-        for (int t = 0; t < ntiles; ++t) {
-            load(t, bop);
-            const float xl = xnb[t * 32 + j32];
+        // four candidate tiles per step, the next step's operands in flight under this step's MFMAs: with one or two
+        // waves per SIMD an unprefetched loop pays a full L2 round trip per tile (Npad / 32 is a multiple of 4)
+        constexpr int GT = 4;
+        float bcur[GT][CH], bnxt[GT][CH], xcur[GT], xnxt[GT];
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-                f32x16 acc;
+        for (int u = 0; u < GT; ++u) {
+            load(u, bcur[u]);
+            xcur[u] = xnb[u * 32 + j32];
+        }
+        for (int t = 0; t < ntiles; t += GT) {
+            const int tn = t + GT < ntiles ? t + GT : t;  // last step: reload the current group (unused)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            for (int u = 0; u < GT; ++u) {
+                load(tn + u, bnxt[u]);
+                xnxt[u] = xnb[(tn + u) * 32 + j32];
+            }
 #pragma unroll
-                for (int s = 0; s < CH; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rt][s], bop[s], acc, 0, 0, 0);
-                if (t & 1) {
+            for (int u = 0; u < GT; ++u) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) m1[rt][r] = fmaxf(m1[rt][r], __builtin_fmaf(2.0f, acc[r], -xl));
-                } else {
+                for (int rt = 0; rt < RT; ++rt) {
+                    f32x16 acc;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) m0[rt][r] = fmaxf(m0[rt][r], __builtin_fmaf(2.0f, acc[r], -xl));
+                    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+                    for (int s = 0; s < CH; ++s)
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rt][s], bcur[u][s], acc, 0, 0, 0);
+                    if (u & 1) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) m1[rt][r] = fmaxf(m1[rt][r], __builtin_fmaf(2.0f, acc[r], -xcur[u]));
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) m0[rt][r] = fmaxf(m0[rt][r], __builtin_fmaf(2.0f, acc[r], -xcur[u]));
+                    }
                 }
+            }
+#pragma unroll
+            for (int u = 0; u < GT; ++u) {
+#pragma unroll
+                for (int s = 0; s < CH; ++s) bcur[u][s] = bnxt[u][s];
+                xcur[u] = xnxt[u];
             }
         }
     }
