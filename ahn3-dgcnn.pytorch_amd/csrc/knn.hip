@@ -372,7 +372,8 @@ __device__ __forceinline__ float knn_f16_eps(float yy_i, float cmax, float xx_i,
 // bound by L2 -> CU traffic, not by arithmetic).  F16 = true: xop are the fp16 centred tiles, xn the
 // centred norms; F16 = false (small C): xop are the fp32 tiles of knn_tile_kernel, xn the raw norms,
 // and the arithmetic is exactly the one of knn_kernel.
-template <int CP, bool F16, int RT>
+// WIDE (fp32 variant only): 128 classes per row (candidate tile index mod 4 x 32 lanes) instead of 64, for 40 < k <= 64.
+template <int CP, bool F16, int RT, bool WIDE = false>
 __global__ __launch_bounds__(64) void knn_bound_kernel(const void *__restrict__ xop, const float *__restrict__ xn,
                                                        const float *__restrict__ xx_raw,
                                                        const unsigned *__restrict__ bmax, int B, int Npad, int k,
@@ -384,10 +385,11 @@ __global__ __launch_bounds__(64) void knn_bound_kernel(const void *__restrict__ 
     const int ntiles = Npad / 32;  // even
 
     float m0[RT][16], m1[RT][16];  // class maxima of 2 dot - xx_l over even / odd candidate tiles
+    float m2[RT][16], m3[RT][16];  // WIDE: tiles 4g, 4g+1, 4g+2, 4g+3 feed m0 .. m3
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) m0[rt][r] = m1[rt][r] = -__builtin_inff();
+        for (int r = 0; r < 16; ++r) m0[rt][r] = m1[rt][r] = m2[rt][r] = m3[rt][r] = -__builtin_inff();
 
     if constexpr (F16) {
         constexpr int KS = CP / 16;
@@ -463,13 +465,9 @@ __global__ __launch_bounds__(64) void knn_bound_kernel(const void *__restrict__ 
 #pragma unroll
                     for (int s = 0; s < CH; ++s)
                         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rt][s], bcur[u][s], acc, 0, 0, 0);
-                    if (u & 1) {
+                    float(&m)[16] = WIDE ? (u == 0 ? m0[rt] : u == 1 ? m1[rt] : u == 2 ? m2[rt] : m3[rt]) : ((u & 1) ? m1[rt] : m0[rt]);
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) m1[rt][r] = fmaxf(m1[rt][r], __builtin_fmaf(2.0f, acc[r], -xcur[u]));
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) m0[rt][r] = fmaxf(m0[rt][r], __builtin_fmaf(2.0f, acc[r], -xcur[u]));
-                    }
+                    for (int r = 0; r < 16; ++r) m[r] = fmaxf(m[r], __builtin_fmaf(2.0f, acc[r], -xcur[u]));
                 }
             }
 #pragma unroll
@@ -488,11 +486,21 @@ __global__ __launch_bounds__(64) void knn_bound_kernel(const void *__restrict__ 
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float other = __uint_as_float(xchg32<32>(__float_as_uint(m1[rt][r])));
+            const float other3 = WIDE ? __uint_as_float(xchg32<32>(__float_as_uint(m3[rt][r]))) : 0.0f;
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
                 // row (r, hh): its lanes hold m0 (own half) and the partner half receives that half's m1
                 unsigned key = f32_to_ordered((h == hh) ? m0[rt][r] : other);
                 bitonic32_sort<64>(key, lane);
+                if constexpr (WIDE) {
+                    // the other 64 classes, sorted too; the top 64 of the union are max(A[i], B[63 - i]), a bitonic
+                    // sequence that one merge pass sorts
+                    unsigned keyb = f32_to_ordered((h == hh) ? m2[rt][r] : other3);
+                    bitonic32_sort<64>(keyb, lane);
+                    const unsigned rev = (unsigned)__shfl((int)keyb, 63 - lane);
+                    key = key > rev ? key : rev;
+                    bitonic32_merge<64, 32>(key, lane);
+                }
                 const unsigned kth = __builtin_amdgcn_readlane(key, k - 1);
                 const float vk = __uint_as_float((kth & 0x80000000u) ? (kth & 0x7fffffffu) : ~kth);
                 const int row = (rb0 + rt) * 32 + mfma32_row(r, hh);
@@ -1473,8 +1481,12 @@ static void knn_bound_launch(int B, hipStream_t st, const void *xop, const float
                              const unsigned *bmax, int Npad, int k, float *tau0, float *epsr)
 {
     constexpr int RT = 1;  // (2 row tiles per wave halve the L2 traffic but measured slower: fewer waves)
-    hipLaunchKernelGGL((knn_bound_kernel<CP, F16, RT>), dim3(B * (Npad / (32 * RT))), dim3(64), 0, st, xop, xn, xx, bmax,
-                       B, Npad, k, tau0, epsr);
+    if (!F16 && k > 40)
+        hipLaunchKernelGGL((knn_bound_kernel<CP, false, RT, true>), dim3(B * (Npad / (32 * RT))), dim3(64), 0, st, xop, xn, xx,
+                           bmax, B, Npad, k, tau0, epsr);
+    else
+        hipLaunchKernelGGL((knn_bound_kernel<CP, F16, RT>), dim3(B * (Npad / (32 * RT))), dim3(64), 0, st, xop, xn, xx, bmax,
+                           B, Npad, k, tau0, epsr);
 }
 
 struct KnnWs {
@@ -1558,7 +1570,12 @@ extern "C" int dgcnn_knn(const float *x, int B, int N, int C, int k, int32_t *id
 
     static const bool prepass_off = getenv("DGCNN_KNN_NO_PREPASS") != nullptr;
     static const bool f16_off = getenv("DGCNN_KNN_NO_F16") != nullptr;
-    const bool prepass = k <= 40 && N >= 256 && !prepass_off;
+    // the fp16 streams split the candidates of a row group over two workgroups when there are enough chunks:
+    // twice the waves per SIMD (the streams are latency-bound at 1.7) and 128 instead of 64 threshold classes
+    const int parts = Npad / (32 * KNN_ST_TILES) >= 8 ? 2 : 1;
+    // threshold pre-pass: the k-th largest of 64 class maxima is a useful bound up to k = 40; with 128 classes (fp16
+    // path: two candidate halves; small C: knn_bound_kernel's WIDE variant) up to k = 64 (about 1.4 k survivors per row)
+    const bool prepass = N >= 256 && !prepass_off && (k <= 40 || (k <= 64 && (CP < 16 || parts == 2)));
     const bool f16path = prepass && CP >= 16 && !f16_off;
     if (prepass && CP >= 16) {
         // one pass over x: norms, fp16 and fp32 operand tiles, norm maxima (after the centre of each batch element)
@@ -1576,13 +1593,10 @@ extern "C" int dgcnn_knn(const float *x, int B, int N, int C, int k, int32_t *id
     }
     DG_CHECK_LAUNCH("knn prep kernels");
 
-    // threshold pre-pass (speed only; see the header).  64 candidate classes per row: worth it for k <= 40.
+    // threshold pre-pass (speed only; see the header)
     const float *tau0 = nullptr;
     const int *rbflag = nullptr;
     const int cap = (k <= 32) ? 64 : 128;
-    // the fp16 streams split the candidates of a row group over two workgroups when there are enough chunks:
-    // twice the waves per SIMD (the streams are latency-bound at 1.7) and 128 instead of 64 threshold classes
-    const int parts = Npad / (32 * KNN_ST_TILES) >= 8 ? 2 : 1;
     // the filter cuts finer (up to KNN_MAXPARTS candidate parts): its workgroups are the unit of load balance, and
     // 3.4 of them per CU (two parts) leave 14 % of the chip idle at the end
     static const int fparts_env = getenv("DGCNN_KNN_FPARTS") ? atoi(getenv("DGCNN_KNN_FPARTS")) : 0;  // experiments

@@ -23,6 +23,8 @@ def _run(x_bcn, k, device):
 @pytest.mark.parametrize("B,C,N,k", [
     (2, 4, 256, 8), (2, 64, 256, 30), (1, 4, 1000, 30), (3, 3, 130, 20), (2, 9, 777, 40),
     (1, 64, 2000, 64), (2, 128, 300, 30), (1, 6, 64, 64), (1, 5, 33, 33), (2, 64, 1, 1),
+    (2, 16, 1500, 50), (1, 32, 4100, 64), (2, 64, 1100, 41),   # 40 < k <= 64 with 128 threshold classes (fp16 path)
+    (1, 4, 3000, 64), (2, 8, 900, 50), (2, 3, 260, 41),        # ... and the fp32 path for small C
 ])
 def test_knn_bit_exact_random(B, C, N, k, device):
     rng = np.random.default_rng(1234 + B * 7 + C * 13 + N)
@@ -106,7 +108,7 @@ def _feature_cases():
 @pytest.mark.parametrize("name", sorted(_feature_cases().keys()))
 def test_knn_f16_filter_path_is_exact(name, device):
     x = _feature_cases()[name]
-    for k in (8, 30, 40):
+    for k in (8, 30, 40, 64):
         np.testing.assert_array_equal(_run(x, k, device), ke.knn_exact(x, k), err_msg="%s k=%d" % (name, k))
 
 
@@ -132,7 +134,7 @@ def test_knn_small_c_filter_path_is_exact(device):
         }
         for name, x in cases.items():
             x = np.ascontiguousarray(x, dtype=np.float32)
-            for k in (8, 30, 40):
+            for k in (8, 30, 40, 64):
                 np.testing.assert_array_equal(_run(x, k, device), ke.knn_exact(x, k), err_msg="C=%d %s k=%d" % (C, name, k))
 
 
