@@ -66,12 +66,12 @@ int mlp_grid(int P);      // backward: number of gW2 / BN1 partial records
 int mlp_grid_fwd(int P);  // forward: number of BN2 partial records
 void launch_edge_mlp_fwd(const float *TP, const float *TQ, const int32_t *idx, int N, int k, int P,
                          const float *stats1, const float *w2, const float *gamma2, float slope, float *usel2,
-                         double *partial, hipStream_t st);
+                         uint8_t *hit2, double *partial, hipStream_t st);
 // dv1 [E][64]; dvsum [P][64] = sum over each point's k edges of dv1; partial_dw2 [grid][64][64]; partial_bn1
 // [grid][2][64] doubles (sum dv1, sum dv1 * uhat1)
 void launch_edge_mlp_bwd(const float *TP, const float *TQ, const int32_t *idx, int N, int k, int P,
                          const float *stats1, const float *stats2, const float *cc2, const float *w2, float slope,
-                         int training, const float *gy, const float *y, const float *usel2, float *dv1, float *dvsum,
+                         int training, const float *gy, const float *y, const uint8_t *hit2, float *dv1, float *dvsum,
                          float *partial_dw2, double *partial_bn1, hipStream_t st);
 
 }  // namespace dgcnn

@@ -1,6 +1,12 @@
 // edge_mlp.hip -- the per-EDGE 64 -> 64 contraction of the two-stage EdgeConv blocks
-// (conv2 / conv4 of the reference, model.py:119-121,125-127 applied at :149,:156) on
-// v_mfma_f32_32x32x2_f32 (exact fp32), fused with everything around it.
+// (conv2 / conv4 of the reference, model.py:119-121,125-127 applied at :149,:156), fused with everything around it.
+// Forward: fp16 matrix cores with both operands split in two halves, x = hi + lo 2^-11 (hi = x with the low 13
+// mantissa bits cleared, lo = fp16((x - hi) 2^11)): u2 = hi.hi + 2^-11 (hi.lo + lo.hi); the dropped lo.lo term and the
+// rounding of lo are 2^-21 relative -- inside fp32's own accumulation error over 64 terms and far inside the 1e-4
+// parity bound -- for 12 v_mfma_f32_32x32x16_f16 (384 cycles) per 32 x 32 x 64 tile instead of 32
+// v_mfma_f32_32x32x2_f32 (2048 cycles).  On gfx950 the fp32-input MFMA also shares the vector ALU's FMA lanes: its time
+// and the gather / epilogue VALU time ADD (measured: 114 us MFMA + 56 + 27 us VALU phases = the fp32 kernel's 206 us).
+// Backward: v_mfma_f32_32x32x2_f32 (its operands are gradients of unknown scale).
 //
 // One wave processes one point at a time; its k edges are the M dimension of a 32-row MFMA tile
 // (k = 30 -> 30 of 32 rows used; k > 32 -> two tiles):
@@ -24,11 +30,11 @@ constexpr int MLP_WAVES = 4;      // forward
 constexpr int MLP_BWD_WAVES = 8;  // backward: two waves per SIMD, one in its MFMA phases while the other gathers / stages
 constexpr int TSTR = 68;  // LDS tile row stride in floats (64 + 4: conflict-free b128 rows)
 
-// workgroups: the backward holds 156 KB of LDS (one workgroup of eight waves per CU); the forward 39 KB, so three per CU hide
-// each other's gather and LDS latencies (measured: 304 us at 32 slots per XCD)
+// workgroups: the backward holds 156 KB of LDS (one workgroup of eight waves per CU); the forward 39 KB and about 220
+// registers per lane: two workgroups per CU (64 slots per XCD: measured 1.25 ms per step against 1.28 at 96, 1.39 at 128)
 static int mlp_slots_fwd()
 {
-    static const int v = getenv("DGCNN_MLP_SLOTS") ? atoi(getenv("DGCNN_MLP_SLOTS")) : 96;  // experiments
+    static const int v = getenv("DGCNN_MLP_SLOTS") ? atoi(getenv("DGCNN_MLP_SLOTS")) : 64;  // experiments
     return v;
 }
 int mlp_grid(int P) { return point_grid(P, MLP_BWD_WAVES, 32); }
@@ -86,42 +92,81 @@ __device__ __forceinline__ void load_a_operand(const float (*tile)[TSTR], int i3
     }
 }
 
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+constexpr float LO_SCALE = 2048.0f, LO_UNSCALE = 1.0f / 2048.0f;
+
+// x = hi + lo / 2^11 up to 2^-21 |x|: hi = x with the low 13 mantissa bits cleared (exactly a fp16 number inside the
+// fp16 normal range), lo = the exact remainder, scaled (and rounded to fp16 by the caller).  |x| beyond the fp16 range
+// saturates (finite garbage instead of NaN); below the normal range the error is at most 2^-25 absolute.
+__device__ __forceinline__ void split_f16(float x, float &hi, float &lo)
+{
+    const float xc = __builtin_amdgcn_fmed3f(x, -65504.0f, 65504.0f);
+    hi = __uint_as_float(__float_as_uint(xc) & 0xffffe000u);
+    lo = (xc - hi) * LO_SCALE;
+}
+// A operand of the 32x32x16 fp16 MFMA from a fp32 [32][TSTR] tile: lane (i, h), step s holds columns 16 s + 8 h .. + 7
+__device__ __forceinline__ void load_a_split(const float (*tile)[TSTR], int i32, int h, half8 (&ahi)[4], half8 (&alo)[4])
+{
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const float4 v0 = *reinterpret_cast<const float4 *>(&tile[i32][16 * s + 8 * h]);
+        const float4 v1 = *reinterpret_cast<const float4 *>(&tile[i32][16 * s + 8 * h + 4]);
+        const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float a, b;
+            split_f16(x[e], a, b);
+            ahi[s][e] = (_Float16)a;
+            alo[s][e] = (_Float16)b;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void edge_mlp_fwd_kernel(const float *__restrict__ TP, const float *__restrict__ TQ,
+__global__ __launch_bounds__(256) void edge_mlp_fwd_kernel(const float *__restrict__ TP, const float *__restrict__ TQ,
                                                            const int32_t *__restrict__ idx, int N, int k, int P,
                                                            const float *__restrict__ stats1,
                                                            const float *__restrict__ w2,
                                                            const float *__restrict__ gamma2, float slope,
-                                                           float *__restrict__ usel2, double *__restrict__ partial)
+                                                           float *__restrict__ usel2, uint8_t *__restrict__ hit2,
+                                                           double *__restrict__ partial)
 {
     __shared__ __attribute__((aligned(16))) float tiles[MLP_WAVES][32][TSTR];
     __shared__ double red[MLP_WAVES][2][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, i32 = lane & 31;
     float(*tileA)[TSTR] = tiles[wave];
 
-    // B operand: B[k = ci][n = co] = W2[co][ci]; lane (n, h) supplies ci = 32 h + s at step s
-    float wb[2][32];
+    // B operand: B[k = ci][n = co] = W2[co][ci]; lane (n, h) supplies ci = 16 s + 8 h .. + 7 at step s, split in halves
+    half8 whi[2][4], wlo[2][4];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int s = 0; s < 32; ++s) wb[nt][s] = w2[(size_t)(nt * 32 + i32) * EC + 32 * h + s];
-    bool neg[2];
+        for (int s = 0; s < 4; ++s)
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) neg[nt] = gamma2[nt * 32 + i32] < 0.0f;
+            for (int e = 0; e < 8; ++e) {
+                float a, b;
+                split_f16(w2[(size_t)(nt * 32 + i32) * EC + 16 * s + 8 * h + e], a, b);
+                whi[nt][s][e] = (_Float16)a;
+                wlo[nt][s][e] = (_Float16)b;
+            }
+    unsigned flip[2];  // gamma2 < 0: the activation's maximum is the pre-activation's minimum
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) flip[nt] = gamma2[nt * 32 + i32] < 0.0f ? 0x80000000u : 0u;
     const float sc1 = stats1[ST_SC + lane], sh1 = stats1[ST_SH + lane];
 
     double sum[2] = {0.0, 0.0}, sq[2] = {0.0, 0.0};
     const PointIter it = point_iter(P, wave, MLP_WAVES);
-    // (three workgroups per CU hide the gather latency here: prefetching the next point's rows as the backward does
-    // costs registers and residency -- measured 280 us against 217)
+    // (prefetching the next point's rows as the backward once did costs 32 registers and one of the two resident
+    // waves per SIMD: measured 183 us against 150)
     for (int pt = it.cur; pt < it.end; pt += it.step) {
         const int b = pt / N;
         const float *Pb = TP + (size_t)b * N * EC;
         const float q = TQ[(size_t)pt * EC + lane];
         const int32_t *ip = idx + (size_t)pt * k;
         float ext[2], ps[2] = {0.0f, 0.0f}, pq[2] = {0.0f, 0.0f};  // fp32 over the <= 32 values of a lane, fp64 across points
+        int arg[2] = {0, 0};  // edge slot of the extreme (the first one on ties): the backward routes dL/dy there
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) ext[nt] = neg[nt] ? __builtin_inff() : -__builtin_inff();
+        for (int nt = 0; nt < 2; ++nt) ext[nt] = -__builtin_inff();  // of the sign-flipped value
         for (int j0 = 0; j0 < k; j0 += 32) {
             const int kk = k - j0 < 32 ? k - j0 : 32;
             {
@@ -143,36 +188,49 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                     }
                 }
             }
-            float a[32];
-            load_a_operand(tileA, i32, h, a);
-            f32x16 acc[2];
+            half8 ahi[4], alo[4];
+            load_a_split(tileA, i32, h, ahi, alo);
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+            for (int nt = 0; nt < 2; ++nt) {
+                f32x16 am, ax;  // hi.hi and (hi.lo + lo.hi) 2^11
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
+                for (int r = 0; r < 16; ++r) am[r] = ax[r] = 0.0f;
 #pragma unroll
-            for (int s = 0; s < 32; ++s) {
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], wb[0][s], acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], wb[1][s], acc[1], 0, 0, 0);
+                for (int s = 0; s < 4; ++s) {
+                    am = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[s], whi[nt][s], am, 0, 0, 0);
+                    ax = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[s], wlo[nt][s], ax, 0, 0, 0);
+                    ax = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[s], whi[nt][s], ax, 0, 0, 0);
+                }
+                // extreme of the sign-flipped value (so that it is always a maximum), then the first slot that holds it
+                float best = -__builtin_inff();
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float u = __builtin_fmaf(ax[r], LO_UNSCALE, am[r]);  // exactly 0 in the padding rows (a1 = 0)
+                    ps[nt] += u;
+                    pq[nt] = __builtin_fmaf(u, u, pq[nt]);
+                    am[r] = mfma32_row(r, h) < kk ? __uint_as_float(__float_as_uint(u) ^ flip[nt]) : -__builtin_inff();
+                    best = fmaxf(best, am[r]);
+                }
+                if (best > ext[nt]) {
+                    int slot = 0;
+#pragma unroll
+                    for (int r = 15; r >= 0; --r) slot = am[r] == best ? mfma32_row(r, h) : slot;
+                    ext[nt] = best;
+                    arg[nt] = j0 + slot;
+                }
             }
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (mfma32_row(r, h) < kk) {
-                        const float u = acc[nt][r];
-                        ps[nt] += u;
-                        pq[nt] = __builtin_fmaf(u, u, pq[nt]);
-                        ext[nt] = neg[nt] ? fminf(ext[nt], u) : fmaxf(ext[nt], u);
-                    }
         }
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             sum[nt] += (double)ps[nt];
             sq[nt] += (double)pq[nt];
             const float o = __shfl_xor(ext[nt], 32);
-            const float e = neg[nt] ? fminf(ext[nt], o) : fmaxf(ext[nt], o);
-            if (h == 0) usel2[(size_t)pt * EC + nt * 32 + i32] = e;
+            const int oa = __shfl_xor(arg[nt], 32);
+            const bool take = o > ext[nt] || (o == ext[nt] && oa < arg[nt]);
+            if (h == 0) {
+                usel2[(size_t)pt * EC + nt * 32 + i32] = __uint_as_float(__float_as_uint(take ? o : ext[nt]) ^ flip[nt]);
+                hit2[(size_t)pt * EC + nt * 32 + i32] = (uint8_t)(take ? oa : arg[nt]);
+            }
         }
     }
     // BN2 partial sums: lane (n, h) holds channel nt * 32 + n; fold the halves, then the waves
@@ -202,7 +260,7 @@ __global__ __launch_bounds__(512) void edge_mlp_bwd_kernel(
     const float *__restrict__ TP, const float *__restrict__ TQ, const int32_t *__restrict__ idx, int N, int k, int P,
     const float *__restrict__ stats1, const float *__restrict__ stats2, const float *__restrict__ cc2,
     const float *__restrict__ w2, float slope, int training, const float *__restrict__ gy,
-    const float *__restrict__ y, const float *__restrict__ usel2, float *__restrict__ dv1,
+    const float *__restrict__ y, const uint8_t *__restrict__ hit2, float *__restrict__ dv1,
     float *__restrict__ dvsum, float *__restrict__ partial_dw2, double *__restrict__ partial_bn1)
 {
     // W2 [co][ci] once, rows padded to 65 floats, serves as the B operand of both products that contract over a
@@ -252,13 +310,13 @@ __global__ __launch_bounds__(512) void edge_mlp_bwd_kernel(
         const float *Pb = TP + (size_t)b * N * EC;
         const float q = TQ[(size_t)pt * EC + lane];
         const int32_t *ip = idx + (size_t)pt * k;
-        float uv[2], dvs[2];
+        float dvs[2];
+        int hit[2];  // the forward's winning edge slot of (point, channel)
         float dcol[2] = {0.0f, 0.0f};  // sum over the point's edges of dv1, per channel (for the centre term dD)
         float dhat[2] = {0.0f, 0.0f};  // ... and of dv1 * uhat1 (fp32 over the <= 32 values of a lane, fp64 across points)
-        bool found[2] = {false, false};
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-            uv[nt] = usel2[(size_t)pt * EC + nt * 32 + i32];
+            hit[nt] = hit2[(size_t)pt * EC + nt * 32 + i32];
             dvs[nt] = sc2[nt] * gy[(size_t)pt * EC + nt * 32 + i32] *
                       (y[(size_t)pt * EC + nt * 32 + i32] > 0.0f ? 1.0f : slope);
         }
@@ -292,21 +350,12 @@ __global__ __launch_bounds__(512) void edge_mlp_bwd_kernel(
 #pragma unroll
                 for (int r = 0; r < 16; ++r) ba[ct][r] = tileA[mfma32_row(r, h)][ct * 32 + i32];
 
-            // ---- du2 (in place of u2).  The whole dL/dy goes to the FIRST edge whose pre-activation is the extreme
-            // the forward selected (the recomputed u2 is bit-identical to the forward's: same operands, same MFMA
-            // order); the rest of du2 are the dense BatchNorm mean terms.
+            // ---- du2 (in place of u2): the whole dL/dy goes to the edge the forward selected (hit2); the rest of du2
+            // are the dense BatchNorm mean terms, affine in u2 (recomputed here in fp32: it differs from the forward's
+            // split-fp16 value by ~1e-6 relative, which only touches these small dense terms).
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                int first = 1000;
-#pragma unroll
-                for (int r = 15; r >= 0; --r) {
-                    const int row = mfma32_row(r, h);
-                    if (row < kk && acc[nt][r] == uv[nt]) first = row;
-                }
-                const int other = __shfl_xor(first, 32);
-                first = first < other ? first : other;
-                const int hitrow = (!found[nt] && first < 1000) ? first : -1;
-                found[nt] = found[nt] || (first < 1000);
+                const int hitrow = hit[nt] - j0;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = mfma32_row(r, h);
@@ -406,19 +455,19 @@ __global__ __launch_bounds__(512) void edge_mlp_bwd_kernel(
 // ---------------------------------------------------------------------------------------------
 void launch_edge_mlp_fwd(const float *TP, const float *TQ, const int32_t *idx, int N, int k, int P,
                          const float *stats1, const float *w2, const float *gamma2, float slope, float *usel2,
-                         double *partial, hipStream_t st)
+                         uint8_t *hit2, double *partial, hipStream_t st)
 {
     hipLaunchKernelGGL(edge_mlp_fwd_kernel, dim3(mlp_grid_fwd(P)), dim3(256), 0, st, TP, TQ, idx, N, k, P, stats1, w2,
-                       gamma2, slope, usel2, partial);
+                       gamma2, slope, usel2, hit2, partial);
 }
 
 void launch_edge_mlp_bwd(const float *TP, const float *TQ, const int32_t *idx, int N, int k, int P,
                          const float *stats1, const float *stats2, const float *cc2, const float *w2, float slope,
-                         int training, const float *gy, const float *y, const float *usel2, float *dv1, float *dvsum,
+                         int training, const float *gy, const float *y, const uint8_t *hit2, float *dv1, float *dvsum,
                          float *partial_dw2, double *partial_bn1, hipStream_t st)
 {
     hipLaunchKernelGGL(edge_mlp_bwd_kernel, dim3(mlp_grid(P)), dim3(64 * MLP_BWD_WAVES), 0, st, TP, TQ, idx, N, k, P, stats1, stats2,
-                       cc2, w2, slope, training, gy, y, usel2, dv1, dvsum, partial_dw2, partial_bn1);
+                       cc2, w2, slope, training, gy, y, hit2, dv1, dvsum, partial_dw2, partial_bn1);
 }
 
 }  // namespace dgcnn

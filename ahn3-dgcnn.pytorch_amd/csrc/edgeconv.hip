@@ -53,7 +53,7 @@ static SavedLayout saved_layout(const dgcnn_edgeconv_desc *d, void *p)
     s.TQ = c.take<float>(P * EC);
     s.usel = c.take<float>(P * EC);
     s.usum = c.take<float>(P * EC);   // sum over k of the stage-1 pre-activation (backward, training mode)
-    s.hitj = c.take<uint8_t>(P * EC);  // slot of the edge that wins max-over-k (one-stage block)
+    s.hitj = c.take<uint8_t>(P * EC);  // slot of the edge that wins max-over-k (of the block's last stage)
     s.stats1 = c.take<float>(ST_SIZE);
     s.stats2 = c.take<float>(ST_SIZE);
     s.wcat = c.take<float>((size_t)128 * d->C);  // [Wa ; Wb - Wa] of the forward, reused by the backward's dgrad
@@ -186,7 +186,8 @@ extern "C" int dgcnn_edgeconv_fwd(const dgcnn_edgeconv_desc *d, const float *x, 
             launch_bn_finalize(w.partial, 0, E, 0, d->bn1, d->eps, d->momentum, s.stats1, st);
             launch_bn_finalize(w.partial, 0, E, 0, d->bn2, d->eps, d->momentum, s.stats2, st);
         }
-        launch_edge_mlp_fwd(s.TP, s.TQ, idx, N, k, P, s.stats1, d->w2, d->bn2.weight, d->slope, s.usel, w.partial, st);
+        launch_edge_mlp_fwd(s.TP, s.TQ, idx, N, k, P, s.stats1, d->w2, d->bn2.weight, d->slope, s.usel, s.hitj, w.partial,
+                            st);
         if (d->training)
             launch_bn_finalize(w.partial, mlp_grid_fwd(P), E, 1, d->bn2, d->eps, d->momentum, s.stats2, st);
         launch_edge_out(s.usel, s.stats2, d->slope, P, y, st);
@@ -229,7 +230,7 @@ extern "C" int dgcnn_edgeconv_bwd(const dgcnn_edgeconv_desc *d, const float *x, 
     } else {
         launch_bwd_point(gy, s.usel, s.stats2, d->slope, P, E, d->training, w.partial, g->gbn2_w, g->gbn2_b, w.cc2, st);
         launch_edge_mlp_bwd(s.TP, s.TQ, idx, N, k, P, s.stats1, s.stats2, w.cc2, d->w2, d->slope, d->training, gy, y,
-                            s.usel, w.dv1, w.dvsum, w.dw2_partial, w.bn1_partial, st);
+                            s.hitj, w.dv1, w.dvsum, w.dw2_partial, w.bn1_partial, st);
         launch_sum_partials(w.dw2_partial, mlp_grid(P), EC * EC, g->gw2, st);
         launch_bn_bwd_finalize(w.bn1_partial, mlp_grid(P), E, d->training, g->gbn1_w, g->gbn1_b, w.cc1, st);
         if (d->training) {
