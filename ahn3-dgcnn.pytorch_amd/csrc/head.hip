@@ -9,31 +9,59 @@
 
 namespace dgcnn {
 
-constexpr int HEAD_ROWS_PER_BLOCK = 512;  // rows reduced by one workgroup (4 waves x 128 rows)
+constexpr int HEAD_ROWS_PER_BLOCK = 256;  // rows reduced by one workgroup (4 waves x 64 rows)
 
-// partial[chunk][2][C]: sum and sum of squares (fp64) of x over the chunk's rows; lane = column
+// partial[chunk][2][C]: sum and sum of squares (fp64) of x over the chunk's rows.  A lane owns four adjacent columns
+// (one 16-byte load per row: 1 KB per wave and row), the four waves of a workgroup take every fourth row, two rows in
+// flight per wave; C is a multiple of 4.
+constexpr int HEAD_COLS_PER_BLOCK = 256;
 __global__ __launch_bounds__(256) void colstats_kernel(const float *__restrict__ x, int P, int C,
                                                        double *__restrict__ partial)
 {
-    __shared__ double red[4][2][64];
+    __shared__ double red[4][2][HEAD_COLS_PER_BLOCK];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane;
+    const int c = blockIdx.x * HEAD_COLS_PER_BLOCK + 4 * lane;
     const int r0 = blockIdx.y * HEAD_ROWS_PER_BLOCK;
     const int r1 = r0 + HEAD_ROWS_PER_BLOCK < P ? r0 + HEAD_ROWS_PER_BLOCK : P;
-    double s = 0.0, ss = 0.0;
+    double s[4] = {0.0, 0.0, 0.0, 0.0}, ss[4] = {0.0, 0.0, 0.0, 0.0};
     if (c < C) {
-        for (int r = r0 + wave; r < r1; r += 4) {
-            const float v = x[(size_t)r * C + c];
-            s += (double)v;
-            ss = __builtin_fma((double)v, (double)v, ss);
+        int r = r0 + wave;
+        for (; r + 4 < r1; r += 8) {
+            const float4 v0 = *reinterpret_cast<const float4 *>(x + (size_t)r * C + c);
+            const float4 v1 = *reinterpret_cast<const float4 *>(x + (size_t)(r + 4) * C + c);
+            const float a[4] = {v0.x, v0.y, v0.z, v0.w}, b[4] = {v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s[e] += (double)a[e];
+                ss[e] = __builtin_fma((double)a[e], (double)a[e], ss[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s[e] += (double)b[e];
+                ss[e] = __builtin_fma((double)b[e], (double)b[e], ss[e]);
+            }
+        }
+        for (; r < r1; r += 4) {
+            const float4 v0 = *reinterpret_cast<const float4 *>(x + (size_t)r * C + c);
+            const float a[4] = {v0.x, v0.y, v0.z, v0.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s[e] += (double)a[e];
+                ss[e] = __builtin_fma((double)a[e], (double)a[e], ss[e]);
+            }
         }
     }
-    red[wave][0][lane] = s;
-    red[wave][1][lane] = ss;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        red[wave][0][4 * lane + e] = s[e];
+        red[wave][1][4 * lane + e] = ss[e];
+    }
     __syncthreads();
-    if (wave == 0 && c < C) {
-        partial[((size_t)blockIdx.y * 2 + 0) * C + c] = (red[0][0][lane] + red[1][0][lane]) + (red[2][0][lane] + red[3][0][lane]);
-        partial[((size_t)blockIdx.y * 2 + 1) * C + c] = (red[0][1][lane] + red[1][1][lane]) + (red[2][1][lane] + red[3][1][lane]);
+    const int cc = blockIdx.x * HEAD_COLS_PER_BLOCK + threadIdx.x;
+    if (cc < C) {
+        const int t = threadIdx.x;
+        partial[((size_t)blockIdx.y * 2 + 0) * C + cc] = (red[0][0][t] + red[1][0][t]) + (red[2][0][t] + red[3][0][t]);
+        partial[((size_t)blockIdx.y * 2 + 1) * C + cc] = (red[0][1][t] + red[1][1][t]) + (red[2][1][t] + red[3][1][t]);
     }
 }
 
@@ -110,34 +138,47 @@ __global__ void bn_lrelu_apply_kernel(const float *__restrict__ x, const float *
     reinterpret_cast<float4 *>(y)[t] = o;
 }
 
-// backward sums: partial[chunk][2][C] = sum dv, sum dv * xhat  with dv = gy * LeakyReLU'(v), sign(v) = sign(y)
+// backward sums: partial[chunk][2][C] = sum dv, sum dv * xhat  with dv = gy * LeakyReLU'(v), sign(v) = sign(y);
+// same thread layout as colstats_kernel
 __global__ __launch_bounds__(256) void bn_lrelu_bwd_reduce_kernel(const float *__restrict__ x, const float *__restrict__ y,
                                                                   const float *__restrict__ gy,
                                                                   const float *__restrict__ stats, int P, int C,
                                                                   float slope, double *__restrict__ partial)
 {
-    __shared__ double red[4][2][64];
+    __shared__ double red[4][2][HEAD_COLS_PER_BLOCK];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane;
+    const int c = blockIdx.x * HEAD_COLS_PER_BLOCK + 4 * lane;
     const int r0 = blockIdx.y * HEAD_ROWS_PER_BLOCK;
     const int r1 = r0 + HEAD_ROWS_PER_BLOCK < P ? r0 + HEAD_ROWS_PER_BLOCK : P;
-    double sb = 0.0, sg = 0.0;
+    double sb[4] = {0.0, 0.0, 0.0, 0.0}, sg[4] = {0.0, 0.0, 0.0, 0.0};
     if (c < C) {
-        const float mean = stats[c], rstd = stats[(size_t)C + c];
+        const float4 m4 = *reinterpret_cast<const float4 *>(stats + c), r4 = *reinterpret_cast<const float4 *>(stats + (size_t)C + c);
+        const float mean[4] = {m4.x, m4.y, m4.z, m4.w}, rstd[4] = {r4.x, r4.y, r4.z, r4.w};
         for (int r = r0 + wave; r < r1; r += 4) {
             const size_t o = (size_t)r * C + c;
-            const float dv = gy[o] * (y[o] > 0.0f ? 1.0f : slope);
-            const float xh = (x[o] - mean) * rstd;
-            sb += (double)dv;
-            sg = __builtin_fma((double)dv, (double)xh, sg);
+            const float4 g4 = *reinterpret_cast<const float4 *>(gy + o), y4 = *reinterpret_cast<const float4 *>(y + o);
+            const float4 x4 = *reinterpret_cast<const float4 *>(x + o);
+            const float g[4] = {g4.x, g4.y, g4.z, g4.w}, yv[4] = {y4.x, y4.y, y4.z, y4.w}, xv[4] = {x4.x, x4.y, x4.z, x4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float dv = g[e] * (yv[e] > 0.0f ? 1.0f : slope);
+                const float xh = (xv[e] - mean[e]) * rstd[e];
+                sb[e] += (double)dv;
+                sg[e] = __builtin_fma((double)dv, (double)xh, sg[e]);
+            }
         }
     }
-    red[wave][0][lane] = sb;
-    red[wave][1][lane] = sg;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        red[wave][0][4 * lane + e] = sb[e];
+        red[wave][1][4 * lane + e] = sg[e];
+    }
     __syncthreads();
-    if (wave == 0 && c < C) {
-        partial[((size_t)blockIdx.y * 2 + 0) * C + c] = (red[0][0][lane] + red[1][0][lane]) + (red[2][0][lane] + red[3][0][lane]);
-        partial[((size_t)blockIdx.y * 2 + 1) * C + c] = (red[0][1][lane] + red[1][1][lane]) + (red[2][1][lane] + red[3][1][lane]);
+    const int cc = blockIdx.x * HEAD_COLS_PER_BLOCK + threadIdx.x;
+    if (cc < C) {
+        const int t = threadIdx.x;
+        partial[((size_t)blockIdx.y * 2 + 0) * C + cc] = (red[0][0][t] + red[1][0][t]) + (red[2][0][t] + red[3][0][t]);
+        partial[((size_t)blockIdx.y * 2 + 1) * C + cc] = (red[0][1][t] + red[1][1][t]) + (red[2][1][t] + red[3][1][t]);
     }
 }
 
@@ -543,7 +584,7 @@ extern "C" int dgcnn_bn_lrelu_fwd(const float *x, int P, int C, const dgcnn_bn_p
     double *partial = (double *)workspace;
     const int nchunk = head_chunks(P);
     if (training)
-        hipLaunchKernelGGL(colstats_kernel, dim3(ceil_div(C, 64), nchunk), dim3(256), 0, st, x, P, C, partial);
+        hipLaunchKernelGGL(colstats_kernel, dim3(ceil_div(C, HEAD_COLS_PER_BLOCK), nchunk), dim3(256), 0, st, x, P, C, partial);
     hipLaunchKernelGGL(colstats_finalize_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, st, partial, nchunk, P, C, training,
                        bn->weight, bn->bias, bn->running_mean, bn->running_var, eps, momentum, stats);
     const size_t n4 = (size_t)P * C / 4;
@@ -563,7 +604,7 @@ extern "C" int dgcnn_bn_lrelu_bwd(const float *x, const float *y, const float *g
     const int nchunk = head_chunks(P);
     double *partial = (double *)workspace;
     float *cc = (float *)((char *)workspace + align_up((size_t)nchunk * 2 * C * sizeof(double), 256));
-    hipLaunchKernelGGL(bn_lrelu_bwd_reduce_kernel, dim3(ceil_div(C, 64), nchunk), dim3(256), 0, st, x, y, gy, stats, P, C,
+    hipLaunchKernelGGL(bn_lrelu_bwd_reduce_kernel, dim3(ceil_div(C, HEAD_COLS_PER_BLOCK), nchunk), dim3(256), 0, st, x, y, gy, stats, P, C,
                        slope, partial);
     hipLaunchKernelGGL(bn_bwd_finalize_cols_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, st, partial, nchunk, P, C,
                        training, gweight, gbias, cc);
@@ -597,7 +638,7 @@ extern "C" int dgcnn_bn_lrelu_max_fwd(const float *x, int B, int N, int C, const
     hkey *keys = (hkey *)((char *)workspace + dgcnn_bn_lrelu_workspace_bytes(P, C));
     const int nchunk = head_chunks(P);
     if (training)
-        hipLaunchKernelGGL(colstats_kernel, dim3(ceil_div(C, 64), nchunk), dim3(256), 0, st, x, P, C, partial);
+        hipLaunchKernelGGL(colstats_kernel, dim3(ceil_div(C, HEAD_COLS_PER_BLOCK), nchunk), dim3(256), 0, st, x, P, C, partial);
     hipLaunchKernelGGL(colstats_finalize_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, st, partial, nchunk, P, C, training,
                        bn->weight, bn->bias, bn->running_mean, bn->running_var, eps, momentum, stats);
     if (hipMemsetAsync(keys, 0, (size_t)B * C * sizeof(hkey), st) != hipSuccess) DG_FAIL("dgcnn_bn_lrelu_max_fwd: memset failed");
