@@ -115,6 +115,10 @@ class DGCNN(nn.Module):
         the intermediate the reference returns at that depth (model.py:151-189).
         `idx` (list of three int [B, N, k] tensors) injects the neighbour graphs of the three blocks;
         `return_idx=True` additionally returns the graphs used (both are test hooks)."""
+        with ops.batch_counters():  # the eight `num_batches_tracked += 1` as one multi-tensor add
+            return self._forward(x, depth, idx, return_idx)
+
+    def _forward(self, x, depth, idx, return_idx):
         in_dev = x.device
         xd = _to_device(x)
         B, _, N = xd.shape

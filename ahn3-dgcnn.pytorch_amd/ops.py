@@ -11,6 +11,31 @@ import torch
 from . import _lib
 
 
+class batch_counters:
+    """Context in which the `num_batches_tracked += 1` of every BatchNorm stage (one tiny kernel each: eight per
+    DGCNN forward) is collected and applied as ONE multi-tensor add on exit.  Outside it the counters are bumped at
+    once, as nn.BatchNorm does."""
+    _open = None
+
+    def __enter__(self):
+        self._outer, batch_counters._open = batch_counters._open, []
+        return self
+
+    def __exit__(self, *exc):
+        pending, batch_counters._open = batch_counters._open, self._outer
+        if pending and exc[0] is None:
+            torch._foreach_add_(pending, 1)
+        return False
+
+
+def _count_batch(bn):
+    if bn is not None and bn.num_batches_tracked is not None:
+        if batch_counters._open is not None:
+            batch_counters._open.append(bn.num_batches_tracked)
+        else:
+            bn.num_batches_tracked += 1
+
+
 def _f32c(t, name):
     _lib.require_device(t, name)
     if t.dtype != torch.float32:
@@ -203,8 +228,7 @@ def edgeconv_pm(x_pm, idx, w1, bn1, w2=None, bn2=None, training=False, slope=0.2
                         float(bn1.eps), float(momentum), float(slope))
     if training:
         for bn in (bn1, bn2):
-            if bn is not None and bn.num_batches_tracked is not None:
-                bn.num_batches_tracked += 1
+            _count_batch(bn)
     return y
 
 
@@ -257,8 +281,8 @@ def bn_lrelu_rows(x, bn, training, slope=0.2):
     momentum = bn.momentum if bn.momentum is not None else 0.1
     y = _BNLReLURows.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bool(use_batch_stats),
                            float(bn.eps), float(momentum), float(slope))
-    if training and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked += 1
+    if training:
+        _count_batch(bn)
     return y
 
 
@@ -315,8 +339,8 @@ def bn_lrelu_max_rows(x, bn, B, N, training, slope=0.2):
     momentum = bn.momentum if bn.momentum is not None else 0.1
     g, _ = _BNLReLUMax.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, int(B), int(N),
                              bool(use_batch_stats), float(bn.eps), float(momentum), float(slope))
-    if training and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked += 1
+    if training:
+        _count_batch(bn)
     return g
 
 
@@ -447,8 +471,8 @@ def embed_max_rows(cat, w, bn, B, N, training, slope=0.2):
     momentum = bn.momentum if bn.momentum is not None else 0.1
     g = _EmbedMax.apply(cat, w, bn.weight, bn.bias, bn.running_mean, bn.running_var, int(B), int(N),
                         bool(use_batch_stats), float(bn.eps), float(momentum), float(slope))
-    if training and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked += 1
+    if training:
+        _count_batch(bn)
     return g
 
 
