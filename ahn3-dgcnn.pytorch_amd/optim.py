@@ -31,23 +31,44 @@ class FlatAdam:
         if self.grad.numel() != total:
             raise ValueError("grad_buffer has %d elements, the parameters %d" % (self.grad.numel(), total))
         off = 0
+        self._grad_views = []
         with torch.no_grad():
             for p in uniq:
                 n = p.numel()
                 self.flat[off:off + n].copy_(p.reshape(-1))
                 p.data = self.flat[off:off + n].view_as(p)       # the module now computes on views of the flat buffer
-                if own_grads:
-                    p.grad = self.grad[off:off + n].view_as(p)   # backward accumulates in place
+                self._grad_views.append(self.grad[off:off + n].view_as(p))
                 off += n
         self.exp_avg = torch.zeros_like(self.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat)
         self.steps = 0
 
-    def zero_grad(self, set_to_none=False):
-        """(`set_to_none` is accepted for torch.optim parity; the gradients are views of the flat buffer and stay)"""
-        self.grad.zero_()
+    def zero_grad(self, set_to_none=True):
+        """set_to_none=True (torch's default): drop the .grad tensors, so that backward hands each parameter its
+        gradient without an accumulation kernel (25 tiny launches per step otherwise); `step` packs them into the
+        flat buffer with one multi-tensor copy.  set_to_none=False: the .grad tensors become (zeroed) views of the flat
+        buffer and backward accumulates in place -- what a shared parallel.FlatGradAllReduce buffer expects."""
+        if set_to_none:
+            for p in self.params:
+                p.grad = None
+        else:
+            self.grad.zero_()
+            for p, v in zip(self.params, self._grad_views):
+                p.grad = v
+
+    def _pack_grads(self):
+        src, dst = [], []
+        for p, v in zip(self.params, self._grad_views):
+            if p.grad is None:
+                v.zero_()  # (torch.optim.Adam would skip such a parameter; every DGCNN parameter gets a gradient)
+            elif p.grad.data_ptr() != v.data_ptr():
+                src.append(p.grad)
+                dst.append(v)
+        if src:
+            torch._foreach_copy_(dst, src)
 
     def step(self):
+        self._pack_grads()
         self.steps += 1
         lib = _lib.load()
         _lib.check(lib.dgcnn_adam_step(_lib.ptr(self.flat), _lib.ptr(self.grad), _lib.ptr(self.exp_avg),

@@ -88,7 +88,8 @@ def test_bad_arguments_raise():
         ops.seg_loss(torch.randn(1, 5, 10), torch.zeros(1, 10))   # CPU tensor: no fallback
 
 
-def test_flat_adam_matches_torch_adam():
+@pytest.mark.parametrize("set_to_none", [True, False])
+def test_flat_adam_matches_torch_adam(set_to_none):
     from ahn3_dgcnn_pytorch_amd.optim import FlatAdam
     g = torch.Generator().manual_seed(0)
     shapes = [(64, 8, 1, 1), (64,), (64,), (5, 256, 1), (1000, 3)]
@@ -98,11 +99,15 @@ def test_flat_adam_matches_torch_adam():
     opt = FlatAdam(mine, lr=1e-3, weight_decay=1e-4)
     for step in range(10):
         opt_r.zero_grad()
-        opt.zero_grad()
+        opt.zero_grad(set_to_none=set_to_none)
         for pr, pm in zip(ref, mine):
             gr = torch.randn(pr.shape, generator=g) * (10.0 ** (step % 3 - 1))
             pr.grad = gr.clone()
-            pm.grad.copy_(gr.to(_dev()))
+            if set_to_none:
+                assert pm.grad is None
+                pm.grad = gr.to(_dev())            # what backward does when .grad is None
+            else:
+                pm.grad.add_(gr.to(_dev()))        # ... and when it is a (zeroed) view of the flat buffer
         opt_r.step()
         opt.step()
     for pr, pm in zip(ref, mine):
