@@ -15,9 +15,12 @@ import torch.distributed as dist
 
 
 class FlatGradAllReduce:
-    """Packs the gradients of `params` into one flat buffer (the .grad of every parameter becomes a
-    view into it, so backward accumulates in place and no per-step packing copy is needed) and
-    averages it across the process group with a single all-reduce."""
+    """Keeps the gradients of `params` in one flat buffer and averages it across the process group with a
+    single all-reduce.  `zero()` drops the .grad tensors, so that backward hands every parameter its
+    gradient without an accumulation kernel, and `sync()` packs them into the flat buffer with ONE
+    multi-tensor copy and re-points every .grad at its slice; with `zero(set_to_none=False)` the .grad
+    tensors stay (zeroed) views of the buffer and backward accumulates in place (gradient accumulation
+    over several backward passes)."""
 
     def __init__(self, params, group=None):
         self.params = [p for p in params if p.requires_grad]
@@ -34,21 +37,43 @@ class FlatGradAllReduce:
         dev, dt = self.params[0].device, self.params[0].dtype
         total = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(total, dtype=dt, device=dev)
-        off = 0
+        self.views, off = [], 0
         for p in self.params:
             n = p.numel()
-            p.grad = self.flat[off:off + n].view_as(p)
+            self.views.append(self.flat[off:off + n].view_as(p))
+            p.grad = self.views[-1]
             off += n
 
     @property
     def world_size(self):
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
 
-    def zero(self):
-        self.flat.zero_()
+    def zero(self, set_to_none=True):
+        if set_to_none:
+            for p in self.params:
+                p.grad = None
+        else:
+            self.flat.zero_()
+            for p, v in zip(self.params, self.views):
+                p.grad = v
+
+    def pack(self):
+        """gather the .grad tensors backward produced into the flat buffer (one multi-tensor copy); afterwards every
+        .grad is a view of its slice again"""
+        src, dst = [], []
+        for p, v in zip(self.params, self.views):
+            if p.grad is None:
+                v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr():
+                src.append(p.grad)
+                dst.append(v)
+            p.grad = v
+        if src:
+            torch._foreach_copy_(dst, src)
 
     def sync(self):
         """sum over ranks, then divide by the world size (gradient of the mean loss over the global batch)."""
+        self.pack()
         ws = self.world_size
         if ws > 1:
             if self._avg is None:

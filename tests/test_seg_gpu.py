@@ -142,51 +142,29 @@ def test_training_step_with_device_loss_and_flat_adam():
     b.train()
     opt_a = torch.optim.Adam(a.parameters(), lr=1e-3, weight_decay=1e-4)
     opt_b = FlatAdam(b.parameters(), lr=1e-3, weight_decay=1e-4)
-    # step 1 starts from identical weights; Adam's first update is lr * sign(g) for every weight, so a weight whose
-    # gradient is rounding noise may land 2 lr apart in the two runs and the second step's losses differ accordingly
-    for tol in (1e-6, 2e-4):
+    # Step 1 starts from identical weights: same loss, same gradients, same update.  Adam's first update is
+    # lr * sign(g) for every weight, so after it a weight whose gradient is rounding noise may sit 2 lr apart in the two
+    # runs, and max-over-k / max-over-points winners near a tie may change: from step 2 on only the loss is compared.
+    def one_step(tol):
         opt_a.zero_grad()
         la, _ = seg_ref.step_loss(a(x), lab)
         la.backward()
-        opt_a.step()
         opt_b.zero_grad()
         lb, _ = ops.seg_loss(b(x), lab)
         lb.backward()
-        opt_b.step()
         assert abs(la.item() - lb.item()) <= tol * max(1.0, abs(la.item()))
-    for (na, pa), (nb, pb) in zip(a.named_parameters(), b.named_parameters()):
-        assert na == nb
-        # Adam's first steps move every weight by ~lr whatever the size of its gradient, so a weight whose gradient is
-        # rounding noise may differ by up to 2 lr per step: compare the mean
-        assert (pa - pb).abs().mean().item() <= 1e-4, na
+        grads = [(n, pa.grad.clone(), pb.grad.clone()) for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters())]
+        opt_a.step()
+        opt_b.step()
+        return grads
 
-
-def test_model_input_is_a_view_of_point_major_memory():
-    from ahn3_dgcnn_pytorch_amd import blocks
-    pts = torch.rand(2, 100, 4, dtype=torch.float64)
-    x = blocks.to_model_input(pts)
-    assert x.shape == (2, 4, 100) and x.dtype == torch.float32 and x.is_cuda
-    assert x.permute(0, 2, 1).is_contiguous()
-    assert torch.equal(x.cpu(), pts.permute(0, 2, 1).float())
-
-
-def test_classify_block_matches_reference_steps():
-    import numpy as np
-    from ahn3_dgcnn_pytorch_amd import DGCNN, blocks
-    from oracle import seg_ref
-    from param_fill import fill_module
-    m = DGCNN(5, 4, 8, dropout=0.5, emb_dims=1024, cuda=True)
-    fill_module(m)
-    rs = np.random.RandomState(3)
-    X = rs.rand(400, 4) * np.array([30.0, 30.0, 20.0, 20.0]) + np.array([1000.0, 2000.0, 0.0, 0.0])
-    X0 = X.copy()
-    pred = blocks.classify_block(m, X, min_class_confidence=0.3)
-    assert np.array_equal(X, X0) and pred.shape == (400, 1)
-    # the same steps with the reference's tensor ops on the model's logits
-    Xl = X - np.array([X[:, 0].min(), X[:, 1].min(), 0.0, 0.0])
-    m.eval()
-    with torch.no_grad():
-        logits = m(torch.tensor(Xl[:, :, np.newaxis]).permute(2, 1, 0).float().cuda()).cpu()
-    pred_r, val_r = seg_ref.predict_step(logits, 0.3)
-    safe = ((val_r - 0.3).abs() > 1e-5).reshape(-1).numpy()
-    assert np.array_equal(pred.reshape(-1)[safe], pred_r.reshape(-1).numpy()[safe])
+    # (some gradients are zero in exact arithmetic -- e.g. bn6.bias: a shift of the pooled feature is removed by bn7 --
+    # and pure rounding noise in both runs, which Adam turns into +-lr steps: compare above a noise floor only)
+    grads = one_step(1e-6)
+    for (n, ga, gb), (_, pa), (_, pb) in zip(grads, a.named_parameters(), b.named_parameters()):
+        floor = 1e-6 * ga.numel() ** 0.5
+        assert (ga - gb).norm().item() <= 1e-3 * max(ga.norm().item(), floor), n
+        solid = ga.abs() > 1e-3          # well above the weight-decay term (1e-4 |w|) and the noise
+        if solid.any():
+            assert (pa - pb).abs()[solid].max().item() <= 2e-5, n
+    one_step(2e-4)
