@@ -168,3 +168,34 @@ def test_training_step_with_device_loss_and_flat_adam():
         if solid.any():
             assert (pa - pb).abs()[solid].max().item() <= 2e-5, n
     one_step(2e-4)
+
+
+def test_model_input_is_a_view_of_point_major_memory():
+    from ahn3_dgcnn_pytorch_amd import blocks
+    pts = torch.rand(2, 100, 4, dtype=torch.float64)
+    x = blocks.to_model_input(pts)
+    assert x.shape == (2, 4, 100) and x.dtype == torch.float32 and x.is_cuda
+    assert x.permute(0, 2, 1).is_contiguous()
+    assert torch.equal(x.cpu(), pts.permute(0, 2, 1).float())
+
+
+def test_classify_block_matches_reference_steps():
+    import numpy as np
+    from ahn3_dgcnn_pytorch_amd import DGCNN, blocks
+    from oracle import seg_ref
+    from param_fill import fill_module
+    m = DGCNN(5, 4, 8, dropout=0.5, emb_dims=1024, cuda=True)
+    fill_module(m)
+    rs = np.random.RandomState(3)
+    X = rs.rand(400, 4) * np.array([30.0, 30.0, 20.0, 20.0]) + np.array([1000.0, 2000.0, 0.0, 0.0])
+    X0 = X.copy()
+    pred = blocks.classify_block(m, X, min_class_confidence=0.3)
+    assert np.array_equal(X, X0) and pred.shape == (400, 1)
+    # the same steps with the reference's tensor ops on the model's logits
+    Xl = X - np.array([X[:, 0].min(), X[:, 1].min(), 0.0, 0.0])
+    m.eval()
+    with torch.no_grad():
+        logits = m(torch.tensor(Xl[:, :, np.newaxis]).permute(2, 1, 0).float().cuda()).cpu()
+    pred_r, val_r = seg_ref.predict_step(logits, 0.3)
+    safe = ((val_r - 0.3).abs() > 1e-5).reshape(-1).numpy()
+    assert np.array_equal(pred.reshape(-1)[safe], pred_r.reshape(-1).numpy()[safe])
