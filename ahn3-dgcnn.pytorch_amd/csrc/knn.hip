@@ -368,16 +368,13 @@ __device__ __forceinline__ float knn_f16_eps(float yy_i, float cmax, float xx_i,
            1e-5f * (yy_i + cmax) + 8e-6f * (xx_i + rmax) + 1e-30f;
 }
 
-// One wave = RT x 32 query rows (RT row tiles share every candidate-operand load: the pre-pass is
-// bound by L2 -> CU traffic, not by arithmetic).  F16 = true: xop are the fp16 centred tiles, xn the
-// centred norms; F16 = false (small C): xop are the fp32 tiles of knn_tile_kernel, xn the raw norms,
-// and the arithmetic is exactly the one of knn_kernel.
-// WIDE (fp32 variant only): 128 classes per row (candidate tile index mod 4 x 32 lanes) instead of 64, for 40 < k <= 64.
-template <int CP, bool F16, int RT, bool WIDE = false>
-__global__ __launch_bounds__(64) void knn_bound_kernel(const void *__restrict__ xop, const float *__restrict__ xn,
-                                                       const float *__restrict__ xx_raw,
-                                                       const unsigned *__restrict__ bmax, int B, int Npad, int k,
-                                                       float *__restrict__ tau0, float *__restrict__ epsr)
+// Threshold pre-pass for small C (CP = 4, 8) in exact fp32.  One wave = RT x 32 query rows; xop are the fp32 tiles
+// of knn_tile_kernel, xn the raw norms, and the arithmetic is exactly the one of knn_kernel.  (C >= 16 uses
+// knn_bound16s_kernel on the fp16 matrix cores.)
+// WIDE: 128 classes per row (candidate tile index mod 4 x 32 lanes) instead of 64, for 40 < k <= 64.
+template <int CP, int RT, bool WIDE = false>
+__global__ __launch_bounds__(64) void knn_bound_kernel(const void *__restrict__ xop, const float *__restrict__ xn, int B,
+                                                       int Npad, int k, float *__restrict__ tau0)
 {
     const int lane = threadIdx.x, h = lane >> 5, j32 = lane & 31;
     const int b = blockIdx.x % B, rb0 = (blockIdx.x / B) * RT;  // first row tile of this wave
@@ -391,38 +388,7 @@ __global__ __launch_bounds__(64) void knn_bound_kernel(const void *__restrict__ 
 #pragma unroll
         for (int r = 0; r < 16; ++r) m0[rt][r] = m1[rt][r] = m2[rt][r] = m3[rt][r] = -__builtin_inff();
 
-    if constexpr (F16) {
-        constexpr int KS = CP / 16;
-        const half8 *xb = reinterpret_cast<const half8 *>(xop) + (size_t)b * ntiles * KS * 64 + lane;
-        half8 a[RT][KS], b0[KS], b1[KS];
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) a[rt][ks] = xb[((size_t)(rb0 + rt) * KS + ks) * 64];
-        auto tile = [&](const half8(&bop)[KS], float xl, float(&m)[RT][16]) {
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-                f32x16 acc;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rt][ks], bop[ks], acc, 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) m[rt][r] = fmaxf(m[rt][r], __builtin_fmaf(2.0f, acc[r], -xl));
-            }
-        };
-        for (int t = 0; t < ntiles; t += 2) {
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                b0[ks] = xb[((size_t)t * KS + ks) * 64];
-                b1[ks] = xb[((size_t)(t + 1) * KS + ks) * 64];
-            }
-            const float x0 = xnb[t * 32 + j32], x1 = xnb[(t + 1) * 32 + j32];
-            tile(b0, x0, m0);
-            tile(b1, x1, m1);
-        }
-    } else {
+    {
         constexpr int CH = CP / 2;
         constexpr int VEC = CH >= 4 ? 4 : CH;
         constexpr int G = CH / VEC;
@@ -480,7 +446,6 @@ __global__ __launch_bounds__(64) void knn_bound_kernel(const void *__restrict__ 
     }
 
     // k-th largest of the 64 class maxima of every row, minus the row's own norm and the error bound
-    const float cmax = F16 ? batch_max(bmax, b, 0, Npad / 32) : 0.0f, rmax = F16 ? batch_max(bmax, b, 1, Npad / 32) : 0.0f;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
@@ -504,19 +469,10 @@ __global__ __launch_bounds__(64) void knn_bound_kernel(const void *__restrict__ 
                 const unsigned kth = __builtin_amdgcn_readlane(key, k - 1);
                 const float vk = __uint_as_float((kth & 0x80000000u) ? (kth & 0x7fffffffu) : ~kth);
                 const int row = (rb0 + rt) * 32 + mfma32_row(r, hh);
-                const float xi = xnb[row], xr = xx_raw[(size_t)b * Npad + row];
-                float t, eps = 0.0f;
-                if constexpr (F16) {
-                    eps = knn_f16_eps(xi, cmax, xr, rmax);
-                    t = (vk - xi) - eps;
-                } else {
-                    const float pd = vk - xi;  // same fp32 operations as knn_kernel
-                    t = pd - fmaxf(__builtin_fabsf(pd) * 4.8e-7f, 1e-37f);
-                }
-                if (lane == 0) {
-                    tau0[(size_t)b * Npad + row] = (t != t) ? -__builtin_inff() : t;  // NaN -> no bound
-                    if (epsr) epsr[(size_t)b * Npad + row] = eps;
-                }
+                const float xi = xnb[row];
+                const float pd = vk - xi;  // same fp32 operations as knn_kernel
+                const float t = pd - fmaxf(__builtin_fabsf(pd) * 4.8e-7f, 1e-37f);
+                if (lane == 0) tau0[(size_t)b * Npad + row] = (t != t) ? -__builtin_inff() : t;  // NaN -> no bound
             }
         }
     }
@@ -1476,17 +1432,15 @@ static void knn_launch_cp(int cap, int B, hipStream_t st, const float *xt, const
         hipLaunchKernelGGL((knn_kernel<CP, 128>), grid, block, 0, st, xt, xx, tau0, rbflag, B, N, Npad, k, idx);
 }
 
-template <int CP, bool F16>
-static void knn_bound_launch(int B, hipStream_t st, const void *xop, const float *xn, const float *xx,
-                             const unsigned *bmax, int Npad, int k, float *tau0, float *epsr)
+template <int CP>
+static void knn_bound_launch(int B, hipStream_t st, const void *xop, const float *xn, int Npad, int k, float *tau0)
 {
     constexpr int RT = 1;  // (2 row tiles per wave halve the L2 traffic but measured slower: fewer waves)
-    if (!F16 && k > 40)
-        hipLaunchKernelGGL((knn_bound_kernel<CP, false, RT, true>), dim3(B * (Npad / (32 * RT))), dim3(64), 0, st, xop, xn, xx,
-                           bmax, B, Npad, k, tau0, epsr);
+    if (k > 40)
+        hipLaunchKernelGGL((knn_bound_kernel<CP, RT, true>), dim3(B * (Npad / (32 * RT))), dim3(64), 0, st, xop, xn, B, Npad, k,
+                           tau0);
     else
-        hipLaunchKernelGGL((knn_bound_kernel<CP, F16, RT>), dim3(B * (Npad / (32 * RT))), dim3(64), 0, st, xop, xn, xx, bmax,
-                           B, Npad, k, tau0, epsr);
+        hipLaunchKernelGGL((knn_bound_kernel<CP, RT>), dim3(B * (Npad / (32 * RT))), dim3(64), 0, st, xop, xn, B, Npad, k, tau0);
 }
 
 struct KnnWs {
@@ -1622,9 +1576,9 @@ extern "C" int dgcnn_knn(const float *x, int B, int N, int C, int k, int32_t *id
                                    Npad, k, w.tau0, w.eps);
             prof_end(PROF_KNN_BOUND, st);
         } else if (CP == 8) {
-            knn_bound_launch<8, false>(B, st, xt, xx, xx, w.bmax, Npad, k, w.tau0, nullptr);
+            knn_bound_launch<8>(B, st, xt, xx, Npad, k, w.tau0);
         } else {
-            knn_bound_launch<4, false>(B, st, xt, xx, xx, w.bmax, Npad, k, w.tau0, nullptr);
+            knn_bound_launch<4>(B, st, xt, xx, Npad, k, w.tau0);
         }
         DG_CHECK_LAUNCH("knn_bound_kernel");
         tau0 = w.tau0;
