@@ -105,7 +105,8 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_loss_kernel(const float *__re
                     dot = __builtin_fmaf(p[c], gp[c], dot);
                 }
             }
-        loss = -(double)acc;
+        // a label outside [0, classes) has no target column (the reference's scatter fails on it): poison the loss
+        loss = (lab >= 0 && lab < nn) ? -(double)acc : (double)__builtin_nanf("");
         pred[t] = arg;
         const int b = t / vw.N, n = t - b * vw.N;
         float *gp_out = gz + (long long)b * vw.sb + (long long)n * vw.sn;

@@ -180,7 +180,8 @@ int dgcnn_embed_max_bwd_scatter(const int32_t *arg, const float *s, const float 
  * points, and the arg-max prediction (train.py:201, :271).  mask (optional, uint8 [B*N]) selects the points that
  * take part, as train.py:182-196 does it: rows get one extra column, (p, 0) with the point's label where mask != 0
  * and (0, ..., 0, 1) with label `classes` elsewhere.  loss: one float; grad_logits (same strides as logits) =
- * d loss / d logits, computed in the same pass; pred int64 [B*N].  classes <= 32. */
+ * d loss / d logits, computed in the same pass; pred int64 [B*N].  classes <= 32.  A label outside [0, classes)
+ * (where the reference's scatter raises) makes the loss NaN. */
 size_t dgcnn_seg_loss_workspace_bytes(int B, int N);
 int dgcnn_seg_loss(const float *logits, int B, int N, int classes, int64_t stride_b, int64_t stride_c,
                    int64_t stride_n, const int64_t *labels, const uint8_t *mask, float smoothing, float *loss,

@@ -79,6 +79,14 @@ def test_seg_predict_matches_reference_ops(C, conf):
         assert (pred.cpu() == seg_ref.UNCLASSIFIED).any()
 
 
+def test_label_out_of_range_poisons_the_loss():
+    from ahn3_dgcnn_pytorch_amd import ops
+    z, lab, _ = _case(1, 5, 100, 9)
+    lab[0, 17] = 5
+    loss, _ = ops.seg_loss(z.to(_dev()), lab.to(_dev()))
+    assert torch.isnan(loss).item()
+
+
 def test_bad_arguments_raise():
     from ahn3_dgcnn_pytorch_amd import _lib, ops
     z = torch.randn(1, 40, 10, device=_dev())
