@@ -7,6 +7,7 @@ reference's own business and stay out ("out of scope").
     collate_pcs     <- data.py:169-182   batch of tiles, each subsampled (without replacement) to the smallest one
     to_model_input  <- train.py:175-176, test.py:118-119   .to(device), permute(0, 2, 1), .float()
     classify_block  <- test.py:296-311   block-local x / y, forward, softmax, max, confidence threshold
+    classify_blocks <- test.py:281-330   the loop over a tile's blocks: points and labels stacked in block order
 """
 import numpy as np
 import torch
@@ -64,3 +65,15 @@ def classify_block(model, X, min_class_confidence=0.0, unclassified=UNCLASSIFIED
     finally:
         model.train(was_training)
     return pred.cpu().numpy().reshape(-1, 1)
+
+
+def classify_blocks(model, block_data, min_class_confidence=0.0, unclassified=UNCLASSIFIED):
+    """Labels of every block of a tile (the loop of test.py:281-330 without its file output): block_data is an
+    iterable of ndarrays [n_i, F]; returns (points [sum n_i, F] stacked in block order, labels int64 [sum n_i, 1])."""
+    pts, preds = [], []
+    for X in block_data:
+        pts.append(np.asarray(X, dtype=np.float64))
+        preds.append(classify_block(model, X, min_class_confidence, unclassified))
+    if not pts:
+        return np.zeros((0, 0)), np.zeros((0, 1), dtype=np.int64)
+    return np.vstack(pts), np.vstack(preds)

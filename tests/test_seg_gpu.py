@@ -207,3 +207,17 @@ def test_classify_block_matches_reference_steps():
     pred_r, val_r = seg_ref.predict_step(logits, 0.3)
     safe = ((val_r - 0.3).abs() > 1e-5).reshape(-1).numpy()
     assert np.array_equal(pred.reshape(-1)[safe], pred_r.reshape(-1).numpy()[safe])
+
+
+def test_classify_blocks_stacks_in_block_order():
+    import numpy as np
+    from ahn3_dgcnn_pytorch_amd import DGCNN, blocks
+    from param_fill import fill_module
+    m = DGCNN(5, 4, 8, dropout=0.5, emb_dims=1024, cuda=True)
+    fill_module(m)
+    rs = np.random.RandomState(5)
+    tiles = [rs.rand(n, 4) * 30.0 for n in (120, 64, 200)]
+    pts, preds = blocks.classify_blocks(m, tiles, 0.25)
+    assert pts.shape == (384, 4) and preds.shape == (384, 1)
+    assert np.array_equal(pts[120:184], tiles[1])
+    assert np.array_equal(preds[120:184], blocks.classify_block(m, tiles[1], 0.25))
