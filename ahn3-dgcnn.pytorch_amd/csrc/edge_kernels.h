@@ -16,7 +16,7 @@ int wgrad_chunks(int P);
 void launch_wgrad(const float *A0, int M0, const float *A1, int M1, const float *X, int C, int P, float *partial,
                   hipStream_t st);
 // G [128][C] = sum of the partials, then gw1[o][c]:  c < C: G[o][c] - G[64 + o][c];  c >= C: G[64 + o][c - C]
-void launch_finish_dw1(const float *partial, int nchunk, int C, float *G, float *gw1, hipStream_t st);
+void launch_finish_dw1(const float *partial, int nchunk, int C, float *gw1, hipStream_t st);
 // out[e] = sum_chunk partial[chunk][e]   (fixed order: deterministic)
 void launch_sum_partials(const float *partial, int nchunk, int n, float *out, hipStream_t st);
 

@@ -242,7 +242,7 @@ extern "C" int dgcnn_edgeconv_bwd(const dgcnn_edgeconv_desc *d, const float *x, 
         }
     }
     launch_wgrad(w.dR, EC, w.dD, EC, x, C, P, w.wg_partial, st);
-    launch_finish_dw1(w.wg_partial, wgrad_chunks(P), C, w.wg_sum, g->gw1, st);
+    launch_finish_dw1(w.wg_partial, wgrad_chunks(P), C, g->gw1, st);
     if (g->gx) launch_rowgemm(w.dR, EC, w.dD, EC, s.wcat, C, g->gx, C, nullptr, P, st);
     DG_CHECK_LAUNCH("dgcnn_edgeconv_bwd");
     return 0;

@@ -270,13 +270,56 @@ __global__ __launch_bounds__(1024) void sum_partials_kernel(const float *__restr
     }
 }
 
-// gw1 [64][2C] from G = dWcat [128][C]:  c < C: G[o][c] - G[64 + o][c];  c >= C: G[64 + o][c - C]
-__global__ void finish_dw1_kernel(const float *__restrict__ G, int C, float *__restrict__ gw1)
+// gw1 [64][2C] of the block's first convolution from the per-chunk partial products G = [dR ; dD]^T x ([128][C]):
+// W = [Wa | Wb] acts as Wa x_j + (Wb - Wa) x_i, so gWa = G_R - G_D (c < C: G[o][c] - G[64 + o][c]) and gWb = G_D
+// (c >= C: G[64 + o][c - C]).  Same summation order as sum_partials_kernel (sixteen waves take consecutive shares of
+// the chunks, eight chunks in flight) for both sources of an output element, then one subtraction: one launch instead
+// of a sum followed by a combine kernel.
+__global__ __launch_bounds__(1024) void finish_dw1_kernel(const float *__restrict__ partial, int nchunk, int C,
+                                                          float *__restrict__ gw1)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= EC * 2 * C) return;
-    const int o = t / (2 * C), c = t % (2 * C);
-    gw1[t] = c < C ? G[(size_t)o * C + c] - G[(size_t)(EC + o) * C + c] : G[(size_t)(EC + o) * C + (c - C)];
+    __shared__ float red[SUM_WAVES][2][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int t = blockIdx.x * 64 + lane, n = 128 * C;
+    const int q = (nchunk + SUM_WAVES - 1) / SUM_WAVES;
+    const int c0 = w * q, c1 = c0 + q < nchunk ? c0 + q : nchunk;
+    float sr = 0.0f, sd = 0.0f;
+    const bool live = t < EC * 2 * C;
+    const int o = live ? t / (2 * C) : 0, c = live ? t % (2 * C) : 0;
+    const bool first = c < C;  // a gWa column: both sources
+    const int er = o * C + (first ? c : 0), ed = (EC + o) * C + (first ? c : c - C);
+    if (live) {
+        int ch = c0;
+        for (; ch + 8 <= c1; ch += 8) {
+            float vr[8], vd[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                vd[u] = partial[(size_t)(ch + u) * n + ed];
+                vr[u] = first ? partial[(size_t)(ch + u) * n + er] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                sd += vd[u];
+                sr += vr[u];
+            }
+        }
+        for (; ch < c1; ++ch) {
+            sd += partial[(size_t)ch * n + ed];
+            sr += first ? partial[(size_t)ch * n + er] : 0.0f;
+        }
+    }
+    red[w][0][lane] = sr;
+    red[w][1][lane] = sd;
+    __syncthreads();
+    if (w == 0 && live) {
+        float tr = red[0][0][lane], td = red[0][1][lane];
+#pragma unroll
+        for (int i = 1; i < SUM_WAVES; ++i) {
+            tr += red[i][0][lane];
+            td += red[i][1][lane];
+        }
+        gw1[t] = first ? tr - td : td;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -394,10 +437,9 @@ void launch_wgrad(const float *A0, int M0, const float *A1, int M1, const float 
 #undef DG_WG
 }
 
-void launch_finish_dw1(const float *partial, int nchunk, int C, float *G, float *gw1, hipStream_t st)
+void launch_finish_dw1(const float *partial, int nchunk, int C, float *gw1, hipStream_t st)
 {
-    launch_sum_partials(partial, nchunk, 128 * C, G, st);
-    hipLaunchKernelGGL(finish_dw1_kernel, dim3(ceil_div(EC * 2 * C, 256)), dim3(256), 0, st, G, C, gw1);
+    hipLaunchKernelGGL(finish_dw1_kernel, dim3(ceil_div(EC * 2 * C, 64)), dim3(1024), 0, st, partial, nchunk, C, gw1);
 }
 
 void launch_sum_partials(const float *partial, int nchunk, int n, float *out, hipStream_t st)
