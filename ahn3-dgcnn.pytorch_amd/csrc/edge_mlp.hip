@@ -23,6 +23,7 @@
 #include <stdlib.h>
 
 #include "edge_kernels.h"
+#include "prof.h"
 
 namespace dgcnn {
 
@@ -457,8 +458,10 @@ void launch_edge_mlp_fwd(const float *TP, const float *TQ, const int32_t *idx, i
                          const float *stats1, const float *w2, const float *gamma2, float slope, float *usel2,
                          uint8_t *hit2, double *partial, hipStream_t st)
 {
+    prof_begin(PROF_EDGE_MLP_FWD, st);
     hipLaunchKernelGGL(edge_mlp_fwd_kernel, dim3(mlp_grid_fwd(P)), dim3(256), 0, st, TP, TQ, idx, N, k, P, stats1, w2,
                        gamma2, slope, usel2, hit2, partial);
+    prof_end(PROF_EDGE_MLP_FWD, st);
 }
 
 void launch_edge_mlp_bwd(const float *TP, const float *TQ, const int32_t *idx, int N, int k, int P,
@@ -466,8 +469,10 @@ void launch_edge_mlp_bwd(const float *TP, const float *TQ, const int32_t *idx, i
                          int training, const float *gy, const float *y, const uint8_t *hit2, float *dv1, float *dvsum,
                          float *partial_dw2, double *partial_bn1, hipStream_t st)
 {
+    prof_begin(PROF_EDGE_MLP_BWD, st);
     hipLaunchKernelGGL(edge_mlp_bwd_kernel, dim3(mlp_grid(P)), dim3(64 * MLP_BWD_WAVES), 0, st, TP, TQ, idx, N, k, P, stats1, stats2,
                        cc2, w2, slope, training, gy, y, hit2, dv1, dvsum, partial_dw2, partial_bn1);
+    prof_end(PROF_EDGE_MLP_BWD, st);
 }
 
 }  // namespace dgcnn

@@ -16,7 +16,8 @@ struct ProfState {
     Region r[PROF_NREGION];
 } g_prof;
 const char *const kNames[PROF_NREGION] = {"knn_bound16s_kernel", "knn_filter16_kernel", "knn_refine_kernel",
-                                          "edge_reduce_kernel", "edge_rgather_kernel"};
+                                          "edge_reduce_kernel", "edge_rgather_kernel", "edge_mlp_fwd_kernel",
+                                          "edge_mlp_bwd_kernel"};
 }  // namespace
 
 void prof_begin(int region, hipStream_t st)

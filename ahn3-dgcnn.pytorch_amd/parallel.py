@@ -14,6 +14,33 @@ import torch
 import torch.distributed as dist
 
 
+def _host_staged(t, group):
+    """gloo (the CPU rehearsal backend) moves host memory: a device buffer goes through a host copy.  RCCL ("nccl")
+    reduces device memory in place."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def all_reduce_sum(t, group=None):
+    if _host_staged(t, group):
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+def broadcast(t, src=0, group=None):
+    """same tensor on every rank (initial parameters of the replicas)"""
+    if _host_staged(t, group):
+        h = t.cpu()
+        dist.broadcast(h, src, group=group)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src, group=group)
+    return t
+
+
 class FlatGradAllReduce:
     """Keeps the gradients of `params` in one flat buffer and averages it across the process group with a
     single all-reduce.  `zero()` drops the .grad tensors, so that backward hands every parameter its
@@ -84,7 +111,7 @@ class FlatGradAllReduce:
                     return self.flat
                 except RuntimeError:  # a build without ncclAvg: sum and scale instead
                     self._avg = False
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            all_reduce_sum(self.flat, self.group)
             self.flat.div_(ws)
         return self.flat
 
@@ -97,7 +124,7 @@ def sync_buffers(module, group=None):
     if not bufs:
         return
     flat = torch.cat([b.reshape(-1) for b in bufs])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    all_reduce_sum(flat, group)
     flat.div_(dist.get_world_size(group))
     off = 0
     for b in bufs:

@@ -1,27 +1,39 @@
 """bench.py -- EdgeConv fwd+bwd throughput on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload block|train]
 
-A "step" is one pass of the hot path over one batch of synthetic point features that is already
-resident in HBM: kNN graph build in 64-d feature space -> EdgeConv block (conv 128->64 + BatchNorm
-(batch statistics) + LeakyReLU(0.2) [+ conv 64->64 + BN + LReLU with --stages 2] -> max over k)
-forward, then its backward for a fixed cotangent (gradients w.r.t. the features and every
-parameter).  Workload = BASELINE.json configs[1]: B=8, N=7000, k=30, C=64 per GPU.  With N GPUs
-every rank runs that workload on its own shard (weak scaling: the batch elements are independent
-units) and the step ends with one RCCL all-reduce of the flat parameter-gradient buffer.
+`--gpus N` with N > 1 and no launcher environment: this process starts the N ranks itself (one process per GPU, as a
+`python -m torch.distributed.run` child, BEFORE it touches the GPU) and relays their output.  Under the driver's own
+launcher (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...`) it is one of the
+ranks.  It never falls back to fewer ranks: WORLD_SIZE != --gpus exits non-zero.
 
-Rank 0 prints ONE JSON line (the contract of the build prompt) with two extra objects:
-  roofline     -- the dominant kernel (the largest of the five profiled kernels of the path): algorithmic
-                  bytes or flops / its HIP-event time (events recorded inside the C ABI on the launch
-                  stream), against the HBM or fp16-MFMA peak of MI355X_MICROARCH.md; the other four follow
-                  in `kernels`, the whole kNN graph build in `knn`
-  cpu_baseline -- oracle/torch_ref.py (the reference's own PyTorch-CPU op sequence) timed on the
-                  host cores of the same box on a bounded sample of the same workload
+Workloads
+  block (default; BASELINE.json configs[1], the configuration the metric is quoted on): one step = kNN graph build in
+        64-d feature space -> EdgeConv block (conv 128->64 + BatchNorm(batch statistics) + LeakyReLU(0.2) [+ conv
+        64->64 + BN + LReLU with --stages 2] -> max over k) forward, then its backward for a fixed cotangent, on
+        B=8, N=7000, k=30, C=64 per GPU, resident in HBM.  With N GPUs every rank runs that workload on its own shard
+        (weak scaling: batch elements are independent units) and the step ends with one RCCL all-reduce of the flat
+        parameter-gradient buffer.  The same line carries `train_step`: configs[3] measured in the same run (below).
+  train (BASELINE.json configs[3]): one step = the reference's training step on synthetic blocks -- float64 [B, N, 4]
+        points -> fp32 (train.py:175-176) -> full DGCNN forward (model.py:144-193) -> softmax + cal_loss + arg-max
+        (train.py:180,197,201) -> backward -> ONE RCCL all-reduce of the 980 864-float gradient buffer -> Adam step
+        (train.py:118,199); global B=32 sharded B/N per GPU (strong scaling), N=7000, k=30, dropout 0.5.
+
+Rank 0 prints ONE JSON line (the contract of the build prompt) with
+  roofline     -- the dominant kernel (largest of the profiled kernels): algorithmic flops or bytes / its HIP-event time
+                  (events recorded inside the C ABI on the launch stream).  `bound` is "mfma" (vs the dense fp16 or fp32
+                  MFMA peak), "hbm" (vs 8 TB/s) or "l2-gather" (row gathers served by the XCD's L2: vs the guide's
+                  L2-resident gathered-row rate); gather kernels also carry `hbm_frac` = PMC-counter HBM bytes / time /
+                  8 TB/s.  The others follow in `kernels`.
+  cpu_baseline -- oracle/torch_ref.py (the reference's own PyTorch-CPU op sequence) timed on the host cores of the same
+                  box on a bounded sample of the same workload.
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -29,20 +41,164 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-# keep rank 0's stdout to the one JSON line: RCCL writes its version banner and its warnings (missing iommu=pt,
-# unreadable topology nodes in a container) to stdout unless told otherwise
-if os.environ.get("NCCL_DEBUG", "VERSION").upper() in ("VERSION", "INFO"):
-    os.environ["NCCL_DEBUG"] = "WARN"
-os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
-
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
-PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md, dense fp16/bf16 MFMA peak
-PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md, "HBM3E peak BW" (spec; 6.29 TB/s measured by a float4 copy)
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md, "HBM3E peak BW" (spec; ~6.3 TB/s achievable)
+PEAK_L2_GATHER_GBS = 18800.0   # MI355X_MICROARCH.md, "Indexed rows": rows shared by every workgroup, served by the
+                               # XCD's L2: 16.8-18.8 TB/s chip-wide
+TRAFFIC_FILE = os.path.join("profiles", "hbm_traffic.json")
 
 
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", choices=("block", "train"), default="block")
+    ap.add_argument("--profile-every", type=int, default=5,
+                    help="record the per-kernel HIP events on every n-th timed step (an event record costs GPU time)")
+    ap.add_argument("--stages", type=int, default=1, choices=(1, 2),
+                    help="block workload: 1 = conv5-shaped block (128->64); 2 = conv3+conv4-shaped block (128->64->64)")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="block: batch elements PER GPU (default 8); train: GLOBAL batch (default 32)")
+    ap.add_argument("--points", type=int, default=7000)
+    ap.add_argument("--k", type=int, default=30)
+    ap.add_argument("--channels", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train-leg", action="store_true", help="block workload: skip the configs[3] `train_step` object")
+    ap.add_argument("--train-steps", type=int, default=20, help="timed steps of the `train_step` leg of the block workload")
+    ap.add_argument("--cpu-sample-batch", type=int, default=None)
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
+                    help="nccl = RCCL over xGMI (the product path); gloo only to rehearse the N-rank code on a box "
+                         "with fewer GPUs than ranks (together with --same-device)")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    return ap.parse_args()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def self_launch(args):
+    """No launcher environment and --gpus N > 1: start the N ranks as a child `torch.distributed.run` (one process per
+    GPU).  Nothing in this process has touched the GPU, and it does not exec: it waits and exits with the child's code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
+
+
+def init_ranks(args):
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d: refusing to report a %d-rank number as a %d-GPU one"
+              % (args.gpus, world, world, args.gpus), file=sys.stderr)
+        raise SystemExit(2)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the EdgeConv path has no CPU fallback)")
+    ndev = torch.cuda.device_count()
+    dev_index = 0 if args.same_device else local_rank
+    if dev_index >= ndev:
+        raise SystemExit("bench.py: rank %d needs GPU %d but only %d are visible" % (rank, dev_index, ndev))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    if world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ):
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group("gloo")
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(2)
+    return rank, world, dev
+
+
+def fence():
+    import torch
+    import torch.distributed as dist
+    torch.cuda.synchronize()
+    if dist.is_initialized():
+        dist.barrier()
+        torch.cuda.synchronize()
+
+
+def max_over_ranks(value, dev):
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def timed_steps(step, n, every, dev):
+    """EXACTLY n steps between two fences; `step(sampled)` with sampled=True on every `every`-th.  Returns the wall
+    time, max over ranks."""
+    fence()
+    t0 = time.perf_counter()
+    for i in range(n):
+        step(every > 0 and i % every == 0)
+    fence()
+    return max_over_ranks(time.perf_counter() - t0, dev)
+
+
+def per_step_ms(step, n):
+    """a second, separate pass (not the one `value` comes from): every step bracketed by events -> the distribution"""
+    import torch
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+    torch.cuda.synchronize()
+    ev[0].record()
+    for i in range(n):
+        step(False)
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    return [ev[i].elapsed_time(ev[i + 1]) for i in range(n)]
+
+
+def region_times(lib):
+    return {lib.dgcnn_profile_region_name(r).decode(): (float(lib.dgcnn_profile_mean_ms(r)), int(lib.dgcnn_profile_samples(r)))
+            for r in range(lib.dgcnn_profile_regions())}
+
+
+def kernel_entries(regions, work, traffic):
+    """one roofline entry per profiled kernel that ran; largest first"""
+    out = []
+    for name, (ms, n) in regions.items():
+        if n == 0 or ms <= 0 or name not in work:
+            continue
+        bound, amount, peak, note = work[name]
+        flops = bound == "mfma"
+        ach = amount / (ms * 1e-3) / (1e12 if flops else 1e9)
+        e = {"kernel": name, "bound": bound, "achieved": ach, "peak": peak, "unit": "TFLOP/s" if flops else "GB/s",
+             "frac": ach / peak, "traffic": None, "kernel_ms": ms, "samples": n,
+             "algorithmic_%s_per_launch" % ("flops" if flops else "bytes"): amount, "note": note}
+        t = traffic.get(name)
+        if t is not None:
+            e["traffic"] = t
+            e["traffic_source"] = TRAFFIC_FILE + " (rocprofv3 --pmc passes of this workload, committed; not re-measured in this run)"
+            e["hbm_frac"] = t / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS
+        out.append(e)
+    out.sort(key=lambda d: -d["kernel_ms"])
+    return out
+
+
+def load_traffic(key):
+    path = os.path.join(ROOT, TRAFFIC_FILE)
+    if not os.path.exists(path):
+        return {}
+    with open(path) as f:
+        return json.load(f).get(key, {})
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# workload "block": BASELINE.json configs[1]
 def make_edge_stage(cin, cout=64):
     """parameter container of one edge-MLP stage: Conv2d 1x1 (no bias) + BatchNorm2d + LeakyReLU(0.2)
     (reference model.py:116-130)"""
@@ -61,17 +217,24 @@ def make_stages(C, n_stage, device):
     return stages
 
 
-def cpu_baseline(B, N, k, C, n_stage, steps=4):
-    """The reference's CPU path (restated op-for-op in oracle/torch_ref.py: materialised BxNxN
-    distances, topk, gather/repeat/cat, Conv2d, BatchNorm2d, LeakyReLU, max) fwd+bwd on the host."""
-    from oracle import torch_ref
-    from param_fill import cotangent
+def cpu_threads():
+    import torch
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     # measured on the MI355X box's host (256 hardware threads): 8 / 16 / 32 / 64 / 128 / 256 threads give
-    # 20.6 / 20.4 / 25.1 / 19.0 / 12.0 / 3.9 k points/s, so the baseline runs at its best setting, 32
+    # 20.6 / 20.4 / 25.1 / 19.0 / 12.0 / 3.9 k points/s on the block, so the baseline runs at its best setting, 32
     # (the reference's own default is 8, train.py:36)
-    nthreads = min(avail, 32)
-    torch.set_num_threads(nthreads)
+    n = min(avail, 32)
+    torch.set_num_threads(n)
+    return n, avail
+
+
+def cpu_baseline_block(B, N, k, C, n_stage, steps=4):
+    """The reference's CPU path (restated op-for-op in oracle/torch_ref.py: materialised BxNxN
+    distances, topk, gather/repeat/cat, Conv2d, BatchNorm2d, LeakyReLU, max) fwd+bwd on the host."""
+    import torch
+    from oracle import torch_ref
+    from param_fill import cotangent
+    nthreads, avail = cpu_threads()
     stages = make_stages(C, n_stage, torch.device("cpu"))
     x = torch.randn(B, C, N, generator=torch.Generator().manual_seed(0))
     R = cotangent((B, 64, N), tag="bench")
@@ -92,44 +255,13 @@ def cpu_baseline(B, N, k, C, n_stage, steps=4):
                           B, N, k, C, n_stage, steps, dt, torch.__version__, nthreads, avail)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--profile-every", type=int, default=5,
-                    help="record the per-kernel HIP events on every n-th timed step (an event record costs GPU time)")
-    ap.add_argument("--stages", type=int, default=1, choices=(1, 2),
-                    help="1: conv5-shaped block (128->64); 2: conv3+conv4-shaped block (128->64->64)")
-    ap.add_argument("--batch", type=int, default=8, help="batch elements per GPU")
-    ap.add_argument("--points", type=int, default=7000)
-    ap.add_argument("--k", type=int, default=30)
-    ap.add_argument("--channels", type=int, default=64)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--graph", action="store_true",
-                    help="replay a captured hipGraph for the steps that are not sampled (measured: 0.627 ms against 0.612 ms "
-                         "eager on an idle host -- the GPU is the bottleneck either way; useful on a loaded host)")
-    ap.add_argument("--cpu-sample-batch", type=int, default=8)
-    args = ap.parse_args()
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and rank == 0:
-        print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device (the EdgeConv path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ  # under torch.distributed.run
-    if world > 1 or launched:
-        dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
-
+def run_block(args, rank, world, dev):
+    import torch
     from ahn3_dgcnn_pytorch_amd import _lib, ops
     from ahn3_dgcnn_pytorch_amd.parallel import FlatGradAllReduce
     from param_fill import cotangent
 
-    B, N, k, C = args.batch, args.points, args.k, args.channels
+    B, N, k, C = args.batch or 8, args.points, args.k, args.channels
     stages = make_stages(C, args.stages, dev)
     params = [p for st in stages for p in st.parameters()]
     sync = FlatGradAllReduce(params)
@@ -139,6 +271,7 @@ def main():
     w2 = stages[1][0].weight if args.stages == 2 else None
     bn2 = stages[1][1] if args.stages == 2 else None
     knn_events = []
+    lib = _lib.load()
 
     def step(sampled):
         sync.zero()
@@ -157,122 +290,241 @@ def main():
         if sampled:
             lib.dgcnn_profile_enable(0)
 
-    def fence():
-        torch.cuda.synchronize()
-        if dist.is_initialized():
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    lib = _lib.load()
     for _ in range(args.warmup):
         step(False)
-    fence()
-    # The step is ~50 kernel launches from Python.  Every C-ABI call only enqueues work on the current stream, so the
-    # whole step is capturable: with --graph the steps that are not sampled replay one captured hipGraph.
-    graph = None
-    if args.graph:
-        try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(2):
-                    step(False)
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                step(False)
-            for _ in range(2):
-                graph.replay()
-            fence()
-        except Exception as exc:  # capture is an optimisation of the harness, never a requirement
-            if rank == 0:
-                print("warning: hipGraph capture failed (%s: %s); launching eagerly" % (type(exc).__name__, exc), file=sys.stderr)
-            graph = None
-            torch.cuda.synchronize()
     lib.dgcnn_profile_enable(1)  # reset the sample rings ...
     lib.dgcnn_profile_enable(0)  # ... recording is switched on for the sampled steps only
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        if i % max(1, args.profile_every) == 0:
-            step(True)
-        elif graph is not None:
-            graph.replay()
-        else:
-            step(False)
-    fence()
-    dt = time.perf_counter() - t0
-    if dist.is_initialized():
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
+    dt = timed_steps(step, args.steps, max(1, args.profile_every), dev)
     knn_ms = sum(a.elapsed_time(b) for a, b in knn_events) / max(1, len(knn_events))
-    regions = {lib.dgcnn_profile_region_name(r).decode(): (float(lib.dgcnn_profile_mean_ms(r)), int(lib.dgcnn_profile_samples(r)))
-               for r in range(lib.dgcnn_profile_regions())}
+    regions = region_times(lib)
+    dist_ms = per_step_ms(step, min(args.steps, 50))
+    if rank != 0:
+        return None
+    P, E = B * N, B * N * k
+    knn_flops = 2.0 * B * N * N * C  # FLOPs_kNN = 2 B N^2 C
+    conv2 = 2.0 * E * 64 * 64
+    # Algorithmic work of one launch of each large kernel.
+    work = {
+        "knn_bound16s_kernel": ("mfma", knn_flops, PEAK_F16_MFMA_TFLOPS,
+                                "all B N^2 pairs once on fp16 MFMA (threshold pre-pass), 2 B N^2 C flops"),
+        "knn_filter16_kernel": ("mfma", knn_flops, PEAK_F16_MFMA_TFLOPS,
+                                "all B N^2 pairs once on fp16 MFMA (exact filter), 2 B N^2 C flops"),
+        "knn_refine_kernel": ("l2-gather", E * (4.0 * C + 4 + 4 + 4), PEAK_L2_GATHER_GBS,
+                              "exact fp32 distance of at least the k winners of every row: one C-float row, its norm and "
+                              "its list entry per winner, the index written; rows come from L2 (latency / VALU chain bound)"),
+        "edge_reduce_kernel": ("l2-gather", E * (256.0 + 4) + P * (256.0 * 3 + 64), PEAK_L2_GATHER_GBS,
+                               "per edge one fp32 [64] row of TP (1.8 MB table per batch element = one XCD's L2) and its "
+                               "index; per point TQ read, usel, usum, hitj written"),
+        "edge_rgather_kernel": ("l2-gather", (E * (256.0 + 4 + 32) if args.stages == 1 else E * (512.0 + 4)) + P * (8.0 + 512),
+                                PEAK_L2_GATHER_GBS,
+                                "per in-edge one fp32 [64] row of TQ (two-stage: also one row of dv1), its reverse-list entry "
+                                "and (one-stage) its hit record; per point list bounds, TP read, dR written"),
+        "edge_mlp_fwd_kernel": ("mfma", conv2, PEAK_F16_MFMA_TFLOPS,
+                                "conv 64->64 per edge, 2 E 64 64 flops; executed as 3 split-fp16 products on fp16 MFMA"),
+        "edge_mlp_bwd_kernel": ("mfma", 2 * conv2, PEAK_F32_MFMA_TFLOPS,
+                                "dgrad + wgrad of conv 64->64 per edge, 2 x 2 E 64 64 flops (the kernel also recomputes the "
+                                "forward product); see `mlp_bwd_math` for the MFMA type in this build"),
+    }
+    traffic = load_traffic("hbm_bytes_per_launch") if args.stages == 1 and (B, N, k, C) == (8, 7000, 30, 64) else {}
+    kernels = kernel_entries(regions, work, traffic)
+    out = {
+        "metric": "EdgeConv fwd+bwd points/sec (B=8,N=7000,k=30)",
+        "value": world * B * N * args.steps / dt,
+        "unit": "points/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "ms_per_step_median": statistics.median(dist_ms),
+        "ms_per_step_p10_p90": [sorted(dist_ms)[len(dist_ms) // 10], sorted(dist_ms)[(len(dist_ms) * 9) // 10]],
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32 (results); the kNN pre-filter runs on f16 MFMA and is followed by an exact f32 refine "
+                 "(indices bit-exact vs the f32 oracle)",
+        "data": "synthetic",
+        "config": {"workload": "single EdgeConv block fwd+bwd (kNN graph build + conv 128->64%s + BN(train) + "
+                               "LeakyReLU + max-over-k), BASELINE.json configs[1]" %
+                               (" + conv 64->64 + BN + LeakyReLU" if args.stages == 2 else ""),
+                   "batch_per_gpu": B, "points": N, "k": k, "channels": C, "stages": args.stages,
+                   "parallelism": "dp%d (batch elements sharded, one all-reduce of the flat grad buffer)" % world,
+                   "launch": "eager", "ranks": world, "backend": args.backend if world > 1 else None},
+        "roofline": kernels[0] if kernels else None,
+        "kernels": kernels[1:],
+        "knn": {"ms": knn_ms, "algorithmic_flops": knn_flops, "tflops": knn_flops / (knn_ms * 1e-3) / 1e12 if knn_ms else None,
+                "note": "whole dgcnn_knn call (prep + fp16 threshold pass + fp16 filter + exact fp32 refine); the "
+                        "distance products run on fp16 MFMA (so this exceeds the 157 TF f32 peak), the result is bit-exact f32"},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_block(min(args.cpu_sample_batch or 8, B), N, k, C, args.stages)
+        out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# workload "train": BASELINE.json configs[3]
+def synthetic_blocks(B, N, seed):
+    """what collate_pcs (data.py:169-182) hands to the training loop for .npy blocks [N, 5]: float64 points [B, N, 4]
+    (block-local x, y in [0, 30) m, z, AGL in [0, 20) m) and float64 labels [B, N] in 0..4"""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    pts = torch.rand(B, N, 4, generator=g, dtype=torch.float64) * torch.tensor([30.0, 30.0, 20.0, 20.0], dtype=torch.float64)
+    lab = torch.randint(0, 5, (B, N), generator=g).double()
+    return pts, lab
+
+
+def cpu_baseline_train(B, N, k, steps=2):
+    """the reference's training step on the host: RefDGCNN (model.py:144-193 op for op) forward, softmax + cal_loss
+    (train.py:180,197), backward, torch.optim.Adam step (train.py:118,199)"""
+    import torch
+    from oracle import seg_ref, torch_ref
+    nthreads, avail = cpu_threads()
+    torch.manual_seed(0)
+    m = torch_ref.RefDGCNN(5, 4, k, dropout=0.5)
+    m.train()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=1e-4)
+    pts, lab = synthetic_blocks(B, N, 0)
+
+    def step():
+        x = pts.permute(0, 2, 1).float()
+        opt.zero_grad()
+        loss, _ = seg_ref.step_loss(m(x), lab)
+        loss.backward()
+        opt.step()
+
+    step()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    dt = time.perf_counter() - t0
+    return {"value": B * N * steps / dt, "unit": "points/s", "cores": nthreads, "kind": "port",
+            "sample": "B=%d of the workload's 32 blocks (same N=%d, k=%d, full DGCNN training step), %d steps after 1 "
+                      "warm-up, %.1f s, torch %s with %d of %d hardware threads" % (
+                          B, N, k, steps, dt, torch.__version__, nthreads, avail)}
+
+
+def run_train(args, rank, world, dev, steps, warmup, with_cpu):
+    import torch
+    import torch.distributed as dist
+    from ahn3_dgcnn_pytorch_amd import DGCNN, _lib, blocks, ops
+    from ahn3_dgcnn_pytorch_amd.optim import FlatAdam
+    from ahn3_dgcnn_pytorch_amd.parallel import FlatGradAllReduce, broadcast, shard_batch
+
+    Bg, N, k = (args.batch if args.workload == "train" and args.batch else 32), args.points, args.k
+    if Bg % world:
+        raise SystemExit("bench.py: global batch %d is not divisible by %d ranks" % (Bg, world))
+    Bl = Bg // world
+    torch.manual_seed(0)                                  # the same initial weights on every rank
+    model = DGCNN(5, 4, k, dropout=0.5, emb_dims=1024, cuda=True)
+    model.train()
+    sync = FlatGradAllReduce(model.parameters())
+    opt = FlatAdam(model.parameters(), lr=1e-3, weight_decay=1e-4, grad_buffer=sync.flat)   # train.py:118
+    if dist.is_initialized() and world > 1:
+        broadcast(opt.flat, 0)
+    pts, lab = synthetic_blocks(Bg, N, 0)
+    pts = shard_batch(pts, rank, world).contiguous().to(dev)     # this rank's blocks, resident in HBM
+    lab = shard_batch(lab, rank, world).contiguous().to(dev)
+    torch.manual_seed(1234 + rank)                        # dropout masks differ per rank
+    lib = _lib.load()
+    ar_events = []
+
+    def step(sampled):
+        if sampled:
+            lib.dgcnn_profile_resume()
+        x = blocks.to_model_input(pts)                    # float64 -> fp32, [B, 4, N] view (train.py:175-176)
+        opt.zero_grad()                                   # train.py:178
+        loss, _pred = ops.seg_loss(model(x), lab)         # train.py:179-201 (softmax, cal_loss, arg-max) in one kernel
+        loss.backward()                                   # train.py:198
+        if sampled:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        sync.sync()                                       # ONE all-reduce of the flat 3.92 MB gradient buffer
+        if sampled:
+            e1.record()
+            ar_events.append((e0, e1))
+        opt.step()                                        # train.py:199
+        if sampled:
+            lib.dgcnn_profile_enable(0)
+
+    for _ in range(warmup):
+        step(False)
+    lib.dgcnn_profile_enable(1)
+    lib.dgcnn_profile_enable(0)
+    dt = timed_steps(step, steps, max(1, min(args.profile_every, steps)), dev)
+    regions = region_times(lib)
+    ar_ms = sum(a.elapsed_time(b) for a, b in ar_events) / max(1, len(ar_events))
+    dist_ms = per_step_ms(step, min(steps, 20))
+    ranks = dist.get_world_size() if dist.is_initialized() else 1
+    if rank != 0:
+        return None
+    E = Bl * N * k
+    conv2 = 2.0 * E * 64 * 64
+    work = {
+        "edge_mlp_fwd_kernel": ("mfma", conv2, PEAK_F16_MFMA_TFLOPS,
+                                "conv2 / conv4 per edge, 2 E 64 64 flops per launch; executed as 3 split-fp16 products"),
+        "edge_mlp_bwd_kernel": ("mfma", 2 * conv2, PEAK_F32_MFMA_TFLOPS,
+                                "dgrad + wgrad of conv2 / conv4 per edge, 2 x 2 E 64 64 flops per launch (the kernel also "
+                                "recomputes the forward product)"),
+    }
+    kernels = kernel_entries(regions, work, {})
+    step_flops = 12.04e6 * Bl * N   # BASELINE.md section 3: 12.04 MFLOP per point for the full training step
+    out = {
+        "metric": "DGCNN training-step points/sec (global B=%d,N=%d,k=%d)" % (Bg, N, k),
+        "value": Bg * N * steps / dt,
+        "unit": "points/s",
+        "n_gpus": world,
+        "steps": steps,
+        "warmup": warmup,
+        "ms_per_step": dt / steps * 1e3,
+        "ms_per_step_median": statistics.median(dist_ms),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32 (results); kNN pre-filter and the conv2/conv4 forward on f16 MFMA (split operands)",
+        "data": "synthetic",
+        "config": {"workload": "train.py step on synthetic blocks (f64 -> f32, DGCNN fwd, softmax + cal_loss, bwd, "
+                               "all-reduce of the flat gradient buffer, Adam), BASELINE.json configs[3]",
+                   "global_batch": Bg, "batch_per_gpu": Bl, "points": N, "k": k, "emb_dims": 1024, "dropout": 0.5,
+                   "parallelism": "dp%d (blocks sharded; per-replica BatchNorm statistics)" % world,
+                   "backend": (args.backend if world > 1 else None), "launch": "eager"},
+        "rccl_ranks": ranks,
+        "allreduce": {"ms": ar_ms, "bytes": sync.flat.numel() * 4, "samples": len(ar_events),
+                      "note": "pack (one multi-tensor copy) + one all-reduce (AVG) of %d floats" % sync.flat.numel()},
+        "step_tflops": step_flops / (dt / steps) / 1e12,
+        "roofline": kernels[0] if kernels else None,
+        "kernels": kernels[1:],
+    }
+    if with_cpu:
+        out["cpu_baseline"] = cpu_baseline_train(args.cpu_sample_batch or 2, N, k)
+        out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def main():
+    args = parse_args()
+    if "RANK" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args))
+
+    # keep rank 0's stdout to the one JSON line: RCCL writes its version banner and its warnings (missing iommu=pt,
+    # unreadable topology nodes in a container) to stdout unless told otherwise
+    if os.environ.get("NCCL_DEBUG", "VERSION").upper() in ("VERSION", "INFO"):
+        os.environ["NCCL_DEBUG"] = "WARN"
+    os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
+    import torch.distributed as dist
+
+    rank, world, dev = init_ranks(args)
+    cpu = world == 1 and not args.no_cpu_baseline
+    if args.workload == "train":
+        out = run_train(args, rank, world, dev, args.steps, args.warmup, cpu)
+    else:
+        out = run_block(args, rank, world, dev)
+        if not args.no_train_leg:
+            leg = run_train(args, rank, world, dev, args.train_steps, 3, cpu)
+            if out is not None:
+                out["train_step"] = leg
     if rank == 0:
-        P, E = B * N, B * N * k
-        knn_flops = 2.0 * B * N * N * C  # FLOPs_kNN = 2 B N^2 C
-        # Algorithmic work of one launch of each large kernel.
-        #  knn_bound16s / knn_filter16: each evaluates all B N^2 pairs once on fp16 MFMA -> 2 B N^2 C flops
-        #  knn_refine: exact fp32 distance of at least the k winners of every row: one C-float row, its norm and
-        #              its list entry per winner, the index row written
-        #  edge_reduce: per edge one fp32 [64] row of TP and its index; per point TQ (read), usel, usum, hitj (written)
-        #  edge_rgather: per edge one fp32 [64] row of TQ (two-stage blocks: also one row of dv), its reverse-list
-        #              entry and (one-stage) the 32-byte hit record; per point the list bounds, TP (read), dR (written)
-        work = {
-            "knn_bound16s_kernel": ("mfma", knn_flops, PEAK_F16_MFMA_TFLOPS),
-            "knn_filter16_kernel": ("mfma", knn_flops, PEAK_F16_MFMA_TFLOPS),
-            "knn_refine_kernel": ("hbm", E * (4.0 * C + 4 + 4 + 4), PEAK_HBM_GBS),
-            "edge_reduce_kernel": ("hbm", E * (256.0 + 4) + P * (256.0 * 3 + 64), PEAK_HBM_GBS),
-            "edge_rgather_kernel": ("hbm", (E * (256.0 + 4 + 32) if args.stages == 1 else E * (512.0 + 4)) + P * (8.0 + 512),
-                                    PEAK_HBM_GBS),
-        }
-        traffic_by_kernel = {}
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if args.stages == 1 and os.path.exists(tpath):  # measured on the one-stage workload
-            with open(tpath) as f:
-                traffic_by_kernel = json.load(f).get("hbm_bytes_per_launch", {})
-        kernels = []
-        for name, (ms, n) in regions.items():
-            bound, amount, peak = work[name]
-            unit = "TFLOP/s" if bound == "mfma" else "GB/s"
-            ach = amount / (ms * 1e-3) / (1e12 if bound == "mfma" else 1e9) if ms > 0 else 0.0
-            kernels.append({"kernel": name, "bound": bound, "achieved": ach, "peak": peak, "unit": unit,
-                            "frac": ach / peak, "traffic": traffic_by_kernel.get(name), "kernel_ms": ms, "samples": n,
-                            "algorithmic_%s_per_launch" % ("flops" if bound == "mfma" else "bytes"): amount})
-        kernels.sort(key=lambda d: -d["kernel_ms"])
-        out = {
-            "metric": "EdgeConv fwd+bwd points/sec (B=8,N=7000,k=30)",
-            "value": world * B * N * args.steps / dt,
-            "unit": "points/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": "single EdgeConv block fwd+bwd (kNN graph build + conv 128->64%s + BN(train) + "
-                                   "LeakyReLU + max-over-k), BASELINE.json configs[1]" %
-                                   (" + conv 64->64 + BN + LeakyReLU" if args.stages == 2 else ""),
-                       "batch_per_gpu": B, "points": N, "k": k, "channels": C, "stages": args.stages,
-                       "parallelism": "dp%d (batch elements sharded, one all-reduce of the flat grad buffer)" % world,
-                       "launch": "hipGraph replay of the captured step" if graph is not None else "eager"},
-            # the dominant kernel = the largest of the profiled kernels; the others follow in "kernels"
-            "roofline": kernels[0],
-            "kernels": kernels[1:],
-            "knn": {"ms": knn_ms, "algorithmic_flops": knn_flops, "tflops": knn_flops / (knn_ms * 1e-3) / 1e12,
-                    "frac_of_f32_mfma_peak": knn_flops / (knn_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                    "note": "whole dgcnn_knn call (prep + fp16 threshold pass + fp16 filter + exact fp32 refine); "
-                            "most of the distance arithmetic runs on fp16 MFMA, the result is bit-exact fp32"},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(min(args.cpu_sample_batch, B), N, k, C, args.stages)
-            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
 

@@ -12,9 +12,12 @@ CPU restatement, in plain PyTorch ops, of the steps either side of DGCNN.forward
 The masked rows are built with tensor ops instead of the reference's per-point Python loops (train.py:186-191); the
 rows are the same: (p, 0) with the point's label where the mask is set, (0, .., 0, 1) with label num_classes elsewhere.
 
-Parity status: restatement only.  util.py and train.py cannot be imported in this image (prettytable, tensorboard,
-h5py, laspy are absent -- SURVEY.md 8c caveat 2) and the reference holds no tests or vectors for these steps.
-Only tests/ may import this module.
+Parity status: PINNED.  util.py / train.py / test.py cannot be imported in this image (prettytable, tensorboard, h5py,
+laspy are absent -- SURVEY.md 8c caveat 2), so tests/golden/gen_golden.py takes the reference's own statements for
+these steps out of the files with `ast` (util.py:17-34, train.py:180-197 + :201, :268-271, test.py:123-127), executes
+them on fixed inputs and commits the results as tests/golden/seg_steps.npz; tests/test_oracle_golden.py holds this
+module to them on every run.
+Only tests/ and bench.py's cpu_baseline leg may import this module.
 """
 import torch
 import torch.nn.functional as F

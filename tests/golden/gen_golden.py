@@ -271,9 +271,97 @@ def gen_dup():
     save("dup_points.npz", x=npf(x), idx_reference_k4=idx.numpy().astype(np.int16), idx_fixed_tiebreak_k4=mine.astype(np.int16))
 
 
+def _ref_nodes(path, first, last, inside=None):
+    """the statements of a reference file whose source lines lie in [first, last] (taken from the outermost
+    block that holds whole statements in that range), as an executable ast.Module -- the reference's own code, run here, never stored"""
+    import ast
+    tree = ast.parse(open(path).read())
+    best = None
+    for node in ast.walk(tree):
+        for field in ("body", "orelse"):
+            body = getattr(node, field, None)
+            if not isinstance(body, list):
+                continue
+            picked = [st for st in body if isinstance(st, ast.stmt) and first <= st.lineno and st.end_lineno <= last]
+            if picked and best is None:     # ast.walk is breadth-first: the outermost block that holds such lines
+                best = picked
+    assert best, "no statements found in %s:%d-%d" % (path, first, last)
+    return ast.Module(body=best, type_ignores=[])
+
+
+def gen_seg():
+    """Pins oracle/seg_ref.py: util.py / train.py / test.py cannot be imported here
+    (prettytable, tensorboard, h5py, laspy are absent), so the reference's OWN statements are taken out of the files
+    with `ast` and executed on fixed inputs: cal_loss (util.py:17-34), the training step's softmax / mask / criterion /
+    arg-max lines (train.py:180-197, :201), the validation step's (train.py:268-271) and the inference post-step
+    (test.py:122-127)."""
+    import torch.nn.functional as F
+    from oracle import seg_ref
+    ns = {"torch": torch, "F": F, "np": np}
+    exec(compile(_ref_nodes("/root/reference/util.py", 17, 34), "util.py", "exec"), ns)
+    cal_loss = ns["cal_loss"]
+    g = torch.Generator().manual_seed(21)
+    B, C, N = 2, 5, 96
+    logits = torch.randn(B, C, N, generator=g) * 2.0
+    labels = torch.randint(0, C, (B, N), generator=g).double()          # collate_pcs hands float64 labels
+    mask = (torch.rand(B, N, generator=g) < 0.35).double()
+    out = {"logits": npf(logits), "labels": npf(labels), "mask": npf(mask)}
+
+    # training step, masked (train.py:180-197 and :201; loss.backward()/opt.step() at :198-199 are left out)
+    step = _ref_nodes("/root/reference/train.py", 180, 197)
+    tail = _ref_nodes("/root/reference/train.py", 201, 201)
+    z = logits.clone().requires_grad_(True)
+    env = dict(ns, labels_pred=z, labels=labels.clone(), mask=mask, num_classes=C, criterion=cal_loss)
+    exec(compile(step, "train.py", "exec"), env)
+    exec(compile(tail, "train.py", "exec"), env)
+    env["loss"].backward()
+    out.update(train_loss=npf(env["loss"]), train_pred=env["pred"].numpy(), train_grad=npf(z.grad))
+    zr = logits.clone().requires_grad_(True)
+    l2, p2 = seg_ref.step_loss(zr, labels, mask)
+    l2.backward()
+    assert abs(float(l2) - float(env["loss"])) <= 1e-7 and torch.equal(p2, env["pred"])
+    assert float((zr.grad - z.grad).abs().max()) <= 1e-9
+
+    # validation step, no mask (train.py:268-271; :267 is the model call)
+    val = _ref_nodes("/root/reference/train.py", 268, 271)
+    z = logits.clone().requires_grad_(True)
+    env = dict(ns, labels_pred=z, labels=labels.clone(), num_classes=C, criterion=cal_loss)
+    exec(compile(val, "train.py", "exec"), env)
+    env["loss"].backward()
+    out.update(val_loss=npf(env["loss"]), val_pred=env["pred"].numpy(), val_grad=npf(z.grad))
+    zr = logits.clone().requires_grad_(True)
+    l2, p2 = seg_ref.step_loss(zr, labels, None)
+    l2.backward()
+    assert abs(float(l2) - float(env["loss"])) <= 1e-7 and torch.equal(p2, env["pred"])
+    assert float((zr.grad - z.grad).abs().max()) <= 1e-9
+
+    # cal_loss itself on raw rows, smoothing on and off (util.py:17-34)
+    rows = torch.randn(64, 7, generator=g)
+    gold = torch.randint(0, 7, (64,), generator=g)
+    out.update(rows=npf(rows), gold=gold.numpy(), cal_loss_smooth=npf(cal_loss(rows, gold, smoothing=True)),
+               cal_loss_plain=npf(cal_loss(rows, gold, smoothing=False)))
+    assert abs(float(seg_ref.cal_loss(rows, gold, True)) - float(out["cal_loss_smooth"])) <= 1e-7
+    assert abs(float(seg_ref.cal_loss(rows, gold, False)) - float(out["cal_loss_plain"])) <= 1e-7
+
+    # inference post-step (test.py:123-127): seg_pred = model(data) is the input
+    post = _ref_nodes("/root/reference/test.py", 123, 127)
+    for conf in (0.0, 0.3, 0.6):
+        env = dict(ns, seg_pred=logits.clone(), softmax=F.softmax, min_class_confidence=conf, UNCLASSIFIED=31)
+        exec(compile(post, "test.py", "exec"), env)
+        out["predict_pred_%d" % int(conf * 10)] = env["pred"].numpy()
+        out["predict_vals_%d" % int(conf * 10)] = npf(env["vals"])
+        p2, v2 = seg_ref.predict_step(logits, conf)
+        assert torch.equal(p2, env["pred"]) and torch.equal(v2, env["vals"])
+    save("seg_steps.npz", **out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "seg":
+        gen_seg()
+        sys.exit(0)
     gen_knn()
     gen_model_small()
     gen_model_readme()
     gen_state_dict()
     gen_dup()
+    gen_seg()

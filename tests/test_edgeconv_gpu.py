@@ -145,6 +145,56 @@ def test_single_stage_block_at_benchmark_size(device):
     assert float((gx12 - (gx1 + gx2)).abs().max()) <= 1e-4 * float(gx12.abs().max())
 
 
+def _rel_l2(a, b):
+    return float((a - b).norm()) / max(1e-30, float(b.norm()))
+
+
+def test_two_stage_block_at_benchmark_size(device):
+    """conv3+conv4-shaped block (128 -> 64 -> 64: blocks 1 and 2 of the model, the largest share of its time) at
+    B=8, N=7000, k=30, C=64, train mode: the split-fp16 forward and the per-edge backward at full size.  Same gates
+    as the one-stage test: forward within 1e-4 everywhere; every gradient within 1e-3 in relative L2 (with 3.6 M
+    maxima a handful of winners are rounding-dependent on either side)."""
+    import copy
+    B, C, N, k = 8, 64, 7000, 30
+    x = torch.randn(B, C, N, generator=torch.Generator().manual_seed(43))
+    idx = ke.knn_exact(x.numpy(), k)
+    base = make_stages(2 * C, 2)
+    R = cotangent((B, 64, N), tag="big2s")
+    y0, gx0, st0 = run_oracle(x, idx, copy.deepcopy(base), True, R)
+    y1, gx1, st1 = run_hip(x, idx, copy.deepcopy(base), True, R, device)
+    np.testing.assert_allclose(y1.numpy(), y0.numpy(), rtol=0, atol=ATOL_FWD)
+    for si in range(2):
+        for a, b, what in ((st1[si][0].weight.grad.cpu(), st0[si][0].weight.grad, "conv weight"),
+                           (st1[si][1].weight.grad.cpu(), st0[si][1].weight.grad, "bn weight"),
+                           (st1[si][1].bias.grad.cpu(), st0[si][1].bias.grad, "bn bias")):
+            assert _rel_l2(a, b) <= 1e-3, "stage %d %s: %.3g" % (si, what, _rel_l2(a, b))
+        np.testing.assert_allclose(st1[si][1].running_mean.cpu().numpy(), st0[si][1].running_mean.numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(st1[si][1].running_var.cpu().numpy(), st0[si][1].running_var.numpy(), rtol=1e-5, atol=1e-6)
+    assert _rel_l2(gx1, gx0) <= 1e-3
+    # eval mode at the same size (running statistics; forward only needs the table kernels + the MFMA pass)
+    y0e, _, _ = run_oracle(x, idx, copy.deepcopy(base), False, R)
+    y1e, _, _ = run_hip(x, idx, copy.deepcopy(base), False, R, device)
+    np.testing.assert_allclose(y1e.numpy(), y0e.numpy(), rtol=0, atol=ATOL_FWD)
+
+
+@pytest.mark.parametrize("n_stage", [1, 2])
+def test_block_at_stress_size(n_stage, device):
+    """BASELINE.json configs[4] shape, one batch element: N=32768, k=64, C=64 (k=64 fills both 32-row MFMA tiles of
+    the two-stage kernels and the whole 64-slot hit mask of the one-stage ones)."""
+    import copy
+    B, C, N, k = 1, 64, 32768, 64
+    x = torch.randn(B, C, N, generator=torch.Generator().manual_seed(44))
+    idx = ke.knn_exact(x.numpy(), k)
+    base = make_stages(2 * C, n_stage)
+    R = cotangent((B, 64, N), tag="stress")
+    y0, gx0, st0 = run_oracle(x, idx, copy.deepcopy(base), True, R)
+    y1, gx1, st1 = run_hip(x, idx, copy.deepcopy(base), True, R, device)
+    np.testing.assert_allclose(y1.numpy(), y0.numpy(), rtol=0, atol=ATOL_FWD)
+    assert _rel_l2(gx1, gx0) <= 1e-3
+    for si in range(n_stage):
+        assert _rel_l2(st1[si][0].weight.grad.cpu(), st0[si][0].weight.grad) <= 1e-3
+
+
 def hub_graph(B, N, k, seed):
     """a neighbour graph (not a kNN graph) in which point 0 is everybody's first neighbour: in-degree N, which the
     backward has to cut into 128-edge segments; the other neighbours are random and distinct"""
@@ -195,9 +245,27 @@ def test_block_with_large_mean_inputs(device):
     R = cotangent((2, 64, 400), tag="edge")
     base = make_stages(8, 2)
     import copy
-    y0, gx0, _ = run_oracle(x, idx, copy.deepcopy(base), True, R)
-    y1, gx1, _ = run_hip(x, idx, base, True, R, device)
-    np.testing.assert_allclose(y1.numpy(), y0.numpy(), rtol=0, atol=2e-4)
+    y0, gx0, st0 = run_oracle(x, idx, copy.deepcopy(base), True, R)
+    y1, gx1, st1 = run_hip(x, idx, base, True, R, device)
+    # the same block in float64: who is how far from the exact result
+    b64 = [copy.deepcopy(s).double() for s in make_stages(8, 2)]
+    for s in b64:
+        s.train(True)
+    x64 = x.double().requires_grad_(True)
+    y64 = torch_ref.edgeconv_block(x64, 16, b64, idx=torch.from_numpy(idx.astype(np.int64)))
+    (y64 * R.double()).sum().backward()
+    err_hip, err_cpu = float((y1.double() - y64.detach()).abs().max()), float((y0.double() - y64.detach()).abs().max())
+    msg = "forward max abs error vs float64: HIP %.3g, PyTorch-CPU fp32 %.3g" % (err_hip, err_cpu)
+    np.testing.assert_allclose(y1.numpy(), y0.numpy(), rtol=0, atol=ATOL_FWD, err_msg=msg)
+    assert err_hip <= ATOL_FWD, msg
+    for a, b, c64, what in [(gx1, gx0, x64.grad, "grad x")] + [
+            (s1[0].weight.grad.cpu(), s0[0].weight.grad, s64[0].weight.grad, "grad conv weight %d" % i)
+            for i, (s0, s1, s64) in enumerate(zip(st0, st1, b64))]:
+        scale = float(c64.abs().max())
+        e_hip, e_cpu = float((a.double() - c64).abs().max()) / scale, float((b.double() - c64).abs().max()) / scale
+        assert float((a - b).abs().max()) <= RTOL_GRAD * float(b.abs().max()), \
+            "%s: HIP vs CPU %.3g; vs float64: HIP %.3g, CPU %.3g (relative to max)" % (
+                what, float((a - b).abs().max()) / float(b.abs().max()), e_hip, e_cpu)
 
 
 def test_get_graph_feature_matches_reference_golden(device):

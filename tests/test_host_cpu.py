@@ -101,3 +101,31 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(dirpath, fn)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), fn
                 assert "torch_ref" not in src and "knn_exact(" not in src, fn
+
+
+@pytest.mark.timeout(180)
+def test_bench_never_reports_fewer_ranks_than_asked():
+    """bench.py --gpus N: a launcher environment with another WORLD_SIZE is refused (non-zero, no JSON line); without
+    one, N > 1 starts N ranks as a child launcher, and with no HIP device every rank fails loudly -- there is no
+    1-rank or CPU fallback."""
+    import subprocess
+    import sys
+    if torch.cuda.is_available():
+        pytest.skip("CPU-only check")
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True,
+                       text=True, timeout=120)
+    assert p.returncode == 2 and "refusing" in p.stderr and "{" not in p.stdout
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
+                       capture_output=True, text=True, timeout=170)
+    assert p.returncode != 0 and "needs a HIP device" in p.stderr and "{" not in p.stdout
+
+
+def test_flat_adam_is_a_torch_optimizer_class():
+    from ahn3_dgcnn_pytorch_amd.optim import FlatAdam
+    assert issubclass(FlatAdam, torch.optim.Optimizer)
+    if not torch.cuda.is_available():
+        from ahn3_dgcnn_pytorch_amd import _lib
+        with pytest.raises(_lib.HipExtensionError):     # no CPU fallback
+            FlatAdam([torch.nn.Parameter(torch.zeros(4))])

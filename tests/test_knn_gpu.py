@@ -78,6 +78,18 @@ def test_knn_full_size_bit_exact(device):
     assert (got[:, :, 0] == np.arange(7000)[None]).all()  # self is neighbour 0 on tie-free data
 
 
+@pytest.mark.parametrize("C", [4, 64])
+def test_knn_stress_size_bit_exact(C, device):
+    # BASELINE.json configs[4]: N=32768, k=64 (one batch element; C=4 is block 1's search in the raw coordinates --
+    # the fp32 path -- and C=64 the feature-space search of blocks 2 and 3 -- the fp16 filter path)
+    rng = np.random.default_rng(5 + C)
+    if C == 4:
+        x = rng.random((1, 4, 32768)).astype(np.float32) * np.array([30, 30, 20, 20], np.float32)[None, :, None]
+    else:
+        x = rng.standard_normal((1, C, 32768)).astype(np.float32)
+    np.testing.assert_array_equal(_run(x, 64, device), ke.knn_exact(x, 64))
+
+
 # ---- the fp16 filter + exact refine path (C >= 16, k <= 40, N >= 256) must never change the result -------------
 def _feature_cases():
     rng = np.random.default_rng(99)

@@ -127,6 +127,37 @@ def test_readme_config_logits(device):
     np.testing.assert_allclose(ys.cpu().numpy(), g["logits"], rtol=0, atol=1e-4)
 
 
+@pytest.mark.timeout(900)
+def test_full_model_eval_at_benchmark_size(device):
+    """BASELINE.json configs[2]: full DGCNN eval forward at B=8, N=7000, k=30 on block-like coordinates (x, y in
+    [0, 30), z, AGL in [0, 20)).  Gate 3 of SURVEY.md 8c at full size: with the CPU restatement's own neighbour
+    graphs injected, logits within 1e-4 everywhere; end to end (HIP kNN) the fraction of points over tolerance is
+    bounded and block 1 (search in the raw coordinates) agrees on >= 99 % of the rows."""
+    from ahn3_dgcnn_pytorch_amd import DGCNN
+    from oracle import torch_ref
+    B, N, k = 8, 7000, 30
+    gen = torch.Generator().manual_seed(8)
+    x = (torch.rand(B, N, 4, generator=gen) * torch.tensor([30.0, 30.0, 20.0, 20.0])).permute(0, 2, 1)  # train.py:176 strides
+    ref = torch_ref.RefDGCNN(5, 4, k, dropout=0.5)
+    fill_module(ref)
+    ref.eval()
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    with torch.no_grad():
+        want, used_ref = ref(x, return_idx=True)
+    m = DGCNN(5, 4, k, dropout=0.5, emb_dims=1024, cuda=True)
+    fill_module(m)
+    m.eval()
+    with torch.no_grad():
+        got = m(x.to(device), idx=[u.to(torch.int32).to(device) for u in used_ref])
+        own, used = m(x.to(device), return_idx=True)
+    err = (got.cpu() - want).abs()
+    assert float(err.max()) <= 1e-4, "max |logit - reference| = %.3g" % float(err.max())
+    rows_equal = (used[0].cpu().numpy() == used_ref[0].numpy()).all(-1).mean()
+    assert rows_equal >= 0.99, rows_equal
+    frac = float(((own.cpu() - want).abs().amax(dim=1) > 1e-4).float().mean())
+    assert frac <= 0.02, "fraction of points whose logits differ by > 1e-4 end to end: %.4f" % frac
+
+
 def test_predict_style_input_and_ropout_alias(device):
     # test.py:304-306 builds X[N, F, 1] -> permute(2, 1, 0): fp32 [1, F, N] with strides (1, 1, F)
     from ahn3_dgcnn_pytorch_amd import DGCNN

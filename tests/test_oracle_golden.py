@@ -137,3 +137,26 @@ def test_knn_oracle_agreement_rate_with_torch_on_block_like_data():
         j = int(np.argmax(mine[bb, ii, :k] != ref[bb, ii]))
         gap = pd[bb, ii, j] - pd[bb, ii, j + 1]
         assert gap <= 64 * np.finfo(np.float32).eps * max(1.0, abs(pd[bb, ii, j]) + 2 * float((x[bb, :, ii] ** 2).sum()))
+
+
+def test_seg_ref_is_pinned_by_the_reference_statements():
+    """tests/golden/seg_steps.npz holds what the reference's OWN statements (util.py:17-34 cal_loss, train.py:180-197 +
+    :201 training step, :268-271 validation step, test.py:123-127 post-step; taken out of the files with `ast` by
+    gen_golden.py and executed there) return on fixed inputs: oracle/seg_ref.py must reproduce them."""
+    from oracle import seg_ref
+    g = load("seg_steps.npz")
+    logits, labels, mask = torch.from_numpy(g["logits"]), torch.from_numpy(g["labels"]), torch.from_numpy(g["mask"])
+    for tag, m in (("train", mask), ("val", None)):
+        z = logits.clone().requires_grad_(True)
+        loss, pred = seg_ref.step_loss(z, labels, m)
+        loss.backward()
+        assert abs(float(loss.detach()) - float(g[tag + "_loss"])) <= 1e-7
+        np.testing.assert_array_equal(pred.numpy(), g[tag + "_pred"])
+        np.testing.assert_allclose(z.grad.numpy(), g[tag + "_grad"], rtol=0, atol=1e-9)
+    rows, gold = torch.from_numpy(g["rows"]), torch.from_numpy(g["gold"])
+    assert abs(float(seg_ref.cal_loss(rows, gold, True)) - float(g["cal_loss_smooth"])) <= 1e-7
+    assert abs(float(seg_ref.cal_loss(rows, gold, False)) - float(g["cal_loss_plain"])) <= 1e-7
+    for conf in (0.0, 0.3, 0.6):
+        pred, vals = seg_ref.predict_step(logits, conf)
+        np.testing.assert_array_equal(pred.numpy(), g["predict_pred_%d" % int(conf * 10)])
+        np.testing.assert_array_equal(vals.numpy(), g["predict_vals_%d" % int(conf * 10)])

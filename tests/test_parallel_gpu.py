@@ -1,0 +1,123 @@
+"""The PRODUCT data-parallel step on the GPU: two fresh processes (one per rank, as deployed; both on
+cuda:0 of the one-GPU box, exchange over gloo -- on the 8-GPU node the same code runs over RCCL), each running the HIP
+DGCNN on its shard -> device loss -> backward -> FlatGradAllReduce.sync -> FlatAdam.step.  Expectation = the same model
+run shard by shard in ONE process, gradients averaged, one FlatAdam step on the average (per-replica BatchNorm
+statistics, running buffers averaged).  Also: bench.py starts its own ranks and refuses rank-count mismatches."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+WORLD = 2
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _env():
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["OMP_NUM_THREADS"] = "2"
+    return env
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_product_step_matches_shardwise_run(tmp_path, device):
+    sys.path.insert(0, HERE)
+    import dp_child
+    from ahn3_dgcnn_pytorch_amd.optim import FlatAdam
+    from ahn3_dgcnn_pytorch_amd.parallel import FlatGradAllReduce
+    g = torch.Generator().manual_seed(0)
+    B, N = 4, 384
+    cfg = {"classes": 5, "k": 8,
+           "x": torch.rand(B, 4, N, generator=g) * torch.tensor([30.0, 30.0, 20.0, 20.0]).view(1, 4, 1),
+           "labels": torch.randint(0, 5, (B, N), generator=g)}
+    fin, fout = str(tmp_path / "in.pt"), str(tmp_path / "out.pt")
+    torch.save(cfg, fin)
+    port = str(_free_port())
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dp_child.py"), str(r), str(WORLD), port, "gloo", fin, fout],
+                              env=_env(), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(WORLD)]
+    outs = [p.communicate(timeout=540)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-4000:]
+    got = torch.load(fout, weights_only=False)
+    assert got["ranks"] == WORLD
+
+    # shard-wise single-process run of the same product model
+    want, rms, losses = None, [], []
+    for r in range(WORLD):
+        m = dp_child.build_model(cfg)
+        sync = FlatGradAllReduce(m.parameters())
+        opt = FlatAdam(m.parameters(), lr=1e-3, weight_decay=1e-4, grad_buffer=sync.flat)
+        per = B // WORLD
+        loss, red = dp_child.local_step(m, cfg["x"][r * per:(r + 1) * per].to(device),
+                                        cfg["labels"][r * per:(r + 1) * per].to(device), sync, opt)
+        want = red.cpu() if want is None else want + red.cpu()
+        rms.append(m.bn1.running_mean.cpu())
+        losses.append(float(loss))
+    want = want / WORLD
+    scale = float(want.abs().max())
+    assert float((got["reduced"] - want).abs().max()) <= 2e-5 * scale     # (the backward's sum order is not fixed)
+    assert abs(got["loss"] - losses[0]) <= 1e-6 * max(1.0, abs(losses[0]))
+    torch.testing.assert_close(got["rm1"], (rms[0] + rms[1]) / 2, rtol=1e-5, atol=1e-6)
+    # one FlatAdam step on the averaged gradient from the same initial weights
+    m = dp_child.build_model(cfg)
+    sync = FlatGradAllReduce(m.parameters())
+    opt = FlatAdam(m.parameters(), lr=1e-3, weight_decay=1e-4, grad_buffer=sync.flat)
+    p0 = opt.flat.cpu().clone()
+    sync.flat.copy_(got["reduced"].to(device))
+    for p, v in zip(sync.params, sync.views):
+        p.grad = v
+    opt.step()
+    assert torch.equal(opt.flat.cpu(), got["params"])      # same kernel, same inputs: the update is bit-identical
+    assert float((got["params"] - p0).abs().max()) > 0
+
+
+def _bench(args, timeout=540):
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=_env(), capture_output=True,
+                          text=True, timeout=timeout)
+
+
+@pytest.mark.timeout(600)
+def test_bench_starts_its_own_ranks_for_the_train_workload():
+    """`python bench.py --gpus 2` without a launcher environment starts two ranks itself (rehearsed on one GPU over
+    gloo) and reports the configs[3] training step with the all-reduce in it."""
+    env_had_rank = "RANK" in os.environ
+    assert not env_had_rank
+    p = _bench(["--gpus", "2", "--workload", "train", "--backend", "gloo", "--same-device", "--batch", "4",
+                "--points", "512", "--k", "8", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"])
+    assert p.returncode == 0, (p.stdout + p.stderr)[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["scaling"] == "strong"
+    assert out["config"]["global_batch"] == 4 and out["config"]["batch_per_gpu"] == 2
+    assert out["allreduce"]["bytes"] == 980864 * 4 and out["allreduce"]["ms"] > 0
+    assert out["value"] > 0 and out["unit"] == "points/s"
+
+
+@pytest.mark.timeout(300)
+def test_bench_refuses_a_rank_count_mismatch():
+    env = _env()
+    env.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=240)
+    assert p.returncode != 0 and "refusing" in p.stderr
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    # more ranks than GPUs under the product backend: every rank needs its own device -> non-zero, no JSON line
+    p = _bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-train-leg"], timeout=280)
+    if torch.cuda.device_count() < 2:
+        assert p.returncode != 0
+        assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]

@@ -123,6 +123,105 @@ def test_flat_adam_matches_torch_adam(set_to_none):
     assert all(pm.data_ptr() >= opt.flat.data_ptr() for pm in mine)     # the parameters are views of the flat buffer
 
 
+def _adam_pair(shapes, seed=0):
+    from ahn3_dgcnn_pytorch_amd.optim import FlatAdam
+    g = torch.Generator().manual_seed(seed)
+    ref = [torch.nn.Parameter(torch.randn(s, generator=g)) for s in shapes]
+    mine = [torch.nn.Parameter(p.detach().clone().to(_dev())) for p in ref]
+    return g, ref, mine, torch.optim.Adam(ref, lr=1e-3, weight_decay=1e-4), FlatAdam(mine, lr=1e-3, weight_decay=1e-4)
+
+
+def _feed(g, ref, mine, skip=()):
+    for i, (pr, pm) in enumerate(zip(ref, mine)):
+        if i in skip:
+            pr.grad = pm.grad = None
+            continue
+        gr = torch.randn(pr.shape, generator=g)
+        pr.grad, pm.grad = gr.clone(), gr.to(_dev())
+
+
+def test_flat_adam_is_an_optimizer_the_reference_schedulers_drive():
+    """train.py:121-124 wraps the optimizer in CosineAnnealingLR (default) / StepLR: the learning rate is read from
+    param_groups[0]['lr'] at every step."""
+    from torch.optim.lr_scheduler import CosineAnnealingLR, StepLR
+    for make in (lambda o: CosineAnnealingLR(o, 6, eta_min=1e-3), lambda o: StepLR(o, 2, 0.5)):
+        g, ref, mine, opt_r, opt = _adam_pair([(64, 8, 1, 1), (64,), (300, 7)])
+        assert isinstance(opt, torch.optim.Optimizer) and len(opt.param_groups) == 1
+        opt.param_groups[0]["lr"] = opt_r.param_groups[0]["lr"] = 0.05
+        sch_r, sch = make(opt_r), make(opt)
+        for _ in range(6):
+            _feed(g, ref, mine)
+            opt_r.step()
+            opt.step()
+            sch_r.step()
+            sch.step()
+            assert opt.param_groups[0]["lr"] == pytest.approx(opt_r.param_groups[0]["lr"])
+        for pr, pm in zip(ref, mine):
+            assert (pm.detach().cpu() - pr.detach()).abs().max().item() <= 2e-5
+
+
+def test_flat_adam_state_dict_interchanges_with_torch_adam():
+    """train.py:131 / :306-309: `optimizer_state_dict` of an existing .t7 checkpoint loads into FlatAdam and a
+    checkpoint FlatAdam wrote loads into torch.optim.Adam."""
+    import io
+    shapes = [(64, 8, 1, 1), (64,), (64,), (5, 256, 1)]
+    g, ref, mine, opt_r, opt = _adam_pair(shapes)
+    for _ in range(3):
+        _feed(g, ref, mine)
+        opt_r.step()
+        opt.step()
+    sd_r, sd = opt_r.state_dict(), opt.state_dict()
+    assert sorted(sd.keys()) == sorted(sd_r.keys()) and sorted(sd["state"].keys()) == sorted(sd_r["state"].keys())
+    assert set(sd_r["param_groups"][0].keys()) <= set(sd["param_groups"][0].keys())
+    for i in sd_r["state"]:
+        assert set(sd["state"][i].keys()) == set(sd_r["state"][i].keys())
+        assert float(sd["state"][i]["step"]) == float(sd_r["state"][i]["step"]) == 3.0
+        for key in ("exp_avg", "exp_avg_sq"):
+            assert (sd["state"][i][key].cpu() - sd_r["state"][i][key]).abs().max().item() <= 1e-6
+    # torch.save / torch.load round trip in both directions, then three more steps side by side
+    def through_file(obj):
+        buf = io.BytesIO()
+        torch.save(obj, buf)
+        buf.seek(0)
+        return torch.load(buf, weights_only=False)
+    g2, ref2, mine2, opt_r2, opt2 = _adam_pair(shapes)
+    with torch.no_grad():
+        for p_new, p_old in zip(ref2, mine):
+            p_new.copy_(p_old.cpu())
+        for p_new, p_old in zip(mine2, ref):
+            p_new.copy_(p_old.to(_dev()))
+    opt_r2.load_state_dict(through_file(sd))       # FlatAdam -> torch.optim.Adam
+    opt2.load_state_dict(through_file(sd_r))       # torch.optim.Adam -> FlatAdam
+    assert opt2.steps == 3
+    for _ in range(3):
+        _feed(g, ref, mine)
+        for a, b in zip(ref2, mine):
+            a.grad = b.grad.cpu()
+        for a, b in zip(mine2, ref):
+            a.grad = b.grad.to(_dev())
+        for o in (opt_r, opt, opt_r2, opt2):
+            o.step()
+    for pr, pm, pr2, pm2 in zip(ref, mine, ref2, mine2):
+        assert (pm.detach().cpu() - pr.detach()).abs().max().item() <= 2e-6
+        assert (pr2.detach() - pr.detach()).abs().max().item() <= 2e-6
+        assert (pm2.detach().cpu() - pr.detach()).abs().max().item() <= 2e-6
+
+
+def test_flat_adam_skips_parameters_without_gradient_and_detects_moved_storage():
+    g, ref, mine, opt_r, opt = _adam_pair([(32, 4), (16,), (8, 8), (5,)])
+    for it in range(4):
+        _feed(g, ref, mine, skip=(1,) if it % 2 else ())      # torch leaves a grad-less parameter and its step alone
+        opt_r.step()
+        opt.step()
+    for pr, pm in zip(ref, mine):
+        assert (pm.detach().cpu() - pr.detach()).abs().max().item() <= 2e-6
+    assert float(opt.state_dict()["state"][1]["step"]) == float(opt_r.state_dict()["state"][1]["step"]) == 2.0
+    mine[2].data = mine[2].data.clone()                        # what model.to() / .float() does to a parameter
+    _feed(g, ref, mine)
+    with pytest.raises(RuntimeError, match="flat buffer"):
+        opt.step()
+
+
 def test_points_to_float_is_exact():
     from ahn3_dgcnn_pytorch_amd import ops
     g = torch.Generator().manual_seed(1)
