@@ -149,6 +149,29 @@ def _rel_l2(a, b):
     return float((a - b).norm()) / max(1e-30, float(b.norm()))
 
 
+def near_tie_count(x, idx, stages, train, gap=2e-6):
+    """number of (point, channel) maxima over k whose two best activations are closer than `gap` (oracle, fp32): there
+    the winner -- the ONE edge that receives dL/dy -- depends on rounding, also inside the reference"""
+    import copy
+    stages = copy.deepcopy(stages)
+    with torch.no_grad():
+        e = torch_ref.edge_features(x, k=idx.shape[2], idx=torch.from_numpy(idx.astype(np.int64)))
+        for st in stages:
+            st.train(train)
+            e = st(e)
+        top2 = e.topk(2, dim=-1)[0]
+    return int(((top2[..., 0] - top2[..., 1]) < gap).sum())
+
+
+def full_size_grad_tol(x, idx, stages, train):
+    """relative-L2 bound for gradients at sizes where near-ties cannot be excluded: one winner that differs moves one
+    of the P * 64 unit contributions to another edge, i.e. about sqrt(2 / (P * 64)) in relative L2 (measured: B=8,
+    N=7000 -> 7.5e-4 per flip).  Allowed: 2e-4 of arithmetic noise plus a flip at every counted near-tie."""
+    B, _, N = x.shape
+    n = near_tie_count(x, idx, stages, train)
+    return 2e-4 + (2.0 * n / (B * N * 64)) ** 0.5, n
+
+
 def test_two_stage_block_at_benchmark_size(device):
     """conv3+conv4-shaped block (128 -> 64 -> 64: blocks 1 and 2 of the model, the largest share of its time) at
     B=8, N=7000, k=30, C=64, train mode: the split-fp16 forward and the per-edge backward at full size.  Same gates
@@ -163,6 +186,8 @@ def test_two_stage_block_at_benchmark_size(device):
     y0, gx0, st0 = run_oracle(x, idx, copy.deepcopy(base), True, R)
     y1, gx1, st1 = run_hip(x, idx, copy.deepcopy(base), True, R, device)
     np.testing.assert_allclose(y1.numpy(), y0.numpy(), rtol=0, atol=ATOL_FWD)
+    tol, n_near = full_size_grad_tol(x, idx, base, True)
+    assert tol <= 3e-3, "input has %d near-ties" % n_near
     for si in range(2):
         for a, b, what in ((st1[si][0].weight.grad.cpu(), st0[si][0].weight.grad, "conv weight"),
                            (st1[si][1].weight.grad.cpu(), st0[si][1].weight.grad, "bn weight"),
@@ -170,7 +195,7 @@ def test_two_stage_block_at_benchmark_size(device):
             assert _rel_l2(a, b) <= 1e-3, "stage %d %s: %.3g" % (si, what, _rel_l2(a, b))
         np.testing.assert_allclose(st1[si][1].running_mean.cpu().numpy(), st0[si][1].running_mean.numpy(), rtol=1e-5, atol=1e-6)
         np.testing.assert_allclose(st1[si][1].running_var.cpu().numpy(), st0[si][1].running_var.numpy(), rtol=1e-5, atol=1e-6)
-    assert _rel_l2(gx1, gx0) <= 1e-3
+    assert _rel_l2(gx1, gx0) <= tol, "grad x: %.3g > %.3g (%d near-ties)" % (_rel_l2(gx1, gx0), tol, n_near)
     # eval mode at the same size (running statistics; forward only needs the table kernels + the MFMA pass)
     y0e, _, _ = run_oracle(x, idx, copy.deepcopy(base), False, R)
     y1e, _, _ = run_hip(x, idx, copy.deepcopy(base), False, R, device)
@@ -190,7 +215,9 @@ def test_block_at_stress_size(n_stage, device):
     y0, gx0, st0 = run_oracle(x, idx, copy.deepcopy(base), True, R)
     y1, gx1, st1 = run_hip(x, idx, copy.deepcopy(base), True, R, device)
     np.testing.assert_allclose(y1.numpy(), y0.numpy(), rtol=0, atol=ATOL_FWD)
-    assert _rel_l2(gx1, gx0) <= 1e-3
+    tol, n_near = full_size_grad_tol(x, idx, base, True)
+    assert tol <= 3e-3, "input has %d near-ties" % n_near
+    assert _rel_l2(gx1, gx0) <= tol, "grad x: %.3g > %.3g (%d near-ties)" % (_rel_l2(gx1, gx0), tol, n_near)
     for si in range(n_stage):
         assert _rel_l2(st1[si][0].weight.grad.cpu(), st0[si][0].weight.grad) <= 1e-3
 
