@@ -130,10 +130,17 @@ def test_readme_config_logits(device):
 @pytest.mark.timeout(900)
 def test_full_model_eval_at_benchmark_size(device):
     """BASELINE.json configs[2]: full DGCNN eval forward at B=8, N=7000, k=30 on block-like coordinates (x, y in
-    [0, 30), z, AGL in [0, 20)).  Gate 3 of SURVEY.md 8c at full size: with the CPU restatement's own neighbour
-    graphs injected, logits within 1e-4 everywhere; end to end (HIP kNN) the fraction of points over tolerance is
-    bounded and block 1 (search in the raw coordinates) agrees on >= 99 % of the rows."""
+    [0, 30), z, AGL in [0, 20)).  SURVEY.md 8c at full size:
+      gate 3  with the CPU restatement's own neighbour graphs injected, logits within 1e-4 everywhere;
+      gate 1  end to end, the graph of every block is bit-exact under the fixed arithmetic GIVEN the features the
+              block was fed (the graph is "dynamic": a function of computed features);
+      gate 2  every end-to-end difference to the reference is explained by the graphs: the CPU restatement run on
+              the HIP path's graphs reproduces the HIP logits within 1e-4 everywhere.  (A per-point fraction against
+              the reference's own graphs is not a usable gate: one changed neighbour list that moves a winner of the
+              global max-pool at model.py:175 shifts every point of its batch element -- measured here: 50 % of the
+              points, i.e. 4 of the 8 batch elements, with block-1 lists equal on > 99 % of the rows.)"""
     from ahn3_dgcnn_pytorch_amd import DGCNN
+    from oracle import knn_exact as ke
     from oracle import torch_ref
     B, N, k = 8, 7000, 30
     gen = torch.Generator().manual_seed(8)
@@ -147,15 +154,22 @@ def test_full_model_eval_at_benchmark_size(device):
     m = DGCNN(5, 4, k, dropout=0.5, emb_dims=1024, cuda=True)
     fill_module(m)
     m.eval()
+    xd = x.to(device)
     with torch.no_grad():
-        got = m(x.to(device), idx=[u.to(torch.int32).to(device) for u in used_ref])
-        own, used = m(x.to(device), return_idx=True)
+        got = m(xd, idx=[u.to(torch.int32).to(device) for u in used_ref])
+        own, used = m(xd, return_idx=True)
+        feats = [xd] + [m(xd, depth=d, idx=used) for d in (1, 2)]      # what each block's search was fed
     err = (got.cpu() - want).abs()
     assert float(err.max()) <= 1e-4, "max |logit - reference| = %.3g" % float(err.max())
+    for bi in range(3):
+        np.testing.assert_array_equal(used[bi].cpu().numpy(), ke.knn_exact(feats[bi].cpu().contiguous().numpy(), k),
+                                      err_msg="block %d graph" % (bi + 1))
     rows_equal = (used[0].cpu().numpy() == used_ref[0].numpy()).all(-1).mean()
     assert rows_equal >= 0.99, rows_equal
-    frac = float(((own.cpu() - want).abs().amax(dim=1) > 1e-4).float().mean())
-    assert frac <= 0.02, "fraction of points whose logits differ by > 1e-4 end to end: %.4f" % frac
+    with torch.no_grad():
+        explained = ref(x, idx=[u.cpu().long() for u in used])
+    err2 = (own.cpu() - explained).abs()
+    assert float(err2.max()) <= 1e-4, "max |HIP logit - CPU restatement on the HIP graphs| = %.3g" % float(err2.max())
 
 
 def test_predict_style_input_and_ropout_alias(device):
