@@ -46,7 +46,8 @@ SIGNATURES = {
     "dgcnn_knn_workspace_bytes": (_c_sz, [_c_int, _c_int, _c_int, _c_int]),
     "dgcnn_knn": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_sz, _c_vp]),
     "dgcnn_graph_feature_fwd": (_c_int, [_c_vp, _c_vp, _c_int, _c_int, _c_int, _c_int, _c_vp, _c_vp]),
-    "dgcnn_graph_feature_bwd": (_c_int, [_c_vp, _c_vp, _c_int, _c_int, _c_int, _c_int, _c_vp, _c_vp]),
+    "dgcnn_graph_feature_bwd_workspace_bytes": (_c_sz, [_c_int, _c_int, _c_int, _c_int]),
+    "dgcnn_graph_feature_bwd": (_c_int, [_c_vp, _c_vp, _c_int, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_sz, _c_vp]),
     "dgcnn_edgeconv_saved_bytes": (_c_sz, [_c_desc_p]),
     "dgcnn_edgeconv_fwd_workspace_bytes": (_c_sz, [_c_desc_p]),
     "dgcnn_edgeconv_bwd_workspace_bytes": (_c_sz, [_c_desc_p]),

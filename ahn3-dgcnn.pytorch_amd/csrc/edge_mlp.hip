@@ -23,6 +23,7 @@
 #include <stdlib.h>
 
 #include "edge_kernels.h"
+#include "fold.h"
 #include "prof.h"
 
 namespace dgcnn {
@@ -130,10 +131,9 @@ __global__ __launch_bounds__(256) void edge_mlp_fwd_kernel(const float *__restri
                                                            const float *__restrict__ w2,
                                                            const float *__restrict__ gamma2, float slope,
                                                            float *__restrict__ usel2, uint8_t *__restrict__ hit2,
-                                                           double *__restrict__ partial)
+                                                           int fin_on, FoldSet fs, BnBatchStats fin)
 {
     __shared__ __attribute__((aligned(16))) float tiles[MLP_WAVES][32][TSTR];
-    __shared__ double red[MLP_WAVES][2][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, i32 = lane & 31;
     float(*tileA)[TSTR] = tiles[wave];
 
@@ -234,25 +234,13 @@ __global__ __launch_bounds__(256) void edge_mlp_fwd_kernel(const float *__restri
             }
         }
     }
-    // BN2 partial sums: lane (n, h) holds channel nt * 32 + n; fold the halves, then the waves
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const double s = sum[nt] + shfl_xor_d(sum[nt], 32);
-        const double ss = sq[nt] + shfl_xor_d(sq[nt], 32);
-        if (h == 0) {
-            red[wave][0][nt * 32 + i32] = s;
-            red[wave][1][nt * 32 + i32] = ss;
-        }
-    }
-    __syncthreads();
-    if (wave == 0) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            double s = red[0][i][lane];
-#pragma unroll
-            for (int w = 1; w < MLP_WAVES; ++w) s += red[w][i][lane];
-            partial[((size_t)blockIdx.x * 2 + i) * 64 + lane] = s;
-        }
+    // BN2 batch statistics (training): lane (n, h) holds channel nt * 32 + n; fold the halves -- lane l then carries
+    // channel l (nt = h) -- and let the pass finish the sums itself (fold.h)
+    if (fin_on) {
+        const double t0 = sum[0] + shfl_xor_d(sum[0], 32), t1 = sum[1] + shfl_xor_d(sum[1], 32);
+        const double q0 = sq[0] + shfl_xor_d(sq[0], 32), q1 = sq[1] + shfl_xor_d(sq[1], 32);
+        const double v[2] = {h ? t1 : t0, h ? q1 : q0};
+        fold_and_finalize<2, MLP_WAVES>(v, fs, fin);
     }
 }
 
@@ -262,7 +250,7 @@ __global__ __launch_bounds__(512) void edge_mlp_bwd_kernel(
     const float *__restrict__ stats1, const float *__restrict__ stats2, const float *__restrict__ cc2,
     const float *__restrict__ w2, float slope, int training, const float *__restrict__ gy,
     const float *__restrict__ y, const uint8_t *__restrict__ hit2, float *__restrict__ dv1,
-    float *__restrict__ dvsum, float *__restrict__ partial_dw2, double *__restrict__ partial_bn1)
+    float *__restrict__ dvsum, float *__restrict__ partial_dw2, FoldSet fs, BnBackwardSums fin1)
 {
     // W2 [co][ci] once, rows padded to 65 floats, serves as the B operand of both products that contract over a
     // channel index without bank conflicts:
@@ -431,47 +419,36 @@ __global__ __launch_bounds__(512) void edge_mlp_bwd_kernel(
         partial_dw2[(size_t)blockIdx.x * 4096 + e] = t;
     }
     __syncthreads();
-    double *red = reinterpret_cast<double *>(scr);  // [wave][2][64]
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const double s = sb[nt] + shfl_xor_d(sb[nt], 32);
-        const double g = sg[nt] + shfl_xor_d(sg[nt], 32);
-        if (h == 0) {
-            red[(wave * 2 + 0) * 64 + nt * 32 + i32] = s;
-            red[(wave * 2 + 1) * 64 + nt * 32 + i32] = g;
-        }
-    }
-    __syncthreads();
-    if (wave == 0) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            double s = red[(0 * 2 + i) * 64 + lane];
-#pragma unroll
-            for (int w = 1; w < MLP_BWD_WAVES; ++w) s += red[(w * 2 + i) * 64 + lane];
-            partial_bn1[((size_t)blockIdx.x * 2 + i) * 64 + lane] = s;
-        }
+    // BN1 backward sums: fold the lane halves (lane l then carries channel l), finish them in this launch (fold.h; the
+    // tile area is free and serves as its scratch)
+    {
+        const double t0 = sb[0] + shfl_xor_d(sb[0], 32), t1 = sb[1] + shfl_xor_d(sb[1], 32);
+        const double g0 = sg[0] + shfl_xor_d(sg[0], 32), g1 = sg[1] + shfl_xor_d(sg[1], 32);
+        const double v[2] = {h ? t1 : t0, h ? g1 : g0};
+        double(*red)[2][64] = reinterpret_cast<double(*)[2][64]>(scr);
+        fold_and_finalize<2, MLP_BWD_WAVES>(v, fs, fin1, red, reinterpret_cast<int *>(scr + MLP_BWD_WAVES * 2 * 64 * 2));
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 void launch_edge_mlp_fwd(const float *TP, const float *TQ, const int32_t *idx, int N, int k, int P,
                          const float *stats1, const float *w2, const float *gamma2, float slope, float *usel2,
-                         uint8_t *hit2, double *partial, hipStream_t st)
+                         uint8_t *hit2, const FoldSet &fs, const BnBatchStats *fin, hipStream_t st)
 {
     prof_begin(PROF_EDGE_MLP_FWD, st);
     hipLaunchKernelGGL(edge_mlp_fwd_kernel, dim3(mlp_grid_fwd(P)), dim3(256), 0, st, TP, TQ, idx, N, k, P, stats1, w2,
-                       gamma2, slope, usel2, hit2, partial);
+                       gamma2, slope, usel2, hit2, fin ? 1 : 0, fs, fin ? *fin : BnBatchStats{});
     prof_end(PROF_EDGE_MLP_FWD, st);
 }
 
 void launch_edge_mlp_bwd(const float *TP, const float *TQ, const int32_t *idx, int N, int k, int P,
                          const float *stats1, const float *stats2, const float *cc2, const float *w2, float slope,
                          int training, const float *gy, const float *y, const uint8_t *hit2, float *dv1, float *dvsum,
-                         float *partial_dw2, double *partial_bn1, hipStream_t st)
+                         float *partial_dw2, const FoldSet &fs, const BnBackwardSums &fin1, hipStream_t st)
 {
     prof_begin(PROF_EDGE_MLP_BWD, st);
     hipLaunchKernelGGL(edge_mlp_bwd_kernel, dim3(mlp_grid(P)), dim3(64 * MLP_BWD_WAVES), 0, st, TP, TQ, idx, N, k, P, stats1, stats2,
-                       cc2, w2, slope, training, gy, y, hit2, dv1, dvsum, partial_dw2, partial_bn1);
+                       cc2, w2, slope, training, gy, y, hit2, dv1, dvsum, partial_dw2, fs, fin1);
     prof_end(PROF_EDGE_MLP_BWD, st);
 }
 

@@ -1,22 +1,23 @@
 // edgeconv.hip -- C ABI of the EdgeConv block: validates the descriptor, carves the caller's
 // workspace and enqueues the kernel sequence on the caller's stream (no allocation, no sync).
 //
-// Forward (reference model.py:147-150 / 154-157 / 161-163), P = B N points, E = P k edges:
-//   prep_wcat        Wcat = [Wa ; Wb - Wa] from conv weight W1 = [Wa | Wb]
-//   rowgemm          TP = x Wa^T, TQ = x (Wb - Wa)^T                           (MFMA, per point)
-//   1 stage : edge_reduce   u = TP[n] + TQ[i]: BN batch sums + selected extreme over k
-//             bn_finalize   mean / rstd / affine; running-statistics update
-//   2 stages: edge_reduce   BN1 batch sums only
-//             bn_finalize   BN1
-//             edge_mlp_fwd  a1 = LReLU(BN1(u)); u2 = W2 a1 (MFMA, per edge); BN2 sums + extreme
-//             bn_finalize   BN2
+// Forward (reference model.py:147-150 / 154-157 / 161-163), P = B N points, E = P k edges; training mode:
+//   rowgemm_fwd      TP = x Wa^T, TQ = x (Wb - Wa)^T  (MFMA, per point; Wcat = [Wa ; Wb - Wa] built in LDS from W1 = [Wa | Wb];
+//                    also zeroes the counters of the statistics passes below)
+//   edge_reduce      u = TP[n] + TQ[i]: BN1 batch sums -- finished in the same launch (fold.h): mean / rstd / affine,
+//                    running statistics -- and, for a one-stage block, the selected extreme over k
+//   2 stages: edge_mlp_fwd  a1 = LReLU(BN1(u)); u2 = W2 a1 (MFMA, per edge); BN2 sums (finished in the launch) + extreme
 //   edge_out         y = LReLU(BN(extreme))      == max over k of the activations, exactly
+// (eval mode: bn_eval_stats per stage instead of the batch statistics.)
 //
 // Backward (autograd nodes listed in SURVEY.md 2.1 "Bw"; formulas Appendix C.5):
-//   bwd_point        last BN: gbn_w, gbn_b and the two mean terms (per-point sums suffice)
-//   2 stages: edge_mlp_bwd  recompute a1, u2; du2; gW2 partials; dv1 = (W2^T du2) * LReLU'; BN1 sums
-//             sum_partials  gW2;   bn_bwd_finalize  BN1
-//   edge_bwd         du1 -> dD (sum over k) and dR (scatter-add to neighbours)
+//   rev_count, rev_slots, rev_place   reverse adjacency of the neighbour graph, lists sorted by edge id (the first
+//                    kernel zeroes the counters used below)
+//   bwd_point        last BN: gbn_w, gbn_b and the two mean terms, finished in the same launch
+//   2 stages: edge_mlp_bwd  recompute a1, u2; du2; gW2 partials; dv1 = (W2^T du2) * LReLU'; BN1 sums finished in the launch
+//             sum_partials  gW2
+//   edge_point_bwd   dD (sum over k), per-edge winner masks and G (one-stage)
+//   edge_rgather     dR (gather over the reverse lists: fixed order, no atomics)
 //   wgrad + finish   gW1 = [ (dR - dD)^T x | dD^T x ]                           (MFMA, per point)
 //   rowgemm          gx = dR Wa + dD (Wb - Wa)                                   (MFMA, per point)
 #include <stdlib.h>
@@ -61,27 +62,43 @@ static SavedLayout saved_layout(const dgcnn_edgeconv_desc *d, void *p)
     return s;
 }
 
+// counters that must be zero when the kernels using them start (zeroed by the first kernel of each call)
+enum { Z_FOLD_A = 0, Z_FOLD_B = FOLD_CTR_WORDS, Z_ALLOC = 2 * FOLD_CTR_WORDS, Z_WORDS = 2 * FOLD_CTR_WORDS + 16 };
+
+struct FoldBufs {
+    double *rec, *folded;
+};
+template <typename C>
+static FoldBufs take_fold(C &c)
+{
+    FoldBufs f;
+    f.rec = c.template take<double>((size_t)PART_MAX * 2 * 64);
+    f.folded = c.template take<double>((size_t)FOLD_GROUPS * 2 * 64);
+    return f;
+}
+
 struct FwdWs {
-    float *wcatT;
-    double *partial;
+    int *zero;  // [Z_WORDS]
+    FoldBufs f1, f2;
     size_t bytes;
 };
 static FwdWs fwd_ws(const dgcnn_edgeconv_desc *d, void *p)
 {
     Carver c(p);
     FwdWs w;
-    w.wcatT = c.take<float>((size_t)(d->C + 1) * 128);
-    w.partial = c.take<double>((size_t)(PART_MAX + PART_FOLD) * 2 * 64);
+    w.zero = c.take<int>(Z_WORDS);
+    w.f1 = take_fold(c);
+    w.f2 = d->n_stage == 2 ? take_fold(c) : FoldBufs{nullptr, nullptr};
     w.bytes = c.off;
     return w;
 }
 
 struct BwdWs {
-    float *cc1, *cc2, *dR, *dD, *wg_partial, *wg_sum, *dv1, *dvsum, *dw2_partial;
-    double *partial, *bn1_partial;
-    int *cnt, *indeg, *rowptr, *rev, *extra;  // reverse adjacency of the kNN graph (training mode)
-    void *hits;
-    float *G;
+    int *zero;  // [Z_WORDS]: fold counters, list allocation
+    FoldBufs fa, fb;
+    float *cc1, *cc2, *dR, *dD, *wg_partial, *dv1, *dvsum, *dw2_partial, *G;
+    int *cnt, *indeg, *rowptr, *rev, *hubs;  // reverse adjacency of the neighbour graph
+    void *masks;
     size_t bytes;
 };
 static BwdWs bwd_ws(const dgcnn_edgeconv_desc *d, void *p)
@@ -89,30 +106,29 @@ static BwdWs bwd_ws(const dgcnn_edgeconv_desc *d, void *p)
     Carver c(p);
     BwdWs w;
     const size_t P = (size_t)d->B * d->N;
-    w.partial = c.take<double>((size_t)(PART_MAX + PART_FOLD) * 2 * 64);
+    w.zero = c.take<int>(Z_WORDS);
+    w.fa = take_fold(c);
+    w.fb = d->n_stage == 2 ? take_fold(c) : FoldBufs{nullptr, nullptr};
     w.cc1 = c.take<float>(128);
     w.cc2 = c.take<float>(128);
     w.dR = c.take<float>(P * EC);
     w.dD = c.take<float>(P * EC);
     w.wg_partial = c.take<float>((size_t)wgrad_chunks((int)P) * 128 * d->C);
-    w.wg_sum = c.take<float>((size_t)128 * d->C);
     w.cnt = c.take<int>((size_t)d->B * rev_chunks(d->B, d->N, d->k) * d->N);
     w.indeg = c.take<int>(P);
-    w.rowptr = c.take<int>(P + 1);
+    w.rowptr = c.take<int>(P);
     w.rev = c.take<int>(P * d->k);
-    w.extra = c.take<int>(2 + 2 * (P * d->k / REV_SEG + 1));  // counter + (point, segment) pairs of long in-edge lists
-    w.hits = d->n_stage == 1 ? (void *)c.take<u64>(P * d->k * 4) : nullptr;  // 32 bytes per edge
+    w.hubs = c.take<int>(P * d->k / REV_SEG + 1);
+    w.masks = d->n_stage == 1 ? (void *)c.take<u64>(P * d->k) : nullptr;  // 8 bytes per edge
     w.G = d->n_stage == 1 ? c.take<float>(P * EC) : nullptr;
     if (d->n_stage == 2) {
         w.dv1 = c.take<float>(P * d->k * EC);
         w.dvsum = c.take<float>(P * EC);
         w.dw2_partial = c.take<float>((size_t)PART_MAX * EC * EC);
-        w.bn1_partial = c.take<double>((size_t)(PART_MAX + PART_FOLD) * 2 * 64);
     } else {
         w.dv1 = nullptr;
         w.dvsum = nullptr;
         w.dw2_partial = nullptr;
-        w.bn1_partial = nullptr;
     }
     w.bytes = c.off;
     return w;
@@ -170,26 +186,21 @@ extern "C" int dgcnn_edgeconv_fwd(const dgcnn_edgeconv_desc *d, const float *x, 
     const int P = d->B * d->N, N = d->N, C = d->C, k = d->k;
     const double E = (double)P * k;
 
-    launch_prep_wcat(d->w1, C, C, w.wcatT, s.wcat, st);
-    launch_rowgemm(x, C, nullptr, 0, w.wcatT, 128, s.TP, EC, s.TQ, P, st);
+    launch_rowgemm_fwd(x, C, d->w1, s.TP, s.TQ, s.wcat, w.zero, Z_WORDS, P, st);
+    const FoldSet fs1{w.f1.rec, w.f1.folded, w.zero + Z_FOLD_A}, fs2{w.f2.rec, w.f2.folded, w.zero + Z_FOLD_B};
+    const BnBatchStats fin1{d->bn1, E, d->eps, d->momentum, s.stats1}, fin2{d->bn2, E, d->eps, d->momentum, s.stats2};
+    if (!d->training) {
+        launch_bn_eval_stats(d->bn1, d->eps, s.stats1, st);
+        if (d->n_stage == 2) launch_bn_eval_stats(d->bn2, d->eps, s.stats2, st);
+    }
     if (d->n_stage == 1) {
-        if (!d->training) launch_bn_finalize(w.partial, 0, E, 0, d->bn1, d->eps, d->momentum, s.stats1, st);
-        launch_edge_reduce(s.TP, s.TQ, idx, N, k, P, d->bn1.weight, s.usel, s.usum, s.hitj, w.partial, st);
-        if (d->training)
-            launch_bn_finalize(w.partial, edge_grid(P), E, 1, d->bn1, d->eps, d->momentum, s.stats1, st);
+        launch_edge_reduce(s.TP, s.TQ, idx, N, k, P, d->bn1.weight, s.usel, s.usum, s.hitj, fs1, d->training ? &fin1 : nullptr,
+                           st);
         launch_edge_out(s.usel, s.stats1, d->slope, P, y, st);
     } else {
-        if (d->training) {
-            launch_edge_reduce(s.TP, s.TQ, idx, N, k, P, d->bn1.weight, nullptr, s.usum, nullptr, w.partial, st);
-            launch_bn_finalize(w.partial, edge_grid(P), E, 1, d->bn1, d->eps, d->momentum, s.stats1, st);
-        } else {
-            launch_bn_finalize(w.partial, 0, E, 0, d->bn1, d->eps, d->momentum, s.stats1, st);
-            launch_bn_finalize(w.partial, 0, E, 0, d->bn2, d->eps, d->momentum, s.stats2, st);
-        }
-        launch_edge_mlp_fwd(s.TP, s.TQ, idx, N, k, P, s.stats1, d->w2, d->bn2.weight, d->slope, s.usel, s.hitj, w.partial,
-                            st);
-        if (d->training)
-            launch_bn_finalize(w.partial, mlp_grid_fwd(P), E, 1, d->bn2, d->eps, d->momentum, s.stats2, st);
+        if (d->training) launch_edge_reduce(s.TP, s.TQ, idx, N, k, P, d->bn1.weight, nullptr, s.usum, nullptr, fs1, &fin1, st);
+        launch_edge_mlp_fwd(s.TP, s.TQ, idx, N, k, P, s.stats1, d->w2, d->bn2.weight, d->slope, s.usel, s.hitj, fs2,
+                            d->training ? &fin2 : nullptr, st);
         launch_edge_out(s.usel, s.stats2, d->slope, P, y, st);
     }
     DG_CHECK_LAUNCH("dgcnn_edgeconv_fwd");
@@ -212,34 +223,25 @@ extern "C" int dgcnn_edgeconv_bwd(const dgcnn_edgeconv_desc *d, const float *x, 
     const int P = d->B * d->N, N = d->N, C = d->C, k = d->k;
     const double E = (double)P * k;
 
-    if (!d->training && hipMemsetAsync(w.dR, 0, (size_t)P * EC * sizeof(float), st) != hipSuccess)
-        DG_FAIL("dgcnn_edgeconv_bwd: hipMemsetAsync failed");  // eval mode scatters into dR
     // (measured: building the lists on a side stream, concurrently with the BatchNorm-backward sums and the
     // per-point pass, costs more in cross-stream barriers than it hides: 0.776 ms against 0.725 ms per step)
-    if (d->training && launch_rev_build(idx, d->B, N, k, w.cnt, w.indeg, w.rowptr, w.rev, w.extra, st)) return 1;
+    if (launch_rev_build(idx, d->B, N, k, w.cnt, w.indeg, w.rowptr, w.rev, w.zero + Z_ALLOC, w.hubs, w.zero, Z_WORDS, st))
+        return 1;
+    const FoldSet fsa{w.fa.rec, w.fa.folded, w.zero + Z_FOLD_A}, fsb{w.fb.rec, w.fb.folded, w.zero + Z_FOLD_B};
     if (d->n_stage == 1) {
-        launch_bwd_point(gy, s.usel, s.stats1, d->slope, P, E, d->training, w.partial, g->gbn1_w, g->gbn1_b, w.cc1, st);
-        if (d->training) {
-            if (launch_edge_bwd_nogather(s.TP, s.TQ, d->B, N, k, s.stats1, w.cc1, d->slope, gy, y, s.hitj, s.usum, nullptr,
-                                         nullptr, w.rowptr, w.rev, w.extra, w.hits, w.G, w.dR, w.dD, st))
-                return 1;
-        } else {
-            launch_edge_bwd(s.TP, s.TQ, idx, N, k, P, s.stats1, w.cc1, d->slope, d->training, gy, y, nullptr, w.dR, w.dD,
-                            st);
-        }
+        launch_bwd_point(gy, s.usel, s.stats1, d->slope, P, E, d->training, fsa, g->gbn1_w, g->gbn1_b, w.cc1, st);
+        if (launch_edge_bwd(s.TP, s.TQ, d->B, N, k, s.stats1, w.cc1, d->slope, gy, y, s.hitj, s.usum, nullptr, nullptr,
+                            w.rowptr, w.indeg, w.rev, w.zero + Z_ALLOC, w.hubs, w.masks, w.G, w.dR, w.dD, st))
+            return 1;
     } else {
-        launch_bwd_point(gy, s.usel, s.stats2, d->slope, P, E, d->training, w.partial, g->gbn2_w, g->gbn2_b, w.cc2, st);
+        launch_bwd_point(gy, s.usel, s.stats2, d->slope, P, E, d->training, fsa, g->gbn2_w, g->gbn2_b, w.cc2, st);
+        const BnBackwardSums fin1{E, d->training, g->gbn1_w, g->gbn1_b, w.cc1};
         launch_edge_mlp_bwd(s.TP, s.TQ, idx, N, k, P, s.stats1, s.stats2, w.cc2, d->w2, d->slope, d->training, gy, y,
-                            s.hitj, w.dv1, w.dvsum, w.dw2_partial, w.bn1_partial, st);
+                            s.hitj, w.dv1, w.dvsum, w.dw2_partial, fsb, fin1, st);
         launch_sum_partials(w.dw2_partial, mlp_grid(P), EC * EC, g->gw2, st);
-        launch_bn_bwd_finalize(w.bn1_partial, mlp_grid(P), E, d->training, g->gbn1_w, g->gbn1_b, w.cc1, st);
-        if (d->training) {
-            if (launch_edge_bwd_nogather(s.TP, s.TQ, d->B, N, k, s.stats1, w.cc1, d->slope, gy, y, nullptr, s.usum, w.dv1,
-                                         w.dvsum, w.rowptr, w.rev, w.extra, nullptr, nullptr, w.dR, w.dD, st))
-                return 1;
-        } else {
-            launch_edge_bwd(s.TP, s.TQ, idx, N, k, P, s.stats1, w.cc1, d->slope, d->training, gy, y, w.dv1, w.dR, w.dD, st);
-        }
+        if (launch_edge_bwd(s.TP, s.TQ, d->B, N, k, s.stats1, w.cc1, d->slope, gy, y, nullptr, s.usum, w.dv1, w.dvsum,
+                            w.rowptr, w.indeg, w.rev, w.zero + Z_ALLOC, w.hubs, nullptr, nullptr, w.dR, w.dD, st))
+            return 1;
     }
     launch_wgrad(w.dR, EC, w.dD, EC, x, C, P, w.wg_partial, st);
     launch_finish_dw1(w.wg_partial, wgrad_chunks(P), C, g->gw1, st);
@@ -258,12 +260,44 @@ extern "C" int dgcnn_graph_feature_fwd(const float *x, const int32_t *idx, int B
     return 0;
 }
 
-extern "C" int dgcnn_graph_feature_bwd(const float *gout, const int32_t *idx, int B, int N, int C, int k, float *gx,
-                                       void *stream)
+struct GfWs {
+    int *zero, *cnt, *indeg, *rowptr, *rev, *hubs;
+    size_t bytes;
+};
+static GfWs gf_ws(int B, int N, int k, void *p)
 {
-    DG_REQUIRE(gout && idx && gx, "dgcnn_graph_feature_bwd: null pointer");
+    Carver c(p);
+    GfWs w;
+    const size_t P = (size_t)B * N;
+    w.zero = c.take<int>(Z_WORDS);
+    w.cnt = c.take<int>((size_t)B * rev_chunks(B, N, k) * N);
+    w.indeg = c.take<int>(P);
+    w.rowptr = c.take<int>(P);
+    w.rev = c.take<int>(P * k);
+    w.hubs = c.take<int>(P * k / REV_SEG + 1);
+    w.bytes = c.off;
+    return w;
+}
+
+extern "C" size_t dgcnn_graph_feature_bwd_workspace_bytes(int B, int N, int C, int k)
+{
+    (void)C;
+    return B > 0 && N > 0 && k > 0 ? gf_ws(B, N, k, nullptr).bytes : 0;
+}
+
+extern "C" int dgcnn_graph_feature_bwd(const float *gout, const int32_t *idx, int B, int N, int C, int k, float *gx,
+                                       void *workspace, size_t workspace_bytes, void *stream)
+{
+    DG_REQUIRE(gout && idx && gx && workspace, "dgcnn_graph_feature_bwd: null pointer");
     DG_REQUIRE(B > 0 && N > 0 && C > 0 && k > 0, "dgcnn_graph_feature_bwd: bad shape");
-    launch_graph_feature_bwd(gout, idx, B, N, C, k, gx, (hipStream_t)stream);
+    DG_REQUIRE(k <= 128, "dgcnn_graph_feature_bwd: k=%d > 128 unsupported", k);
+    DG_REQUIRE((size_t)B * N * k < ((size_t)1 << 31), "dgcnn_graph_feature_bwd: more than 2^31 edges");
+    const GfWs w = gf_ws(B, N, k, workspace);
+    DG_REQUIRE(workspace_bytes >= w.bytes, "dgcnn_graph_feature_bwd: workspace too small (%zu < %zu)", workspace_bytes,
+               w.bytes);
+    hipStream_t st = (hipStream_t)stream;
+    if (launch_rev_build(idx, B, N, k, w.cnt, w.indeg, w.rowptr, w.rev, w.zero + Z_ALLOC, w.hubs, w.zero, Z_WORDS, st)) return 1;
+    launch_graph_feature_bwd(gout, w.rowptr, w.indeg, w.rev, B, N, C, k, gx, st);
     DG_CHECK_LAUNCH("graph_feature_bwd_kernel");
     return 0;
 }

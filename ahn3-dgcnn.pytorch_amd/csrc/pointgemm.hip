@@ -11,21 +11,20 @@
 
 namespace dgcnn {
 
-__global__ void prep_wcat_kernel(const float *__restrict__ w1, int C, int Ke, float *__restrict__ wcatT,
-                                 float *__restrict__ wcat)
+// Forward mode of the two row kernels below (FROM_W1): W is not a ready [K][NO] matrix but the convolution weight
+// w1 [64][2C]; every workgroup builds Wcat^T [C][128] = [Wa ; Wb - Wa]^T in LDS itself (32 KB of L2-resident reads: one
+// launch less than a separate prep kernel), workgroup 0 also writes wcat [128][C] for the backward's dgrad and zeroes
+// the counters of the statistics passes that follow in the same call.
+__device__ __forceinline__ float wcat_at(const float *__restrict__ w1, int C, int o, int c)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= Ke * 128) return;
-    const int c = t / 128, o = t % 128;
-    float v = 0.0f;
-    if (c < C) {
-        if (o < EC)
-            v = w1[(size_t)o * 2 * C + c];
-        else
-            v = w1[(size_t)(o - EC) * 2 * C + C + c] - w1[(size_t)(o - EC) * 2 * C + c];
-        wcat[(size_t)o * C + c] = v;
-    }
-    wcatT[(size_t)c * 128 + o] = v;
+    return o < EC ? w1[(size_t)o * 2 * C + c] : w1[(size_t)(o - EC) * 2 * C + C + c] - w1[(size_t)(o - EC) * 2 * C + c];
+}
+__device__ __forceinline__ void fwd_side_jobs(const float *__restrict__ w1, int C, float *__restrict__ wcat,
+                                              int *__restrict__ zero_words, int nzero)
+{
+    if (blockIdx.x != 0) return;
+    for (int i = threadIdx.x; i < nzero; i += 256) zero_words[i] = 0;
+    for (int e = threadIdx.x; e < 128 * C; e += 256) wcat[e] = wcat_at(w1, C, e / C, e % C);
 }
 
 // One wave = one 32-row tile of points x all NO (<= 32 NT) output columns.
@@ -38,20 +37,25 @@ constexpr int RG_KH_MAX = 64;  // K0 + K1 <= 128
 
 constexpr int RG_LDS_FLOATS = 8192;  // W (K x NO <= 128 x 64 or 64 x 128 fp32 = 32 KB) staged once per workgroup
 
-template <int NT>
+template <int NT, bool FROM_W1>
 __global__ __launch_bounds__(256) void rowgemm_kernel(const float *__restrict__ A0, int K0,
                                                       const float *__restrict__ A1, int K1,
                                                       const float *__restrict__ W, int NO,
                                                       float *__restrict__ Y0, int NO0, float *__restrict__ Y1,
-                                                      int P)
+                                                      int P, float *__restrict__ wcat, int *__restrict__ zero_words,
+                                                      int nzero)
 {
     // the weights are read by every wave at every step: stage them in LDS (the kernel was bound by the
     // latency of those loads: 73 % of its wave cycles in s_waitcnt)
     __shared__ float wl[RG_LDS_FLOATS];
     const int K = K0 + K1, KH = (K + 1) >> 1;
     const bool staged = K * NO <= RG_LDS_FLOATS;
-    if (staged)
+    if (FROM_W1) {  // K = C <= 64, NO = 128: always staged
+        fwd_side_jobs(W, K, wcat, zero_words, nzero);
+        for (int e = threadIdx.x; e < K * 128; e += 256) wl[e] = wcat_at(W, K, e & 127, e >> 7);
+    } else if (staged) {
         for (int e = threadIdx.x; e < K * NO; e += 256) wl[e] = W[e];
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, i32 = lane & 31;
     const int p0 = (blockIdx.x * 4 + wave) * 32;
@@ -120,16 +124,36 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(const float *__restrict__ 
 // above guards every operand and ends up with one branch and one s_waitcnt per MFMA).
 //   K = 2 KH, NO = 32 NT, K * NO <= RG_LDS_FLOATS, NO0 a multiple of 32, and either K1 == 0 or K0 == KH, so that the
 //   KH values of a lane (k = h KH + s) are one contiguous run of one source row.
-template <int KH, int NT>
+template <int KH, int NT, bool FROM_W1>
 __global__ __launch_bounds__(256) void rowgemm_fast_kernel(const float *__restrict__ A0, int K0,
                                                            const float *__restrict__ A1, int K1,
                                                            const float *__restrict__ W, float *__restrict__ Y0, int NO0,
-                                                           float *__restrict__ Y1, int P)
+                                                           float *__restrict__ Y1, int P, float *__restrict__ wcat,
+                                                           int *__restrict__ zero_words, int nzero)
 {
     constexpr int K = 2 * KH, NO = 32 * NT;
     __shared__ float wl[K * NO];
-    for (int e = threadIdx.x; e < K * NO / 4; e += 256)
-        reinterpret_cast<float4 *>(wl)[e] = reinterpret_cast<const float4 *>(W)[e];
+    if (FROM_W1) {  // K = C = 64, NO = 128: wl[c][o] = Wcat[o][c]; lanes run over o (conflict-free LDS writes), each
+                    // reads 16 bytes of row o of w1
+        static_assert(!FROM_W1 || (K == 64 && NO == 128), "forward shape");
+        fwd_side_jobs(W, K, wcat, zero_words, nzero);
+        for (int e = threadIdx.x; e < 128 * (K / 4); e += 256) {
+            const int o = e & 127, c4 = (e >> 7) * 4;
+            const float *row = W + (size_t)(o & 63) * 2 * K;
+            float4 v = *reinterpret_cast<const float4 *>(row + c4);
+            if (o >= EC) {
+                const float4 b = *reinterpret_cast<const float4 *>(row + K + c4);
+                v = float4{b.x - v.x, b.y - v.y, b.z - v.z, b.w - v.w};
+            }
+            wl[(c4 + 0) * NO + o] = v.x;
+            wl[(c4 + 1) * NO + o] = v.y;
+            wl[(c4 + 2) * NO + o] = v.z;
+            wl[(c4 + 3) * NO + o] = v.w;
+        }
+    } else {
+        for (int e = threadIdx.x; e < K * NO / 4; e += 256)
+            reinterpret_cast<float4 *>(wl)[e] = reinterpret_cast<const float4 *>(W)[e];
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, i32 = lane & 31;
     const int p0 = (blockIdx.x * 4 + wave) * 32;
     const int row = p0 + i32 < P ? p0 + i32 : P - 1;  // clamped: loads are unconditional, stores guarded
@@ -323,9 +347,16 @@ __global__ __launch_bounds__(1024) void finish_dw1_kernel(const float *__restric
 }
 
 // ---------------------------------------------------------------------------------------------
-void launch_prep_wcat(const float *w1, int C, int Ke, float *wcatT, float *wcat, hipStream_t st)
+void launch_rowgemm_fwd(const float *x, int C, const float *w1, float *TP, float *TQ, float *wcat, int *zero_words,
+                        int nzero, int P, hipStream_t st)
 {
-    hipLaunchKernelGGL(prep_wcat_kernel, dim3(ceil_div(Ke * 128, 256)), dim3(256), 0, st, w1, C, Ke, wcatT, wcat);
+    const dim3 grid(ceil_div(ceil_div(P, 32), 4)), block(256);
+    if (C == 64)
+        hipLaunchKernelGGL((rowgemm_fast_kernel<32, 4, true>), grid, block, 0, st, x, C, nullptr, 0, w1, TP, EC, TQ, P, wcat,
+                           zero_words, nzero);
+    else
+        hipLaunchKernelGGL((rowgemm_kernel<4, true>), grid, block, 0, st, x, C, nullptr, 0, w1, 128, TP, EC, TQ, P, wcat,
+                           zero_words, nzero);
 }
 
 void launch_rowgemm(const float *A0, int K0, const float *A1, int K1, const float *W, int NO, float *Y0, int NO0,
@@ -337,20 +368,25 @@ void launch_rowgemm(const float *A0, int K0, const float *A1, int K1, const floa
     const bool runs_ok = (K1 == 0 || K0 == K / 2) && (K0 & 3) == 0 && (K1 & 3) == 0;
     if (runs_ok && NO0 % 32 == 0 && NO1 % 32 == 0 && (NO1 == 0 || Y1)) {
         if (K == 64 && NO == 128) {
-            hipLaunchKernelGGL((rowgemm_fast_kernel<32, 4>), grid, block, 0, st, A0, K0, A1, K1, W, Y0, NO0, Y1, P);
+            hipLaunchKernelGGL((rowgemm_fast_kernel<32, 4, false>), grid, block, 0, st, A0, K0, A1, K1, W, Y0, NO0, Y1, P,
+                               nullptr, nullptr, 0);
             return;
         }
         if (K == 128 && NO == 64) {
-            hipLaunchKernelGGL((rowgemm_fast_kernel<64, 2>), grid, block, 0, st, A0, K0, A1, K1, W, Y0, NO0, Y1, P);
+            hipLaunchKernelGGL((rowgemm_fast_kernel<64, 2, false>), grid, block, 0, st, A0, K0, A1, K1, W, Y0, NO0, Y1, P,
+                               nullptr, nullptr, 0);
             return;
         }
     }
     if (nt <= 1)
-        hipLaunchKernelGGL((rowgemm_kernel<1>), grid, block, 0, st, A0, K0, A1, K1, W, NO, Y0, NO0, Y1, P);
+        hipLaunchKernelGGL((rowgemm_kernel<1, false>), grid, block, 0, st, A0, K0, A1, K1, W, NO, Y0, NO0, Y1, P, nullptr,
+                           nullptr, 0);
     else if (nt == 2)
-        hipLaunchKernelGGL((rowgemm_kernel<2>), grid, block, 0, st, A0, K0, A1, K1, W, NO, Y0, NO0, Y1, P);
+        hipLaunchKernelGGL((rowgemm_kernel<2, false>), grid, block, 0, st, A0, K0, A1, K1, W, NO, Y0, NO0, Y1, P, nullptr,
+                           nullptr, 0);
     else
-        hipLaunchKernelGGL((rowgemm_kernel<4>), grid, block, 0, st, A0, K0, A1, K1, W, NO, Y0, NO0, Y1, P);
+        hipLaunchKernelGGL((rowgemm_kernel<4, false>), grid, block, 0, st, A0, K0, A1, K1, W, NO, Y0, NO0, Y1, P, nullptr,
+                           nullptr, 0);
 }
 
 // wgrad_kernel for M0 = M1 = 64, C = 64 (the 64-channel blocks): no operand guards, only the row clamp

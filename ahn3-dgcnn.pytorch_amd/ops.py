@@ -108,10 +108,12 @@ class _GraphFeature(torch.autograd.Function):
         (idx,) = ctx.saved_tensors
         B, N, C, k = ctx.shape
         gout = gout.contiguous()
-        gx = torch.zeros((B, N, C), dtype=torch.float32, device=gout.device)
+        gx = torch.empty((B, N, C), dtype=torch.float32, device=gout.device)
         lib = _lib.load()
-        _lib.check(lib.dgcnn_graph_feature_bwd(_lib.ptr(gout), _lib.ptr(idx), B, N, C, k, _lib.ptr(gx),
-                                               _lib.stream_ptr(gout.device)), "dgcnn_graph_feature_bwd")
+        ws_bytes = lib.dgcnn_graph_feature_bwd_workspace_bytes(B, N, C, k)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=gout.device)
+        _lib.check(lib.dgcnn_graph_feature_bwd(_lib.ptr(gout), _lib.ptr(idx), B, N, C, k, _lib.ptr(gx), _lib.ptr(ws),
+                                               ws_bytes, _lib.stream_ptr(gout.device)), "dgcnn_graph_feature_bwd")
         return gx, None
 
 

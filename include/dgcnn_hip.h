@@ -63,12 +63,15 @@ int dgcnn_knn(const float *x, int B, int N, int C, int k, int32_t *idx,
  *   out[b][n][j][C..2C) = x[b][n][:]
  * out is [B][N][k][2C] contiguous -- exactly the memory the reference returns through a
  * permuted [B][2C][N][k] view.  The EdgeConv kernels never materialise this tensor.
- * The backward adds into gx (caller zero-fills): centre term by a local sum over k,
- * neighbour term by a scatter-add (autograd's IndexBackward0 of model.py:74). */
+ * The backward OVERWRITES gx: centre term by a local sum over k, neighbour term (autograd's
+ * IndexBackward0 of model.py:74, a scatter-add with atomics there) as a gather over the reverse
+ * neighbour lists, which the call builds in `workspace` sorted by edge id: the additions happen in
+ * a fixed order and the result is bit-stable from run to run.  k <= 128. */
 int dgcnn_graph_feature_fwd(const float *x, const int32_t *idx, int B, int N, int C, int k,
                             float *out, void *stream);
+size_t dgcnn_graph_feature_bwd_workspace_bytes(int B, int N, int C, int k);
 int dgcnn_graph_feature_bwd(const float *gout, const int32_t *idx, int B, int N, int C, int k,
-                            float *gx, void *stream);
+                            float *gx, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- EdgeConv block ---------------------------------------------------------------------
  * One call = one EdgeConv block of DGCNN.forward, i.e. (model.py:147-150 / 154-157 / 161-163)
@@ -120,7 +123,11 @@ size_t dgcnn_edgeconv_bwd_workspace_bytes(const dgcnn_edgeconv_desc *d);
 int dgcnn_edgeconv_fwd(const dgcnn_edgeconv_desc *d, const float *x, const int32_t *idx, float *y,
                        void *saved, void *workspace, size_t workspace_bytes, void *stream);
 
-/* gy: dL/dy point-major [B][N][64].  Every gradient is OVERWRITTEN (not accumulated). */
+/* gy: dL/dy point-major [B][N][64].  Every gradient is OVERWRITTEN (not accumulated).  The backward is
+ * deterministic: the scatter-add of autograd's IndexBackward0 (model.py:74) runs as a gather over reverse
+ * neighbour lists sorted by edge id, every reduction has a fixed association, no floating-point atomics:
+ * two calls on the same inputs return the same bits (provided no row of idx repeats a neighbour -- a kNN
+ * graph never does).  N <= 40000. */
 int dgcnn_edgeconv_bwd(const dgcnn_edgeconv_desc *d, const float *x, const int32_t *idx,
                        const float *y, const float *gy, const void *saved,
                        const dgcnn_edgeconv_grads *g, void *workspace, size_t workspace_bytes,

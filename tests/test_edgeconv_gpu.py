@@ -259,6 +259,53 @@ def test_backward_with_hub_points_and_crowded_edges(N, k, n_stage, device):
         assert float((a - b).abs().max()) <= tol, what
 
 
+def _grads_twice(x, idx, base, train, R, device):
+    import copy
+    outs = []
+    for _ in range(2):
+        y, gx, st = run_hip(x, idx, copy.deepcopy(base), train, R, device)
+        outs.append([y, gx] + [t.grad.cpu() for s_ in st for t in (s_[0].weight, s_[1].weight, s_[1].bias)] +
+                    [b.cpu() for s_ in st for b in (s_[1].running_mean, s_[1].running_var)])
+    return outs
+
+
+@pytest.mark.parametrize("train", [True, False])
+@pytest.mark.parametrize("n_stage", [1, 2])
+def test_backward_is_bit_stable(n_stage, train, device):
+    """the scatter-add of autograd's IndexBackward0 runs as a gather over reverse neighbour lists
+    sorted by edge id, every reduction has a fixed association and there is no floating-point atomic: two runs on the
+    same inputs return the same bits (the determinism test doubles as a race detector).  Benchmark-size kNN graph in
+    feature space (hubs with in-degree > 1000) and the artificial hub graph."""
+    B, C, N, k = 8, 64, 7000, 30
+    x = torch.randn(B, C, N, generator=torch.Generator().manual_seed(77))
+    idx = ke.knn_exact(x.numpy(), k)
+    indeg = np.bincount(idx[0].reshape(-1), minlength=N)
+    assert indeg.max() > 64           # the input has hubs: the workgroup-per-hub path runs
+    base = make_stages(2 * C, n_stage)
+    a, b = _grads_twice(x, idx, base, train, cotangent((B, 64, N), tag="stable"), device)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    Bh, Ch, Nh, kh = 2, 16, 400, 16
+    xh = torch.randn(Bh, Ch, Nh, generator=torch.Generator().manual_seed(78))
+    a, b = _grads_twice(xh, hub_graph(Bh, Nh, kh, 3), make_stages(2 * Ch, n_stage), train,
+                        cotangent((Bh, 64, Nh), tag="stable"), device)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+
+
+def test_get_graph_feature_backward_is_bit_stable(device):
+    from ahn3_dgcnn_pytorch_amd import get_graph_feature
+    x = torch.randn(2, 64, 3000, generator=torch.Generator().manual_seed(5))
+    idx = torch.from_numpy(ke.knn_exact(x.numpy(), 20).astype(np.int64))
+    R = cotangent((2, 128, 3000, 20), tag="ggf").to(device)
+    grads = []
+    for _ in range(2):
+        xd = x.to(device).requires_grad_(True)
+        (get_graph_feature(xd, k=20, idx=idx) * R).sum().backward()
+        grads.append(xd.grad.clone())
+    assert torch.equal(grads[0], grads[1])
+
+
 def test_single_stage_block_k_above_64(device):
     compare(1, 8, 200, 70, 1, True, device)
 
