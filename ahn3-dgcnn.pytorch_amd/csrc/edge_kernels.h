@@ -40,18 +40,21 @@ void launch_edge_out(const float *usel, const float *stats, float slope, int P, 
 void launch_bwd_point(const float *gy, const float *usel, const float *stats, float slope, int P, double count,
                       int training, const FoldSet &fs, float *gbn_w, float *gbn_b, float *cc, hipStream_t st);
 // Reverse adjacency of the neighbour graph (depends on idx only), every list sorted by edge id.  Scratch: cnt
-// [B * rev_chunks][N]; results: rowptr [P] (list start), indeg [P], rev [E], alloc [2] (alloc[1] = number of hubs),
-// hubs [<= E / REV_SEG].  The first kernel also zeroes zero_words[0 .. nzero) (which must contain alloc).
+// [B * rev_chunks][N]; results: rowptr [P] (list start), indeg [P], segbase [P], pcnt [P] (zeroed), rev [E], alloc [2]
+// (alloc[1] = number of extra (point, segment) pairs), extra [2 (E / REV_SEG + 1)] ints.  The first kernel also zeroes
+// zero_words[0 .. nzero) (which must contain alloc).
 int rev_chunks(int B, int N, int k);
-int launch_rev_build(const int32_t *idx, int B, int N, int k, int *cnt, int *indeg, int *rowptr, int32_t *rev,
-                     int *alloc, int *hubs, int *zero_words, int nzero, hipStream_t st);
+int launch_rev_build(const int32_t *idx, int B, int N, int k, int *cnt, int *indeg, int *rowptr, int *segbase, int *pcnt,
+                     int32_t *rev, int *alloc, int *extra, int *zero_words, int nzero, hipStream_t st);
 // stage-1 backward as a gather over the reverse lists (see edge_stream.hip): dR and dD are overwritten.
-// dv == NULL: sparse dv from (gy, y, hitj) -- masks [E] x 8 bytes and G [P][64] are scratch; else dense dv [E][64] with
-// dvsum [P][64] = its sums over k.  cc = 0 (eval mode) drops the BatchNorm mean terms.
+// dv == NULL: sparse dv from (gy, y, hitj) -- hits [E] x 32 bytes and G [P][64] are scratch; else dense dv [E][64] with
+// dvsum [P][64] = its sums over k.  part0 [P][128], partx [E / REV_SEG + 1][128] floats: segment partials of long lists.
+// cc = 0 (eval mode) drops the BatchNorm mean terms.
 int launch_edge_bwd(const float *TP, const float *TQ, int B, int N, int k, const float *stats, const float *cc, float slope,
                     const float *gy, const float *y, const uint8_t *hitj, const float *usum, const float *dv,
-                    const float *dvsum, const int *rowptr, const int *indeg, const int32_t *rev, const int *alloc,
-                    const int *hubs, void *masks, float *G, float *dR, float *dD, hipStream_t st);
+                    const float *dvsum, const int *rowptr, const int *indeg, const int *segbase, int *pcnt,
+                    const int32_t *rev, const int *alloc, const int *extra, void *hits, float *G, float *part0,
+                    float *partx, float *dR, float *dD, hipStream_t st);
 void launch_graph_feature_fwd(const float *x, const int32_t *idx, int B, int N, int C, int k, float *out,
                               hipStream_t st);
 void launch_graph_feature_bwd(const float *gout, const int *rowptr, const int *indeg, const int32_t *rev, int B, int N,

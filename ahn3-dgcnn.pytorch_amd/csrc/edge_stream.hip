@@ -201,7 +201,8 @@ __global__ __launch_bounds__(256) void bwd_point_kernel(const float *__restrict_
 //   dD[i] = sum_j sc dv[i][j] + k A[i] - alpha (usum[i] - k TQ[i])          (Repeat/Sub/CatBackward0; usum from the forward)
 // The scatter form of dR costs one 256-byte wave-atomic per edge (global float atomics: ~1.3 TB/s of added bytes on
 // MI355X: 0.4 ms for 1.68 M edges) and sums in arrival order.  The gather needs one coalesced 256-byte row load per
-// in-edge, no atomic, and -- the lists being SORTED by edge id -- adds in a fixed order: the backward is bit-stable.
+// in-edge, no float atomic on global memory, and -- the lists being SORTED by edge id -- adds in a fixed order: the
+// backward is bit-stable from run to run.
 //
 // Reverse lists, deterministic by construction.  The sources of a batch element are cut into `chunks` contiguous row
 // ranges; ONE WAVE owns a range and walks its rows in order, lane j holding neighbour j of the row.  The neighbours of
@@ -210,48 +211,88 @@ __global__ __launch_bounds__(256) void bwd_point_kernel(const float *__restrict_
 //   rev_count : cnt[b][chunk][m]  = number of edges from the chunk's rows into m               (ds_add, in LDS)
 //   rev_slots : indeg[m] = sum over chunks; list space for m is allocated (one global atomic per 256 points: WHERE a
 //               list lies is arbitrary, its contents are not); cnt[b][chunk][m] <- first slot of the chunk in m's list;
-//               points with more than REV_SEG in-edges are listed as hubs
+//               the (point, segment) pairs beyond the first REV_SEG entries of long lists are listed as extra work
 //   rev_place : rev[table[m]++] = edge id, rows in order (ds_add_rtn)  ->  every list ascends in edge id.
 // (Rows with REPEATED neighbours -- no kNN graph has them -- are still handled correctly; only the order of the repeated
 // pair inside the list is then left to the LDS unit.)
 constexpr int REV_MAX_N = 40000;  // N ints of LDS per wave (160 KB per CU)
-constexpr int REV_ROWS = 4;       // rows in flight per wave
+constexpr int REV_ROWS = 8;       // rows per step; two steps are in flight (the next step's index rows are loaded
+                                  // while this step's go through the LDS: two waves per CU, nothing else hides a load)
 
+// index rows r .. r + REV_ROWS - 1 of one batch element, lane j = neighbour j (K2: also neighbours 64 .. k - 1); rows
+// past r1 and lanes past k read a clamped address and come back negative (no branch around a load: the waits stay counted)
+template <bool K2>
+struct RevRows {
+    int n0[REV_ROWS], n1[K2 ? REV_ROWS : 1];
+};
+template <bool K2>
+__device__ __forceinline__ void rev_load_rows(const int32_t *__restrict__ ib, int k, int r, int r1, int lane, RevRows<K2> &v)
+{
+    const int l0 = lane < k ? lane : k - 1, l1 = 64 + lane < k ? 64 + lane : k - 1;
+#pragma unroll
+    for (int u = 0; u < REV_ROWS; ++u) {
+        const int rr = r + u < r1 ? r + u : r1 - 1;
+        // (the sign bit marks an invalid entry; or-ed in, so that the load is needed on every path and the compiler
+        // cannot sink it under a branch with a full wait behind it)
+        v.n0[u] = ib[(size_t)rr * k + l0] | (r + u < r1 && lane < k ? 0 : (int)0x80000000);
+        if (K2) v.n1[u] = ib[(size_t)rr * k + l1] | (r + u < r1 && 64 + lane < k ? 0 : (int)0x80000000);
+    }
+}
+
+template <bool K2>
 __global__ __launch_bounds__(64) void rev_count_kernel(const int32_t *__restrict__ idx, int N, int k, int chunks,
                                                        int rows_per, int *__restrict__ cnt,
                                                        int *__restrict__ zero_words, int nzero)
 {
     extern __shared__ int table[];
     const int lane = threadIdx.x;
-    const int b = blockIdx.x / chunks, chunk = blockIdx.x - b * chunks;
+    // workgroups are dealt round-robin over the 8 XCDs: batch element = blockIdx % B keeps all writers of a batch
+    // element's lists (scattered 4-byte stores into one region of `rev`) behind ONE L2, where they merge into whole lines
+    const int B_ = (int)gridDim.x / chunks, b = (int)blockIdx.x % B_, chunk = (int)blockIdx.x / B_;
+    const int row = b * chunks + chunk;  // this chunk's row of cnt
     // the counters of the kernels behind this one in the same call (fold.h tickets, list allocation) start at zero
     if (blockIdx.x == 0)
         for (int i = lane; i < nzero; i += 64) zero_words[i] = 0;
-    for (int m = lane; m < N; m += 64) table[m] = 0;
     const int r0 = chunk * rows_per, r1 = r0 + rows_per < N ? r0 + rows_per : N;
     const int32_t *ib = idx + (size_t)b * N * k;
-    for (int r = r0; r < r1; r += REV_ROWS) {
-        int n0[REV_ROWS], n1[REV_ROWS];
-#pragma unroll
-        for (int u = 0; u < REV_ROWS; ++u) {
-            const bool rv = r + u < r1;
-            n0[u] = rv && lane < k ? ib[(size_t)(r + u) * k + lane] : -1;
-            n1[u] = rv && 64 + lane < k ? ib[(size_t)(r + u) * k + 64 + lane] : -1;
-        }
-#pragma unroll
-        for (int u = 0; u < REV_ROWS; ++u) {
-            if (n0[u] >= 0) atomicAdd(&table[n0[u]], 1);
-            if (n1[u] >= 0) atomicAdd(&table[n1[u]], 1);
-        }
+    int *out = cnt + (size_t)row * N;
+    if (r0 >= r1) {  // (an empty chunk: only when N is not a multiple of the chunk size)
+        for (int m = lane; m < N; m += 64) out[m] = 0;
+        return;
     }
-    int *out = cnt + (size_t)blockIdx.x * N;
-    for (int m = lane; m < N; m += 64) out[m] = table[m];
+    RevRows<K2> ra, rb;
+    rev_load_rows<K2>(ib, k, r0, r1, lane, ra);
+    for (int m = lane; m < N; m += 64) table[m] = 0;
+    auto count = [&](const RevRows<K2> &v) {
+#pragma unroll
+        for (int u = 0; u < REV_ROWS; ++u) {
+            if (v.n0[u] >= 0) atomicAdd(&table[v.n0[u]], 1);
+            if (K2 && v.n1[u] >= 0) atomicAdd(&table[v.n1[u]], 1);
+        }
+    };
+    for (int r = r0; r < r1; r += 2 * REV_ROWS) {  // ping-pong: the other buffer's rows are in flight
+        rev_load_rows<K2>(ib, k, r + REV_ROWS, r1, lane, rb);
+        count(ra);
+        rev_load_rows<K2>(ib, k, r + 2 * REV_ROWS, r1, lane, ra);
+        count(rb);
+    }
+    for (int m0 = 0; m0 < N; m0 += 64 * 16) {  // 16 LDS reads in flight, then 16 stores
+        int v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = m0 + u * 64 + lane < N ? table[m0 + u * 64 + lane] : 0;
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (m0 + u * 64 + lane < N) out[m0 + u * 64 + lane] = v[u];
+    }
 }
 
-// alloc[0]: list space handed out so far, alloc[1]: number of hubs (both zeroed by rev_count_kernel)
+// alloc[0]: list space handed out so far, alloc[1]: number of extra (point, segment) pairs (both zeroed by
+// rev_count_kernel).  Per point: rowptr (list start), indeg, segbase (index of its first pair in `extra`), pcnt = 0 (the
+// arrival counter of its segments in edge_rgather_kernel).
 __global__ __launch_bounds__(256) void rev_slots_kernel(int N, int chunks, int P, int *__restrict__ cnt,
                                                         int *__restrict__ rowptr, int *__restrict__ indeg,
-                                                        int *__restrict__ alloc, int *__restrict__ hubs)
+                                                        int *__restrict__ segbase, int *__restrict__ pcnt,
+                                                        int *__restrict__ alloc, int2 *__restrict__ extra)
 {
     const int g = blockIdx.x * 256 + threadIdx.x;
     int deg = 0;
@@ -259,80 +300,115 @@ __global__ __launch_bounds__(256) void rev_slots_kernel(int N, int chunks, int P
     if (g < P) {
         const int b = g / N, m = g - b * N;
         cb = cnt + (size_t)b * chunks * N + m;
-        for (int c = 0; c < chunks; ++c) deg += cb[(size_t)c * N];
+        int c = 0;
+        for (; c + 16 <= chunks; c += 16) {  // 16 loads in flight (one workgroup per CU: nothing else hides them)
+            int v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = cb[(size_t)(c + u) * N];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) deg += v[u];
+        }
+        for (; c < chunks; ++c) deg += cb[(size_t)c * N];
     }
-    const int hub = deg > REV_SEG ? 1 : 0;
-    // exclusive scans of deg and hub over the workgroup; ONE atomic each on the global counters per workgroup
+    const int nseg = deg > REV_SEG ? (deg - 1) / REV_SEG : 0;  // segments beyond the first
+    // exclusive scans of deg and nseg over the workgroup; ONE atomic each on the global counters per workgroup
     __shared__ int wtot[4][2], wbase[4][2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int inc_d = deg, inc_h = hub;
+    int inc_d = deg, inc_s = nseg;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
-        const int td = __shfl_up(inc_d, o), th = __shfl_up(inc_h, o);
+        const int td = __shfl_up(inc_d, o), ts = __shfl_up(inc_s, o);
         if (lane >= o) {
             inc_d += td;
-            inc_h += th;
+            inc_s += ts;
         }
     }
     if (lane == 63) {
         wtot[wave][0] = inc_d;
-        wtot[wave][1] = inc_h;
+        wtot[wave][1] = inc_s;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        int td = 0, th = 0;
+        int td = 0, ts = 0;
         for (int w = 0; w < 4; ++w) {
             wbase[w][0] = td;
-            wbase[w][1] = th;
+            wbase[w][1] = ts;
             td += wtot[w][0];
-            th += wtot[w][1];
+            ts += wtot[w][1];
         }
         const int bd = td ? atomicAdd(&alloc[0], td) : 0;
-        const int bh = th ? atomicAdd(&alloc[1], th) : 0;
+        const int bs = ts ? atomicAdd(&alloc[1], ts) : 0;
         for (int w = 0; w < 4; ++w) {
             wbase[w][0] += bd;
-            wbase[w][1] += bh;
+            wbase[w][1] += bs;
         }
     }
     __syncthreads();
     if (g < P) {
         int slot = wbase[wave][0] + inc_d - deg;
+        const int sb = wbase[wave][1] + inc_s - nseg;
         rowptr[g] = slot;
         indeg[g] = deg;
-        for (int c = 0; c < chunks; ++c) {
+        segbase[g] = sb;
+        pcnt[g] = 0;
+        int c = 0;
+        for (; c + 16 <= chunks; c += 16) {
+            int v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = cb[(size_t)(c + u) * N];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                cb[(size_t)(c + u) * N] = slot;
+                slot += v[u];
+            }
+        }
+        for (; c < chunks; ++c) {
             const int n = cb[(size_t)c * N];
             cb[(size_t)c * N] = slot;
             slot += n;
         }
-        if (hub) hubs[wbase[wave][1] + inc_h - 1] = g;
+        for (int sg = 0; sg < nseg; ++sg) extra[sb + sg] = int2{g, sg + 1};
     }
 }
 
+template <bool K2>
 __global__ __launch_bounds__(64) void rev_place_kernel(const int32_t *__restrict__ idx, int N, int k, int chunks,
                                                        int rows_per, const int *__restrict__ cnt,
                                                        int32_t *__restrict__ rev)
 {
     extern __shared__ int table[];
     const int lane = threadIdx.x;
-    const int b = blockIdx.x / chunks, chunk = blockIdx.x - b * chunks;
-    const int *first = cnt + (size_t)blockIdx.x * N;
-    for (int m = lane; m < N; m += 64) table[m] = first[m];
+    // workgroups are dealt round-robin over the 8 XCDs: batch element = blockIdx % B keeps all writers of a batch
+    // element's lists (scattered 4-byte stores into one region of `rev`) behind ONE L2, where they merge into whole lines
+    const int B_ = (int)gridDim.x / chunks, b = (int)blockIdx.x % B_, chunk = (int)blockIdx.x / B_;
+    const int row = b * chunks + chunk;  // this chunk's row of cnt
+    const int *first = cnt + (size_t)row * N;
     const int r0 = chunk * rows_per, r1 = r0 + rows_per < N ? r0 + rows_per : N;
+    if (r0 >= r1) return;
     const int32_t *ib = idx + (size_t)b * N * k;
-    for (int r = r0; r < r1; r += REV_ROWS) {
-        int n0[REV_ROWS], n1[REV_ROWS];
+    RevRows<K2> ra, rb;
+    rev_load_rows<K2>(ib, k, r0, r1, lane, ra);
+    for (int m0 = 0; m0 < N; m0 += 64 * 16) {  // 16 loads in flight, then 16 LDS writes
+        int v[16];
 #pragma unroll
-        for (int u = 0; u < REV_ROWS; ++u) {
-            const bool rv = r + u < r1;
-            n0[u] = rv && lane < k ? ib[(size_t)(r + u) * k + lane] : -1;
-            n1[u] = rv && 64 + lane < k ? ib[(size_t)(r + u) * k + 64 + lane] : -1;
-        }
+        for (int u = 0; u < 16; ++u) v[u] = first[m0 + u * 64 + lane < N ? m0 + u * 64 + lane : 0];
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (m0 + u * 64 + lane < N) table[m0 + u * 64 + lane] = v[u];
+    }
+    auto place = [&](const RevRows<K2> &v, int r) {
 #pragma unroll
         for (int u = 0; u < REV_ROWS; ++u) {
             const int e = (b * N + r + u) * k + lane;  // edge id = (global source point) * k + slot
-            if (n0[u] >= 0) rev[atomicAdd(&table[n0[u]], 1)] = e;
-            if (n1[u] >= 0) rev[atomicAdd(&table[n1[u]], 1)] = e + 64;
+            if (v.n0[u] >= 0) rev[atomicAdd(&table[v.n0[u]], 1)] = e;
+            if (K2 && v.n1[u] >= 0) rev[atomicAdd(&table[v.n1[u]], 1)] = e + 64;
         }
+    };
+    for (int r = r0; r < r1; r += 2 * REV_ROWS) {  // ping-pong: the other buffer's rows are in flight
+        rev_load_rows<K2>(ib, k, r + REV_ROWS, r1, lane, rb);
+        place(ra, r);
+        rev_load_rows<K2>(ib, k, r + 2 * REV_ROWS, r1, lane, ra);
+        place(rb, r + REV_ROWS);
     }
 }
 
@@ -344,39 +420,59 @@ int rev_chunks(int B, int N, int k)
     // 512 chunks of N = 7000.
     int per_cu = (160 * 1024) / (4 * N + 64);
     per_cu = per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu);
+    static const int mult = getenv("DGCNN_REV_MULT") ? atoi(getenv("DGCNN_REV_MULT")) : 0;  // experiments
+    if (mult > 0) per_cu = mult;
     int c = ceil_div(256 * per_cu, B);
     const int cap = ceil_div(N, 16);
     if (c > cap) c = cap;
     return c < 1 ? 1 : c;
 }
 
-int launch_rev_build(const int32_t *idx, int B, int N, int k, int *cnt, int *indeg, int *rowptr, int32_t *rev,
-                     int *alloc, int *hubs, int *zero_words, int nzero, hipStream_t st)
+int launch_rev_build(const int32_t *idx, int B, int N, int k, int *cnt, int *indeg, int *rowptr, int *segbase, int *pcnt,
+                     int32_t *rev, int *alloc, int *extra, int *zero_words, int nzero, hipStream_t st)
 {
     DG_REQUIRE(N <= REV_MAX_N, "dgcnn: N=%d > %d unsupported in the backward", N, REV_MAX_N);
     const int P = B * N, chunks = rev_chunks(B, N, k), rows_per = ceil_div(N, chunks);
     const size_t lds = (size_t)N * sizeof(int);
     static bool attr_done = false;
     if (!attr_done) {  // more than the default 64 KB of dynamic LDS for large N
-        (void)hipFuncSetAttribute((const void *)rev_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, REV_MAX_N * 4);
-        (void)hipFuncSetAttribute((const void *)rev_place_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, REV_MAX_N * 4);
+        (void)hipFuncSetAttribute((const void *)rev_count_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, REV_MAX_N * 4);
+        (void)hipFuncSetAttribute((const void *)rev_count_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, REV_MAX_N * 4);
+        (void)hipFuncSetAttribute((const void *)rev_place_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, REV_MAX_N * 4);
+        (void)hipFuncSetAttribute((const void *)rev_place_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, REV_MAX_N * 4);
         attr_done = true;
     }
-    hipLaunchKernelGGL(rev_count_kernel, dim3(B * chunks), dim3(64), lds, st, idx, N, k, chunks, rows_per, cnt, zero_words,
-                       nzero);
-    hipLaunchKernelGGL(rev_slots_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, st, N, chunks, P, cnt, rowptr, indeg, alloc,
-                       hubs);
-    hipLaunchKernelGGL(rev_place_kernel, dim3(B * chunks), dim3(64), lds, st, idx, N, k, chunks, rows_per, cnt, rev);
+    if (k > 64)
+        hipLaunchKernelGGL((rev_count_kernel<true>), dim3(B * chunks), dim3(64), lds, st, idx, N, k, chunks, rows_per, cnt,
+                           zero_words, nzero);
+    else
+        hipLaunchKernelGGL((rev_count_kernel<false>), dim3(B * chunks), dim3(64), lds, st, idx, N, k, chunks, rows_per, cnt,
+                           zero_words, nzero);
+    hipLaunchKernelGGL(rev_slots_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, st, N, chunks, P, cnt, rowptr, indeg, segbase,
+                       pcnt, alloc, reinterpret_cast<int2 *>(extra));
+    if (k > 64)
+        hipLaunchKernelGGL((rev_place_kernel<true>), dim3(B * chunks), dim3(64), lds, st, idx, N, k, chunks, rows_per, cnt, rev);
+    else
+        hipLaunchKernelGGL((rev_place_kernel<false>), dim3(B * chunks), dim3(64), lds, st, idx, N, k, chunks, rows_per, cnt, rev);
     return 0;
 }
 
 // ---------------------------------------------------------------------------------------------
+constexpr int HIT_REC = 4;  // hit values stored per edge
+// what the sparse backward keeps per edge (one 32-byte sector, read once by the gather): the channels whose
+// max-over-k picked this edge and the gradient of the first HIT_REC of them
+struct __attribute__((aligned(16))) HitRec {
+    u64 mask;
+    float v[HIT_REC];
+    u64 pad;
+};
+static_assert(sizeof(HitRec) == 32, "HitRec is one 32-byte sector");
+
 // Per-point part of the stage-1 backward:  dD[i] = sum_j sc dv[i][j] + k A[i] - alpha (usum[i] - k TQ[i]).
 // DENSE: `dv` here is the per-point sum of dv1 over the k edges [P][64] (edge_mlp_bwd_kernel).
 // Sparse (single-stage block): dL/dy of (i, c) belongs to the ONE edge that won max-over-k, slot hitj[i][c] from the
-// forward.  The kernel writes G[i][c] = sc dv of that edge and, per edge, the 64-bit mask of the channels it won
-// (masks [E]; built in LDS with one 64-bit atomic-or per channel lane, then lane j owns edge j): the gather adds
-// G[source][c] for the set bits of each in-edge.
+// forward.  The kernel writes G[i][c] = sc dv of that edge and the HitRec of every edge of the point; the records of a
+// point are assembled in LDS: one 64-bit atomic-or per channel lane builds the masks, then lane j owns edge j.
 template <bool DENSE>
 __global__ __launch_bounds__(256) void edge_point_bwd_kernel(const float *__restrict__ TQ, int k, int P,
                                                              const float *__restrict__ stats,
@@ -384,10 +480,11 @@ __global__ __launch_bounds__(256) void edge_point_bwd_kernel(const float *__rest
                                                              const float *__restrict__ gy, const float *__restrict__ y,
                                                              const uint8_t *__restrict__ hitj,
                                                              const float *__restrict__ usum,
-                                                             const float *__restrict__ dv, u64 *__restrict__ masks,
+                                                             const float *__restrict__ dv, HitRec *__restrict__ hits,
                                                              float *__restrict__ G, float *__restrict__ dD)
 {
     __shared__ u64 smask[EDGE_WAVES][128];  // by slot (k <= 96)
+    __shared__ float sval[EDGE_WAVES][128][HIT_REC];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float mean = stats[ST_MEAN + lane], rstd = stats[ST_RSTD + lane], sc = stats[ST_SC + lane];
     const float c1 = cc[lane], c2 = cc[64 + lane];
@@ -411,8 +508,19 @@ __global__ __launch_bounds__(256) void edge_point_bwd_kernel(const float *__rest
             __builtin_amdgcn_wave_barrier();
             atomicOr(&sm[hj], 1ull << lane);
             __builtin_amdgcn_wave_barrier();
-            if (lane < k) masks[(size_t)pt * k + lane] = sm[lane];
-            if (64 + lane < k) masks[(size_t)pt * k + 64 + lane] = sm[64 + lane];
+            const int rank = __popcll(sm[hj] & ((1ull << lane) - 1ull));
+            if (rank < HIT_REC) sval[wave][hj][rank] = dsum;
+            __builtin_amdgcn_wave_barrier();
+            if (lane < k) {
+                HitRec *h = hits + (size_t)pt * k + lane;
+                h->mask = sm[lane];
+                *reinterpret_cast<float4 *>(h->v) = *reinterpret_cast<const float4 *>(sval[wave][lane]);
+            }
+            if (64 + lane < k) {
+                HitRec *h = hits + (size_t)pt * k + 64 + lane;
+                h->mask = sm[64 + lane];
+                *reinterpret_cast<float4 *>(h->v) = *reinterpret_cast<const float4 *>(sval[wave][64 + lane]);
+            }
             __builtin_amdgcn_wave_barrier();
         }
         // (eval mode: alpha = 0 and the forward has not written usum)
@@ -422,187 +530,262 @@ __global__ __launch_bounds__(256) void edge_point_bwd_kernel(const float *__rest
 }
 
 // Neighbour graphs in feature space have hubs (at B = 8, N = 7000, k = 30 on Gaussian features: median in-degree 12,
-// maximum 1372), and one wave walking a hub's list alone would set the kernel time: a point with more than REV_SEG
-// in-edges (a hub, listed by rev_slots_kernel) gets a whole WORKGROUP -- wave w takes the 64-entry segments w, w + 4, ...
-// of the (sorted) list in order and the four wave sums are added in wave order -- while the point workgroups skip it.
-// No atomics, no second pass: each row of dR is written once, by one wave, from a fixed sequence of additions.
+// maximum 1372), and one wave walking a long list alone would set the kernel time.  A list is therefore cut into
+// segments of REV_SEG in-edges (64: measured 76 / 69 / 67 / 70 us at 32 / 48 / 64 / 96): rev_slots_kernel lists the
+// (point, segment) pairs beyond segment 0, and edge_rgather_kernel runs workgroups for the points (segment 0) and for
+// those pairs side by side.  A point with ONE segment is finished by the wave that walks it.  A point with more leaves
+// one partial [sq | sd] per segment (written through, sc1) and an arrival count; the wave that arrives LAST adds the
+// partials in SEGMENT order and writes the row (fold.h's hand-off: payload sc1 + drained, ticket, sc1 loads) -- which
+// wave that is does not enter the sum, so the row is bit-stable, and no float atomic touches global memory.
 //
-// adds the in-edges held one per lane (ev = edge id, hm = the edge's channel mask; the first `cnt` lanes are valid):
-// s0/s1 += the sources' TQ rows (alternating), d0/d1 += dv rows (DENSE, by edge id) or G[source] at the mask's set bits
+// one segment: the entries [0, cnt) held one per lane (ev = edge id): sq = sum of the sources' TQ rows, sd = sum of
+// their dv rows (DENSE, by edge id) or of the hit gradients (sparse: lane t owns in-edge t -- its channel mask and hit
+// record; the few hits of an edge go to the channel sums in LDS (sacc), so the cost is per hit and not per (edge,
+// channel); LDS float atomics of ONE wave-instruction on one address are served in a fixed lane order, and the
+// instructions run in program order, so sacc is a function of the (sorted) list alone).
 template <bool DENSE>
-__device__ __forceinline__ void rgather_run(const float *__restrict__ TQ, int k, const float *__restrict__ dv,
-                                            const float *__restrict__ G, int cnt, int ev, u64 hm, int lane, float &s0,
-                                            float &s1, float &d0, float &d1)
+__device__ __forceinline__ void rgather_segment(const float *__restrict__ TQ, int k, const float *__restrict__ dv,
+                                                const HitRec *__restrict__ hits, const float *__restrict__ G, int cnt,
+                                                int ev, u64 hm, float4 rec, float *sacc, int lane, float &sq, float &sd)
 {
+    float s0 = 0.0f, s1 = 0.0f, d0 = 0.0f, d1 = 0.0f;
     const int src = (int)((unsigned)ev / (unsigned)k);
-    const unsigned hlo = (unsigned)hm, hhi = (unsigned)(hm >> 32);
-    const bool upper = lane >= 32;
-    const unsigned bit = (unsigned)lane & 31u;
     // 8 rows in flight per wave (16, as two groups, measured slower: most lists are short)
     for (int t = 0; t < cnt; t += 8) {
         float q[8], d[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int tt = t + u < cnt ? t + u : t;  // clamped: no branch around the loads
-            const unsigned i = (unsigned)__builtin_amdgcn_readlane(src, tt);
-            q[u] = TQ[i * (unsigned)EC + (unsigned)lane];  // scalar base + 32-bit offset
-            if (DENSE) {
-                d[u] = dv[(size_t)__builtin_amdgcn_readlane(ev, tt) * EC + lane];
-            } else {
-                const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)hlo, tt);
-                const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)hhi, tt);
-                d[u] = 0.0f;
-                if (((upper ? hi : lo) >> bit) & 1u) d[u] = G[i * (unsigned)EC + (unsigned)lane];
-            }
+            const int i = __builtin_amdgcn_readlane(src, tt);
+            q[u] = TQ[(unsigned)i * (unsigned)EC + (unsigned)lane];  // scalar base + 32-bit offset
+            if (DENSE) d[u] = dv[(size_t)__builtin_amdgcn_readlane(ev, tt) * EC + lane];
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const bool on = t + u < cnt;
             if (u & 1) {
                 s1 += on ? q[u] : 0.0f;
-                d1 += on ? d[u] : 0.0f;
+                if (DENSE) d1 += on ? d[u] : 0.0f;
             } else {
                 s0 += on ? q[u] : 0.0f;
-                d0 += on ? d[u] : 0.0f;
+                if (DENSE) d0 += on ? d[u] : 0.0f;
             }
         }
     }
+    sq = s0 + s1;
+    sd = d0 + d1;
+    if (!DENSE) {
+        const float rv[HIT_REC] = {rec.x, rec.y, rec.z, rec.w};
+#pragma unroll
+        for (int r = 0; r < HIT_REC; ++r) {
+            if (hm) {
+                atomicAdd(&sacc[__builtin_ctzll(hm)], rv[r]);
+                hm &= hm - 1ull;
+            }
+        }
+        while (__ballot(hm != 0)) {  // rare: more hits on one edge than its record holds
+            if (hm) {
+                const int c = __builtin_ctzll(hm);
+                atomicAdd(&sacc[c], G[(size_t)src * EC + c]);
+                hm &= hm - 1ull;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        sd = sacc[lane];
+        sacc[lane] = 0.0f;
+        __builtin_amdgcn_wave_barrier();
+    }
+    (void)hits;
+}
+
+__device__ __forceinline__ void st_sc1_f32(float *p, float v)
+{
+    __hip_atomic_store((gu32 *)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ld_sc1_f32(const float *p)
+{
+    return __uint_as_float(__hip_atomic_load((gu32 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+struct RgatherCtx {
+    const float *TP;
+    float *dR;
+    const int *indeg, *segbase;
+    int *pcnt;
+    float *part0;  // [P][2][64]: partial of segment 0 of a multi-segment point
+    float *partx;  // [pairs][2][64]: partials of the extra (point, segment) pairs, by pair index
+    float alpha, a0, dscale;
+};
+// a wave has finished segment `seg` of the multi-segment point pt (deg in-edges): publish its partial, draw a ticket;
+// the last arriver adds the partials in segment order and writes dR[pt]
+__device__ __forceinline__ void rgather_publish(const RgatherCtx &cx, int pt, int seg, int deg, float sq, float sd, int lane)
+{
+    const int nseg = (deg + REV_SEG - 1) / REV_SEG;
+    const int sb = cx.segbase[pt];
+    float *dst = seg == 0 ? cx.part0 + (size_t)pt * 128 : cx.partx + (size_t)(sb + seg - 1) * 128;
+    st_sc1_f32(dst + lane, sq);
+    st_sc1_f32(dst + 64 + lane, sd);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the partial has left this wave before the ticket is drawn
+    int last = 0;
+    if (lane == 0) last = ticket(cx.pcnt + pt) == nseg - 1 ? 1 : 0;
+    last = __builtin_amdgcn_readfirstlane(last);
+    if (!last) return;
+    float tq = ld_sc1_f32(cx.part0 + (size_t)pt * 128 + lane), td = ld_sc1_f32(cx.part0 + (size_t)pt * 128 + 64 + lane);
+    const float *px = cx.partx + (size_t)sb * 128;
+    for (int s0 = 0; s0 < nseg - 1; s0 += 8) {  // 8 partials in flight, added in segment order
+        float vq[8], vd[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int sx = s0 + u < nseg - 1 ? s0 + u : s0;
+            vq[u] = ld_sc1_f32(px + (size_t)sx * 128 + lane);
+            vd[u] = ld_sc1_f32(px + (size_t)sx * 128 + 64 + lane);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool on = s0 + u < nseg - 1;
+            tq += on ? vq[u] : 0.0f;
+            td += on ? vd[u] : 0.0f;
+        }
+    }
+    const float fdeg = (float)deg;
+    cx.dR[(size_t)pt * EC + lane] = fdeg * cx.a0 - cx.alpha * (tq + fdeg * cx.TP[(size_t)pt * EC + lane]) + cx.dscale * td;
 }
 
 template <bool DENSE>
 __global__ __launch_bounds__(256) void edge_rgather_kernel(const float *__restrict__ TP, const float *__restrict__ TQ,
                                                            const int *__restrict__ rowptr, const int *__restrict__ indeg,
+                                                           const int *__restrict__ segbase, int *__restrict__ pcnt,
                                                            const int32_t *__restrict__ rev, int k, int P,
                                                            const float *__restrict__ stats,
                                                            const float *__restrict__ cc, const float *__restrict__ dv,
-                                                           const u64 *__restrict__ masks, const float *__restrict__ G,
-                                                           const int *__restrict__ nhubs_p, const int *__restrict__ hubs,
-                                                           int hub_blocks, float *__restrict__ dR)
+                                                           const HitRec *__restrict__ hits, const float *__restrict__ G,
+                                                           const int *__restrict__ nextra, const int2 *__restrict__ extra,
+                                                           float *__restrict__ part0, float *__restrict__ partx,
+                                                           int main_blocks, float *__restrict__ dR)
 {
-    // Workgroups 0 .. hub_blocks - 1 take the hubs (long-running: dispatched first), the others walk the points.
-    // DENSE: dv [E][64] rows by edge id, pre-multiplied by nothing (sc applied here).  Sparse: masks [E] by edge id and
-    // G [P][64] = sc dL/dv of the centre's surviving edge per channel, both from edge_point_bwd_kernel.
+    // Workgroups 0 .. main_blocks - 1 walk the points (segment 0 of every list), the others the extra segments of the
+    // long lists, concurrently (one launch; dispatching the extra workgroups first was measured slower).
+    // DENSE: dv [E][64] rows by edge id (sc applied here).  Sparse: hits[e] by edge id and G [P][64] = sc dL/dv of the
+    // centre's surviving edge per channel, both written by edge_point_bwd_kernel.
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float mean = stats[ST_MEAN + lane], rstd = stats[ST_RSTD + lane], sc = stats[ST_SC + lane];
     const float c1 = cc[lane], c2 = cc[64 + lane];
-    const float alpha = sc * c2 * rstd, a0 = -sc * (c1 - c2 * rstd * mean);
-    const float dscale = DENSE ? sc : 1.0f;
-    if ((int)blockIdx.x < hub_blocks) {
-        __shared__ float red[EDGE_WAVES][2][64];
-        const int nh = *nhubs_p;
-        for (int hx = (int)blockIdx.x; hx < nh; hx += hub_blocks) {
-            const int pt = hubs[hx];
-            const int beg = rowptr[pt], deg = indeg[pt];
-            float s0 = 0.0f, s1 = 0.0f, d0 = 0.0f, d1 = 0.0f;
-            for (int e0 = wave * REV_SEG; e0 < deg; e0 += EDGE_WAVES * REV_SEG) {
-                const int cnt = deg - e0 < REV_SEG ? deg - e0 : REV_SEG;
-                const int ev = lane < cnt ? rev[beg + e0 + lane] : 0;
-                u64 hm = 0;
-                if (!DENSE && lane < cnt) hm = masks[ev];
-                rgather_run<DENSE>(TQ, k, dv, G, cnt, ev, hm, lane, s0, s1, d0, d1);
+    RgatherCtx cx;
+    cx.TP = TP;
+    cx.dR = dR;
+    cx.indeg = indeg;
+    cx.segbase = segbase;
+    cx.pcnt = pcnt;
+    cx.part0 = part0;
+    cx.partx = partx;
+    cx.alpha = sc * c2 * rstd;
+    cx.a0 = -sc * (c1 - c2 * rstd * mean);
+    cx.dscale = DENSE ? sc : 1.0f;
+    __shared__ float sacc_all[EDGE_WAVES][64];  // sparse dv: hit gradients of the current segment, by channel
+    float *sacc = sacc_all[wave];
+    if (!DENSE) sacc[lane] = 0.0f;
+    if ((int)blockIdx.x >= main_blocks) {
+        const int n = *nextra;
+        for (int w = ((int)blockIdx.x - main_blocks) * EDGE_WAVES + wave; w < n;
+             w += ((int)gridDim.x - main_blocks) * EDGE_WAVES) {
+            const int2 ps = extra[w];
+            const int pt = __builtin_amdgcn_readfirstlane(ps.x), seg = __builtin_amdgcn_readfirstlane(ps.y);
+            const int pbeg = __builtin_amdgcn_readfirstlane(rowptr[pt]), deg = __builtin_amdgcn_readfirstlane(indeg[pt]);
+            const int e0 = seg * REV_SEG;
+            const int cnt = deg - e0 < REV_SEG ? deg - e0 : REV_SEG;
+            const int ev = lane < cnt ? rev[pbeg + e0 + lane] : 0;
+            u64 hm = 0;
+            float4 rec = float4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (!DENSE && lane < cnt) {
+                const HitRec *h = hits + ev;
+                hm = h->mask;
+                rec = *reinterpret_cast<const float4 *>(h->v);
             }
-            red[wave][0][lane] = s0 + s1;
-            red[wave][1][lane] = d0 + d1;
-            __syncthreads();
-            if (wave == 0) {
-                float sq = red[0][0][lane], sd = red[0][1][lane];
-#pragma unroll
-                for (int w = 1; w < EDGE_WAVES; ++w) {
-                    sq += red[w][0][lane];
-                    sd += red[w][1][lane];
-                }
-                const float fdeg = (float)deg;
-                dR[(size_t)pt * EC + lane] = fdeg * a0 - alpha * (sq + fdeg * TP[(size_t)pt * EC + lane]) + dscale * sd;
-            }
-            __syncthreads();
+            float sq, sd;
+            rgather_segment<DENSE>(TQ, k, dv, hits, G, cnt, ev, hm, rec, sacc, lane, sq, sd);
+            rgather_publish(cx, pt, seg, deg, sq, sd, lane);
         }
         return;
     }
-    PointIter it;  // point_iter() over the point workgroups only (hub_blocks is a multiple of 8)
+    PointIter it;  // point_iter() over the first main_blocks workgroups only
     {
-        const int id = (int)blockIdx.x - hub_blocks, nb = (int)gridDim.x - hub_blocks;
-        const int xcd = id & 7, slot = id >> 3, nslots = nb >> 3;
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = main_blocks >> 3;
         const int per = (P + 7) >> 3, first = xcd * per;
         it.end = first + per < P ? first + per : P;
         it.cur = first + slot * EDGE_WAVES + wave;
         it.step = nslots * EDGE_WAVES;
     }
-    // The chain list bounds -> list entries -> (masks,) rows is three or four dependent loads deep, so it is
-    // software-pipelined across the points of a wave: bounds three points ahead, entries two, masks one.
-    int beg1 = 0, deg1 = 0, ev1 = 0;  // point + 1 step: bounds arrived, entries in flight
-    int beg2 = 0, deg2 = 0;           // point + 2 steps: bounds in flight
-    int deg0 = 0, ev0 = 0;            // this point
-    u64 hm0 = 0;
+    // The chain list bounds -> list entries -> rows is three dependent loads deep, so it is software-pipelined
+    // across the points of a wave: the bounds are fetched two points ahead, the first 64 list entries one.
     int pt = it.cur;
-    auto bounds = [&](int p, int &b_, int &d_) {
-        b_ = 0;
-        d_ = 0;
-        if (p < it.end) {
-            b_ = rowptr[p];
-            d_ = indeg[p];
+    int deg_n = 0, ev_n = 0;    // degree (uniform) and first entries of the point about to be processed
+    int b_nn = 0, d_nn = 0;     // bounds of the point after it, in flight
+    if (pt < it.end) {
+        const int beg_n = __builtin_amdgcn_readfirstlane(rowptr[pt]);
+        deg_n = __builtin_amdgcn_readfirstlane(indeg[pt]);
+        ev_n = lane < deg_n ? rev[beg_n + lane] : 0;
+        if (pt + it.step < it.end) {
+            b_nn = rowptr[pt + it.step];
+            d_nn = indeg[pt + it.step];
         }
-    };
-    auto entries = [&](int b_, int d_) -> int {
-        const int bu = __builtin_amdgcn_readfirstlane(b_), du = __builtin_amdgcn_readfirstlane(d_);
-        return du <= REV_SEG && lane < du ? rev[bu + lane] : 0;
-    };
-    {
-        int b0;
-        bounds(pt, b0, deg0);
-        bounds(pt + it.step, beg1, deg1);
-        bounds(pt + 2 * it.step, beg2, deg2);
-        ev0 = entries(b0, deg0);
-        ev1 = entries(beg1, deg1);
-        deg0 = __builtin_amdgcn_readfirstlane(deg0);
-        if (!DENSE && deg0 <= REV_SEG && lane < deg0) hm0 = masks[ev0];
     }
     for (; pt < it.end; pt += it.step) {
         // (wave-uniform values are made visibly so: lane selects of v_readlane must be scalars)
-        const int deg = deg0, ev = ev0;
-        const u64 hm = hm0;
-        // advance the pipeline
-        const int degn = __builtin_amdgcn_readfirstlane(deg1);
-        u64 hmn = 0;
-        if (!DENSE && degn <= REV_SEG && lane < degn) hmn = masks[ev1];
-        const int evn = ev1;
-        ev1 = entries(beg2, deg2);
-        beg1 = beg2;
-        deg1 = deg2;
-        bounds(pt + 3 * it.step, beg2, deg2);
-        deg0 = degn;
-        ev0 = evn;
-        hm0 = hmn;
-        if (deg > REV_SEG) continue;  // a hub: its workgroup writes the row
-        float s0 = 0.0f, s1 = 0.0f, d0 = 0.0f, d1 = 0.0f;
-        rgather_run<DENSE>(TQ, k, dv, G, deg, ev, hm, lane, s0, s1, d0, d1);
-        const float fdeg = (float)deg;
-        dR[(size_t)pt * EC + lane] =
-            fdeg * a0 - alpha * ((s0 + s1) + fdeg * TP[(size_t)pt * EC + lane]) + dscale * (d0 + d1);
+        const int deg = deg_n;
+        const int ev = ev_n;
+        if (pt + it.step < it.end) {
+            const int beg_n = __builtin_amdgcn_readfirstlane(b_nn);
+            deg_n = __builtin_amdgcn_readfirstlane(d_nn);
+            ev_n = lane < deg_n ? rev[beg_n + lane] : 0;
+        }
+        if (pt + 2 * it.step < it.end) {
+            b_nn = rowptr[pt + 2 * it.step];
+            d_nn = indeg[pt + 2 * it.step];
+        }
+        const int cnt = deg < REV_SEG ? deg : REV_SEG;
+        u64 hm = 0;
+        float4 rec = float4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (!DENSE && lane < cnt) {
+            const HitRec *h = hits + ev;
+            hm = h->mask;
+            rec = *reinterpret_cast<const float4 *>(h->v);
+        }
+        float sq, sd;
+        rgather_segment<DENSE>(TQ, k, dv, hits, G, cnt, ev, hm, rec, sacc, lane, sq, sd);
+        if (deg <= REV_SEG) {
+            const float fdeg = (float)deg;
+            dR[(size_t)pt * EC + lane] = fdeg * cx.a0 - cx.alpha * (sq + fdeg * TP[(size_t)pt * EC + lane]) + cx.dscale * sd;
+        } else {
+            rgather_publish(cx, pt, 0, deg, sq, sd, lane);
+        }
     }
 }
 
 int launch_edge_bwd(const float *TP, const float *TQ, int B, int N, int k, const float *stats, const float *cc, float slope,
                     const float *gy, const float *y, const uint8_t *hitj, const float *usum, const float *dv,
-                    const float *dvsum, const int *rowptr, const int *indeg, const int32_t *rev, const int *alloc,
-                    const int *hubs, void *masks, float *G, float *dR, float *dD, hipStream_t st)
+                    const float *dvsum, const int *rowptr, const int *indeg, const int *segbase, int *pcnt,
+                    const int32_t *rev, const int *alloc, const int *extra, void *hits, float *G, float *part0,
+                    float *partx, float *dR, float *dD, hipStream_t st)
 {
     const int P = B * N;
     const dim3 grid(stream_grid(P)), block(256);
     if (dv)
         hipLaunchKernelGGL((edge_point_bwd_kernel<true>), grid, block, 0, st, TQ, k, P, stats, cc, slope, gy, y, hitj, usum,
-                           dvsum, (u64 *)masks, G, dD);
+                           dvsum, (HitRec *)hits, G, dD);
     else
         hipLaunchKernelGGL((edge_point_bwd_kernel<false>), grid, block, 0, st, TQ, k, P, stats, cc, slope, gy, y, hitj, usum,
-                           nullptr, (u64 *)masks, G, dD);
+                           nullptr, (HitRec *)hits, G, dD);
     prof_begin(PROF_EDGE_RGATHER, st);
-    const int hub_blocks = 256;
-    const dim3 ggrid(hub_blocks + grid.x);
+    // one launch: the point workgroups and, behind them, workgroups for the extra segments of the long lists
+    const int main_blocks = (int)grid.x, extra_blocks = main_blocks / 2;
+    const dim3 ggrid(main_blocks + extra_blocks);
+    const int2 *elist = reinterpret_cast<const int2 *>(extra);
     if (dv)
-        hipLaunchKernelGGL((edge_rgather_kernel<true>), ggrid, block, 0, st, TP, TQ, rowptr, indeg, rev, k, P, stats, cc, dv,
-                           (const u64 *)masks, G, alloc + 1, hubs, hub_blocks, dR);
+        hipLaunchKernelGGL((edge_rgather_kernel<true>), ggrid, block, 0, st, TP, TQ, rowptr, indeg, segbase, pcnt, rev, k, P,
+                           stats, cc, dv, (const HitRec *)hits, G, alloc + 1, elist, part0, partx, main_blocks, dR);
     else
-        hipLaunchKernelGGL((edge_rgather_kernel<false>), ggrid, block, 0, st, TP, TQ, rowptr, indeg, rev, k, P, stats, cc, dv,
-                           (const u64 *)masks, G, alloc + 1, hubs, hub_blocks, dR);
+        hipLaunchKernelGGL((edge_rgather_kernel<false>), ggrid, block, 0, st, TP, TQ, rowptr, indeg, segbase, pcnt, rev, k, P,
+                           stats, cc, dv, (const HitRec *)hits, G, alloc + 1, elist, part0, partx, main_blocks, dR);
     prof_end(PROF_EDGE_RGATHER, st);
     return 0;
 }

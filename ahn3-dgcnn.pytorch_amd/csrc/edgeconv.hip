@@ -16,7 +16,7 @@
 //   bwd_point        last BN: gbn_w, gbn_b and the two mean terms, finished in the same launch
 //   2 stages: edge_mlp_bwd  recompute a1, u2; du2; gW2 partials; dv1 = (W2^T du2) * LReLU'; BN1 sums finished in the launch
 //             sum_partials  gW2
-//   edge_point_bwd   dD (sum over k), per-edge winner masks and G (one-stage)
+//   edge_point_bwd   dD (sum over k), per-edge hit records and G (one-stage)
 //   edge_rgather     dR (gather over the reverse lists: fixed order, no atomics)
 //   wgrad + finish   gW1 = [ (dR - dD)^T x | dD^T x ]                           (MFMA, per point)
 //   rowgemm          gx = dR Wa + dD (Wb - Wa)                                   (MFMA, per point)
@@ -96,9 +96,9 @@ static FwdWs fwd_ws(const dgcnn_edgeconv_desc *d, void *p)
 struct BwdWs {
     int *zero;  // [Z_WORDS]: fold counters, list allocation
     FoldBufs fa, fb;
-    float *cc1, *cc2, *dR, *dD, *wg_partial, *dv1, *dvsum, *dw2_partial, *G;
-    int *cnt, *indeg, *rowptr, *rev, *hubs;  // reverse adjacency of the neighbour graph
-    void *masks;
+    float *cc1, *cc2, *dR, *dD, *wg_partial, *dv1, *dvsum, *dw2_partial, *G, *part0, *partx;
+    int *cnt, *indeg, *rowptr, *segbase, *pcnt, *rev, *extra;  // reverse adjacency of the neighbour graph
+    void *hits;
     size_t bytes;
 };
 static BwdWs bwd_ws(const dgcnn_edgeconv_desc *d, void *p)
@@ -117,9 +117,13 @@ static BwdWs bwd_ws(const dgcnn_edgeconv_desc *d, void *p)
     w.cnt = c.take<int>((size_t)d->B * rev_chunks(d->B, d->N, d->k) * d->N);
     w.indeg = c.take<int>(P);
     w.rowptr = c.take<int>(P);
+    w.segbase = c.take<int>(P);
+    w.pcnt = c.take<int>(P);
     w.rev = c.take<int>(P * d->k);
-    w.hubs = c.take<int>(P * d->k / REV_SEG + 1);
-    w.masks = d->n_stage == 1 ? (void *)c.take<u64>(P * d->k) : nullptr;  // 8 bytes per edge
+    w.extra = c.take<int>(2 * (P * d->k / REV_SEG + 1));
+    w.part0 = c.take<float>(P * 128);
+    w.partx = c.take<float>((P * d->k / REV_SEG + 1) * 128);
+    w.hits = d->n_stage == 1 ? (void *)c.take<u64>(P * d->k * 4) : nullptr;  // 32 bytes per edge
     w.G = d->n_stage == 1 ? c.take<float>(P * EC) : nullptr;
     if (d->n_stage == 2) {
         w.dv1 = c.take<float>(P * d->k * EC);
@@ -225,13 +229,15 @@ extern "C" int dgcnn_edgeconv_bwd(const dgcnn_edgeconv_desc *d, const float *x, 
 
     // (measured: building the lists on a side stream, concurrently with the BatchNorm-backward sums and the
     // per-point pass, costs more in cross-stream barriers than it hides: 0.776 ms against 0.725 ms per step)
-    if (launch_rev_build(idx, d->B, N, k, w.cnt, w.indeg, w.rowptr, w.rev, w.zero + Z_ALLOC, w.hubs, w.zero, Z_WORDS, st))
+    if (launch_rev_build(idx, d->B, N, k, w.cnt, w.indeg, w.rowptr, w.segbase, w.pcnt, w.rev, w.zero + Z_ALLOC, w.extra,
+                         w.zero, Z_WORDS, st))
         return 1;
     const FoldSet fsa{w.fa.rec, w.fa.folded, w.zero + Z_FOLD_A}, fsb{w.fb.rec, w.fb.folded, w.zero + Z_FOLD_B};
     if (d->n_stage == 1) {
         launch_bwd_point(gy, s.usel, s.stats1, d->slope, P, E, d->training, fsa, g->gbn1_w, g->gbn1_b, w.cc1, st);
         if (launch_edge_bwd(s.TP, s.TQ, d->B, N, k, s.stats1, w.cc1, d->slope, gy, y, s.hitj, s.usum, nullptr, nullptr,
-                            w.rowptr, w.indeg, w.rev, w.zero + Z_ALLOC, w.hubs, w.masks, w.G, w.dR, w.dD, st))
+                            w.rowptr, w.indeg, w.segbase, w.pcnt, w.rev, w.zero + Z_ALLOC, w.extra, w.hits, w.G, w.part0,
+                            w.partx, w.dR, w.dD, st))
             return 1;
     } else {
         launch_bwd_point(gy, s.usel, s.stats2, d->slope, P, E, d->training, fsa, g->gbn2_w, g->gbn2_b, w.cc2, st);
@@ -240,7 +246,8 @@ extern "C" int dgcnn_edgeconv_bwd(const dgcnn_edgeconv_desc *d, const float *x, 
                             s.hitj, w.dv1, w.dvsum, w.dw2_partial, fsb, fin1, st);
         launch_sum_partials(w.dw2_partial, mlp_grid(P), EC * EC, g->gw2, st);
         if (launch_edge_bwd(s.TP, s.TQ, d->B, N, k, s.stats1, w.cc1, d->slope, gy, y, nullptr, s.usum, w.dv1, w.dvsum,
-                            w.rowptr, w.indeg, w.rev, w.zero + Z_ALLOC, w.hubs, nullptr, nullptr, w.dR, w.dD, st))
+                            w.rowptr, w.indeg, w.segbase, w.pcnt, w.rev, w.zero + Z_ALLOC, w.extra, nullptr, nullptr,
+                            w.part0, w.partx, w.dR, w.dD, st))
             return 1;
     }
     launch_wgrad(w.dR, EC, w.dD, EC, x, C, P, w.wg_partial, st);
@@ -261,7 +268,7 @@ extern "C" int dgcnn_graph_feature_fwd(const float *x, const int32_t *idx, int B
 }
 
 struct GfWs {
-    int *zero, *cnt, *indeg, *rowptr, *rev, *hubs;
+    int *zero, *cnt, *indeg, *rowptr, *segbase, *pcnt, *rev, *extra;
     size_t bytes;
 };
 static GfWs gf_ws(int B, int N, int k, void *p)
@@ -273,8 +280,10 @@ static GfWs gf_ws(int B, int N, int k, void *p)
     w.cnt = c.take<int>((size_t)B * rev_chunks(B, N, k) * N);
     w.indeg = c.take<int>(P);
     w.rowptr = c.take<int>(P);
+    w.segbase = c.take<int>(P);
+    w.pcnt = c.take<int>(P);
     w.rev = c.take<int>(P * k);
-    w.hubs = c.take<int>(P * k / REV_SEG + 1);
+    w.extra = c.take<int>(2 * (P * k / REV_SEG + 1));
     w.bytes = c.off;
     return w;
 }
@@ -296,7 +305,9 @@ extern "C" int dgcnn_graph_feature_bwd(const float *gout, const int32_t *idx, in
     DG_REQUIRE(workspace_bytes >= w.bytes, "dgcnn_graph_feature_bwd: workspace too small (%zu < %zu)", workspace_bytes,
                w.bytes);
     hipStream_t st = (hipStream_t)stream;
-    if (launch_rev_build(idx, B, N, k, w.cnt, w.indeg, w.rowptr, w.rev, w.zero + Z_ALLOC, w.hubs, w.zero, Z_WORDS, st)) return 1;
+    if (launch_rev_build(idx, B, N, k, w.cnt, w.indeg, w.rowptr, w.segbase, w.pcnt, w.rev, w.zero + Z_ALLOC, w.extra, w.zero,
+                         Z_WORDS, st))
+        return 1;
     launch_graph_feature_bwd(gout, w.rowptr, w.indeg, w.rev, B, N, C, k, gx, st);
     DG_CHECK_LAUNCH("graph_feature_bwd_kernel");
     return 0;
