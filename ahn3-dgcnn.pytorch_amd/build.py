@@ -26,7 +26,6 @@ FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
          "-mllvm", "-amdgpu-mfma-vgpr-form"]
 FLAGS += os.environ.get("DGCNN_EXTRA_HIPCC_FLAGS", "").split()  # experiments only (e.g. ablation -D switches)
 
-
 def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 

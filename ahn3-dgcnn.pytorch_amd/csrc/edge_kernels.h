@@ -37,8 +37,10 @@ void launch_bn_eval_stats(const dgcnn_bn_params &bn, float eps, float *stats, hi
 // y = LeakyReLU(sc * usel + sh)
 void launch_edge_out(const float *usel, const float *stats, float slope, int P, float *y, hipStream_t st);
 // last-stage BN backward sums from per-point quantities, finished in the same launch: gbn_w, gbn_b and cc = [c1 | c2]
+// gmax_bits (zero at launch): receives the bits of max |gy . LReLU'| (an atomic max: order-independent)
 void launch_bwd_point(const float *gy, const float *usel, const float *stats, float slope, int P, double count,
-                      int training, const FoldSet &fs, float *gbn_w, float *gbn_b, float *cc, hipStream_t st);
+                      int training, const FoldSet &fs, float *gbn_w, float *gbn_b, float *cc, unsigned *gmax_bits,
+                      hipStream_t st);
 // Reverse adjacency of the neighbour graph (depends on idx only), every list sorted by edge id.  Scratch: cnt
 // [B * rev_chunks][N]; results: rowptr [P] (list start), indeg [P], segbase [P], pcnt [P] (zeroed), rev [E], alloc [2]
 // (alloc[1] = number of extra (point, segment) pairs), extra [2 (E / REV_SEG + 1)] ints.  The first kernel also zeroes
@@ -69,9 +71,12 @@ void launch_edge_mlp_fwd(const float *TP, const float *TQ, const int32_t *idx, i
                          uint8_t *hit2, const FoldSet &fs, const BnBatchStats *fin, hipStream_t st);
 // dv1 [E][64]; dvsum [P][64] = sum over each point's k edges of dv1; partial_dw2 [grid][64][64]; the BatchNorm-1
 // backward sums (sum dv1, sum dv1 * uhat1) are finished in the same launch (fold.h) -> fin1
+// gmax_bits: bits of max |dL/dy . LReLU'| (launch_bwd_point); guard: one int, zero at launch -- raised when an operand
+// leaves the fp16 range, in which case the fp32 form of the pass (fold counters fs_fallback) redoes it in the same call
 void launch_edge_mlp_bwd(const float *TP, const float *TQ, const int32_t *idx, int N, int k, int P,
                          const float *stats1, const float *stats2, const float *cc2, const float *w2, float slope,
-                         int training, const float *gy, const float *y, const uint8_t *hit2, float *dv1, float *dvsum,
-                         float *partial_dw2, const FoldSet &fs, const BnBackwardSums &fin1, hipStream_t st);
+                         int training, const float *gy, const float *y, const uint8_t *hit2, const unsigned *gmax_bits,
+                         float *dv1, float *dvsum, float *partial_dw2, const FoldSet &fs, const FoldSet &fs_fallback,
+                         const BnBackwardSums &fin1, int *guard, hipStream_t st);
 
 }  // namespace dgcnn

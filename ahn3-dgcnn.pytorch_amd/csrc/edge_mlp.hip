@@ -6,7 +6,8 @@
 // parity bound -- for 12 v_mfma_f32_32x32x16_f16 (384 cycles) per 32 x 32 x 64 tile instead of 32
 // v_mfma_f32_32x32x2_f32 (2048 cycles).  On gfx950 the fp32-input MFMA also shares the vector ALU's FMA lanes: its time
 // and the gather / epilogue VALU time ADD (measured: 114 us MFMA + 56 + 27 us VALU phases = the fp32 kernel's 206 us).
-// Backward: v_mfma_f32_32x32x2_f32 (its operands are gradients of unknown scale).
+// Backward: the same three-product split on fp16 MFMA with exact power-of-two operand scales (edge_mlp_bwd16_kernel); the
+// fp32 kernel (v_mfma_f32_32x32x2_f32) stays as its guarded fallback.
 //
 // One wave processes one point at a time; its k edges are the M dimension of a 32-row MFMA tile
 // (k = 30 -> 30 of 32 rows used; k > 32 -> two tiles):
@@ -23,14 +24,11 @@
 #include <stdlib.h>
 
 #include "edge_kernels.h"
+#include "edge_mlp_common.h"
 #include "fold.h"
 #include "prof.h"
 
 namespace dgcnn {
-
-constexpr int MLP_WAVES = 4;      // forward
-constexpr int MLP_BWD_WAVES = 8;  // backward: two waves per SIMD, one in its MFMA phases while the other gathers / stages
-constexpr int TSTR = 68;  // LDS tile row stride in floats (64 + 4: conflict-free b128 rows)
 
 // workgroups: the backward holds 156 KB of LDS (one workgroup of eight waves per CU); the forward 39 KB and about 220
 // registers per lane: two workgroups per CU (64 slots per XCD: measured 1.25 ms per step against 1.28 at 96, 1.39 at 128)
@@ -41,45 +39,6 @@ static int mlp_slots_fwd()
 }
 int mlp_grid(int P) { return point_grid(P, MLP_BWD_WAVES, 32); }
 int mlp_grid_fwd(int P) { return point_grid(P, MLP_WAVES, mlp_slots_fwd()); }
-
-__device__ __forceinline__ double shfl_xor_d(double v, int m)
-{
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __shfl_xor(lo, m);
-    hi = __shfl_xor(hi, m);
-    return __hiloint2double(hi, lo);
-}
-
-// gather one M-tile (edges j0 .. j0 + 31 of a point): the loads (rows of TP -> registers; wave-uniform table base,
-// 32-bit element offsets, rows past the list end repeat its last row) are split from the consumer, so that the
-// next point's rows can be in flight under the current point's MFMA phases
-__device__ __forceinline__ void gather_rows(const float *__restrict__ Pb, int nv, int kk, int lane, float (&p)[32])
-{
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        if (g * 8 < kk) {
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const int tt = g * 8 + t < kk ? g * 8 + t : kk - 1;
-                p[g * 8 + t] = Pb[(unsigned)__builtin_amdgcn_readlane(nv, tt) * (unsigned)EC + (unsigned)lane];
-            }
-        }
-    }
-}
-// leave a1 (and optionally u1) of the gathered tile in LDS; rows >= kk are zero
-template <bool KEEP_U>
-__device__ __forceinline__ void stage_tile(const float (&p)[32], float q, int kk, float sc1, float sh1, float slope,
-                                           float (*tileA)[TSTR], float (*tileU)[TSTR], int lane)
-{
-#pragma unroll
-    for (int j = 0; j < 32; ++j) {
-        const bool on = j < kk;
-        const float u = on ? p[j] + q : 0.0f;
-        const float a = on ? lrelu(__builtin_fmaf(u, sc1, sh1), slope) : 0.0f;
-        tileA[j][lane] = a;
-        if (KEEP_U) tileU[j][lane] = u;
-    }
-}
 
 // A operand of the 32x32x2 MFMA from a [32][TSTR] tile: lane (i, h) holds row i, columns 32 h + s
 __device__ __forceinline__ void load_a_operand(const float (*tile)[TSTR], int i32, int h, float (&a)[32])
@@ -94,7 +53,6 @@ __device__ __forceinline__ void load_a_operand(const float (*tile)[TSTR], int i3
     }
 }
 
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 constexpr float LO_SCALE = 2048.0f, LO_UNSCALE = 1.0f / 2048.0f;
 
 // x = hi + lo / 2^11 up to 2^-21 |x|: hi = x with the low 13 mantissa bits cleared (exactly a fp16 number inside the
@@ -245,13 +203,17 @@ __global__ __launch_bounds__(256) void edge_mlp_fwd_kernel(const float *__restri
 }
 
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void edge_mlp_bwd_kernel(
+// The fp32 form of the backward (v_mfma_f32_32x32x2_f32 throughout).  It is the FALLBACK of edge_mlp_bwd16_kernel
+// below: launched behind it, it returns at once unless that kernel has raised *guard (an operand left the fp16 range).
+__global__ __launch_bounds__(512) void edge_mlp_bwd_f32_kernel(
     const float *__restrict__ TP, const float *__restrict__ TQ, const int32_t *__restrict__ idx, int N, int k, int P,
     const float *__restrict__ stats1, const float *__restrict__ stats2, const float *__restrict__ cc2,
     const float *__restrict__ w2, float slope, int training, const float *__restrict__ gy,
     const float *__restrict__ y, const uint8_t *__restrict__ hit2, float *__restrict__ dv1,
-    float *__restrict__ dvsum, float *__restrict__ partial_dw2, FoldSet fs, BnBackwardSums fin1)
+    float *__restrict__ dvsum, float *__restrict__ partial_dw2, FoldSet fs, BnBackwardSums fin1,
+    const int *__restrict__ guard)
 {
+    if (guard && *guard == 0) return;
     // W2 [co][ci] once, rows padded to 65 floats, serves as the B operand of both products that contract over a
     // channel index without bank conflicts:
     //   u2  = a1 . W2^T :  B[k = ci = 32 h + s][n = co] = w2s[nt 32 + n][32 h + s]   (lanes n: stride 65)
@@ -430,6 +392,7 @@ __global__ __launch_bounds__(512) void edge_mlp_bwd_kernel(
     }
 }
 
+
 // ---------------------------------------------------------------------------------------------
 void launch_edge_mlp_fwd(const float *TP, const float *TQ, const int32_t *idx, int N, int k, int P,
                          const float *stats1, const float *w2, const float *gamma2, float slope, float *usel2,
@@ -441,14 +404,31 @@ void launch_edge_mlp_fwd(const float *TP, const float *TQ, const int32_t *idx, i
     prof_end(PROF_EDGE_MLP_FWD, st);
 }
 
+void launch_edge_mlp_bwd16(const float *TP, const float *TQ, const int32_t *idx, int N, int k, int P, const float *stats1,
+                           const float *stats2, const float *cc2, const float *w2, float slope, int training,
+                           const float *gy, const float *y, const uint8_t *hit2, const unsigned *gmax_bits, float *dv1,
+                           float *dvsum, float *partial_dw2, const FoldSet &fs, const BnBackwardSums &fin1, int *guard,
+                           int grid, hipStream_t st);  // edge_mlp_bwd16.hip
+
 void launch_edge_mlp_bwd(const float *TP, const float *TQ, const int32_t *idx, int N, int k, int P,
                          const float *stats1, const float *stats2, const float *cc2, const float *w2, float slope,
-                         int training, const float *gy, const float *y, const uint8_t *hit2, float *dv1, float *dvsum,
-                         float *partial_dw2, const FoldSet &fs, const BnBackwardSums &fin1, hipStream_t st)
+                         int training, const float *gy, const float *y, const uint8_t *hit2, const unsigned *gmax_bits,
+                         float *dv1, float *dvsum, float *partial_dw2, const FoldSet &fs, const FoldSet &fs_fallback,
+                         const BnBackwardSums &fin1, int *guard, hipStream_t st)
 {
+    static const int force32 = getenv("DGCNN_MLP_BWD_F32") ? atoi(getenv("DGCNN_MLP_BWD_F32")) : 0;  // experiments / tests
+    const dim3 grid(mlp_grid(P)), block(64 * MLP_BWD_WAVES);
     prof_begin(PROF_EDGE_MLP_BWD, st);
-    hipLaunchKernelGGL(edge_mlp_bwd_kernel, dim3(mlp_grid(P)), dim3(64 * MLP_BWD_WAVES), 0, st, TP, TQ, idx, N, k, P, stats1, stats2,
-                       cc2, w2, slope, training, gy, y, hit2, dv1, dvsum, partial_dw2, fs, fin1);
+    if (force32) {
+        hipLaunchKernelGGL(edge_mlp_bwd_f32_kernel, grid, block, 0, st, TP, TQ, idx, N, k, P, stats1, stats2, cc2, w2, slope,
+                           training, gy, y, hit2, dv1, dvsum, partial_dw2, fs, fin1, (const int *)nullptr);
+    } else {
+        launch_edge_mlp_bwd16(TP, TQ, idx, N, k, P, stats1, stats2, cc2, w2, slope, training, gy, y, hit2, gmax_bits, dv1,
+                              dvsum, partial_dw2, fs, fin1, guard, (int)grid.x, st);
+        // the fp32 form of the same pass: returns at once unless the fp16 kernel raised *guard
+        hipLaunchKernelGGL(edge_mlp_bwd_f32_kernel, grid, block, 0, st, TP, TQ, idx, N, k, P, stats1, stats2, cc2, w2, slope,
+                           training, gy, y, hit2, dv1, dvsum, partial_dw2, fs_fallback, fin1, (const int *)guard);
+    }
     prof_end(PROF_EDGE_MLP_BWD, st);
 }
 

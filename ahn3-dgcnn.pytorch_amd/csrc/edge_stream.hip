@@ -175,12 +175,13 @@ __global__ void edge_out_kernel(const float *__restrict__ usel, const float *__r
 // the sums itself (fold.h): gbn_b, gbn_w and the two mean terms cc.
 __global__ __launch_bounds__(256) void bwd_point_kernel(const float *__restrict__ gy, const float *__restrict__ usel,
                                                         const float *__restrict__ stats, float slope, int P,
-                                                        FoldSet fs, BnBackwardSums fin)
+                                                        FoldSet fs, BnBackwardSums fin, unsigned *__restrict__ gmax_bits)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float mean = stats[ST_MEAN + lane], rstd = stats[ST_RSTD + lane];
     const float sc = stats[ST_SC + lane], sh = stats[ST_SH + lane];
     double acc[2] = {0.0, 0.0};
+    float gmax = 0.0f;
     for (int pt = blockIdx.x * EDGE_WAVES + wave; pt < P; pt += gridDim.x * EDGE_WAVES) {
         const float us = usel[(size_t)pt * EC + lane];
         const float v = __builtin_fmaf(us, sc, sh);
@@ -188,6 +189,23 @@ __global__ __launch_bounds__(256) void bwd_point_kernel(const float *__restrict_
         const float uhat = (us - mean) * rstd;
         acc[0] += (double)dv;
         acc[1] = __builtin_fma((double)dv, (double)uhat, acc[1]);
+        gmax = fmaxf(gmax, fabsf(dv));
+    }
+    // max |dv| for the operand scale of edge_mlp_bwd16_kernel: non-negative floats order like their bits, and a
+    // maximum does not depend on the order of its arguments
+    if (gmax_bits) {  // (one atomic per workgroup, and only while it still raises the maximum: same-address atomics queue)
+        __shared__ float s_gmax[EDGE_WAVES];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, o));
+        if (lane == 0) s_gmax[wave] = gmax;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float m = s_gmax[0];
+#pragma unroll
+            for (int w = 1; w < EDGE_WAVES; ++w) m = fmaxf(m, s_gmax[w]);
+            const unsigned bits = __float_as_uint(m);
+            if (bits > __hip_atomic_load(gmax_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(gmax_bits, bits);
+        }
     }
     fold_and_finalize<2, EDGE_WAVES>(acc, fs, fin);
 }
@@ -862,12 +880,13 @@ void launch_edge_out(const float *usel, const float *stats, float slope, int P, 
 }
 
 void launch_bwd_point(const float *gy, const float *usel, const float *stats, float slope, int P, double count,
-                      int training, const FoldSet &fs, float *gbn_w, float *gbn_b, float *cc, hipStream_t st)
+                      int training, const FoldSet &fs, float *gbn_w, float *gbn_b, float *cc, unsigned *gmax_bits,
+                      hipStream_t st)
 {
     int grid = ceil_div(P, EDGE_WAVES * 8);
     if (grid > 512) grid = 512;
     const BnBackwardSums fin{count, training, gbn_w, gbn_b, cc};
-    hipLaunchKernelGGL(bwd_point_kernel, dim3(grid), dim3(256), 0, st, gy, usel, stats, slope, P, fs, fin);
+    hipLaunchKernelGGL(bwd_point_kernel, dim3(grid), dim3(256), 0, st, gy, usel, stats, slope, P, fs, fin, gmax_bits);
 }
 
 void launch_graph_feature_fwd(const float *x, const int32_t *idx, int B, int N, int C, int k, float *out,

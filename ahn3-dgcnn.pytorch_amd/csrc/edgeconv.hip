@@ -63,7 +63,15 @@ static SavedLayout saved_layout(const dgcnn_edgeconv_desc *d, void *p)
 }
 
 // counters that must be zero when the kernels using them start (zeroed by the first kernel of each call)
-enum { Z_FOLD_A = 0, Z_FOLD_B = FOLD_CTR_WORDS, Z_ALLOC = 2 * FOLD_CTR_WORDS, Z_WORDS = 2 * FOLD_CTR_WORDS + 16 };
+enum {
+    Z_FOLD_A = 0,
+    Z_FOLD_B = FOLD_CTR_WORDS,
+    Z_FOLD_C = 2 * FOLD_CTR_WORDS,   // the fp32 fallback of edge_mlp_bwd16_kernel
+    Z_ALLOC = 3 * FOLD_CTR_WORDS,    // [0] reverse-list space, [1] extra (point, segment) pairs
+    Z_GMAX = Z_ALLOC + 2,            // bits of max |dL/dy . LReLU'| (bwd_point -> edge_mlp_bwd16)
+    Z_GUARD = Z_ALLOC + 3,           // raised by edge_mlp_bwd16_kernel when an operand leaves the fp16 range
+    Z_WORDS = 3 * FOLD_CTR_WORDS + 16
+};
 
 struct FoldBufs {
     double *rec, *folded;
@@ -234,16 +242,19 @@ extern "C" int dgcnn_edgeconv_bwd(const dgcnn_edgeconv_desc *d, const float *x, 
         return 1;
     const FoldSet fsa{w.fa.rec, w.fa.folded, w.zero + Z_FOLD_A}, fsb{w.fb.rec, w.fb.folded, w.zero + Z_FOLD_B};
     if (d->n_stage == 1) {
-        launch_bwd_point(gy, s.usel, s.stats1, d->slope, P, E, d->training, fsa, g->gbn1_w, g->gbn1_b, w.cc1, st);
+        launch_bwd_point(gy, s.usel, s.stats1, d->slope, P, E, d->training, fsa, g->gbn1_w, g->gbn1_b, w.cc1, nullptr, st);
         if (launch_edge_bwd(s.TP, s.TQ, d->B, N, k, s.stats1, w.cc1, d->slope, gy, y, s.hitj, s.usum, nullptr, nullptr,
                             w.rowptr, w.indeg, w.segbase, w.pcnt, w.rev, w.zero + Z_ALLOC, w.extra, w.hits, w.G, w.part0,
                             w.partx, w.dR, w.dD, st))
             return 1;
     } else {
-        launch_bwd_point(gy, s.usel, s.stats2, d->slope, P, E, d->training, fsa, g->gbn2_w, g->gbn2_b, w.cc2, st);
+        launch_bwd_point(gy, s.usel, s.stats2, d->slope, P, E, d->training, fsa, g->gbn2_w, g->gbn2_b, w.cc2,
+                         reinterpret_cast<unsigned *>(w.zero + Z_GMAX), st);
         const BnBackwardSums fin1{E, d->training, g->gbn1_w, g->gbn1_b, w.cc1};
+        const FoldSet fsc{w.fb.rec, w.fb.folded, w.zero + Z_FOLD_C};
         launch_edge_mlp_bwd(s.TP, s.TQ, idx, N, k, P, s.stats1, s.stats2, w.cc2, d->w2, d->slope, d->training, gy, y,
-                            s.hitj, w.dv1, w.dvsum, w.dw2_partial, fsb, fin1, st);
+                            s.hitj, reinterpret_cast<const unsigned *>(w.zero + Z_GMAX), w.dv1, w.dvsum, w.dw2_partial, fsb,
+                            fsc, fin1, w.zero + Z_GUARD, st);
         launch_sum_partials(w.dw2_partial, mlp_grid(P), EC * EC, g->gw2, st);
         if (launch_edge_bwd(s.TP, s.TQ, d->B, N, k, s.stats1, w.cc1, d->slope, gy, y, nullptr, s.usum, w.dv1, w.dvsum,
                             w.rowptr, w.indeg, w.segbase, w.pcnt, w.rev, w.zero + Z_ALLOC, w.extra, nullptr, nullptr,
