@@ -161,8 +161,8 @@ class DGCNN(nn.Module):
                             # (one [B, emb] x [emb, 512] product per batch element + a 192-wide per-point GEMM:
                             # 84 % fewer FLOPs than the 1216-wide one)
                             w7 = self.conv7[0].weight.squeeze(-1)
-                            u7 = ops.linear_rows(cat.reshape(P, 192), w7[:, emb:]).view(B, N, -1) + F.linear(g, w7[:, :emb])
-                            z = ops.bn_lrelu_rows(u7.reshape(P, -1), self.bn7, self.training, NEG_SLOPE)
+                            u7 = ops.linear_rows(cat.reshape(P, 192), w7[:, emb:], F.linear(g.view(B, emb), w7[:, :emb]), N)
+                            z = ops.bn_lrelu_rows(u7, self.bn7, self.training, NEG_SLOPE)
                             if depth == 8:
                                 out = ops.from_point_major_autograd(z.view(B, N, -1))
                             else:

@@ -370,26 +370,75 @@ def rows_wgrad(a, b):
     return dw
 
 
+def rows_gemm(x, w, add=None, rows_per_add=0):
+    """x [P, K] . w [N, K]^T (+ add[row // rows_per_add]) -> [P, N] on the fp16 matrix cores with split operands
+    (dgcnn_rows_gemm; fp32 in, fp32 out).  x and w may be views with a row stride; K a multiple of 32."""
+    _lib.require_device(x, "x")
+    _lib.require_device(w, "w")
+    if x.dtype != torch.float32 or w.dtype != torch.float32:
+        raise TypeError("rows_gemm needs float32 operands")
+    if x.stride(1) != 1 or x.stride(0) % 4 or x.data_ptr() % 16:
+        x = x.contiguous()
+    if w.stride(1) != 1 or w.stride(0) % 4 or w.data_ptr() % 16:
+        w = w.contiguous()
+    P, K = x.shape
+    N = w.shape[0]
+    if w.shape[1] != K:
+        raise ValueError("x [P, K] and w [N, K] disagree on K")
+    if add is not None:
+        add = add.contiguous()
+        if add.shape[1] != N or add.shape[0] * rows_per_add < P:
+            raise ValueError("add must be [ceil(P / rows_per_add), N]")
+    lib = _lib.load()
+    y = torch.empty((P, N), dtype=torch.float32, device=x.device)
+    ws_bytes = lib.dgcnn_rows_gemm_workspace_bytes(P, K, N)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x.device)
+    _lib.check(lib.dgcnn_rows_gemm(_lib.ptr(x), x.stride(0), _lib.ptr(w), w.stride(0), P, K, N,
+                                   _lib.ptr(add) if add is not None else None, int(rows_per_add), _lib.ptr(y), N, _lib.ptr(ws),
+                                   ws_bytes, _lib.stream_ptr(x.device)), "dgcnn_rows_gemm")
+    return y
+
+
+def _gemm_ok(K):
+    return K % 32 == 0
+
+
 class _LinearRows(torch.autograd.Function):
-    """y = x W^T on point-major rows (a 1x1 Conv1d without bias, model.py:132-141): forward and dL/dx are plain
-    library GEMMs; dL/dW, a contraction over the points with a small output, goes through rows_wgrad."""
+    """y = x W^T (+ add[b] on the rows of batch element b) on point-major rows (a 1x1 Conv1d without bias,
+    model.py:132-141): forward and dL/dx through dgcnn_rows_gemm (fp16 matrix cores, split operands); dL/dW, a
+    contraction over the points with a small output, through rows_wgrad.  (A contraction length that is not a multiple of
+    32 -- conv9's five classes in dL/dx -- falls to the library product.)"""
 
     @staticmethod
-    def forward(ctx, x, w):
+    def forward(ctx, x, w, add, rows_per_add):
         ctx.save_for_backward(x, w)
-        return torch.mm(x, w.t())
+        ctx.rows_per_add = rows_per_add
+        ctx.has_add = add is not None
+        if _gemm_ok(x.shape[1]):
+            return rows_gemm(x.detach(), w.detach(), add.detach() if add is not None else None, rows_per_add)
+        y = torch.mm(x, w.t())
+        if add is not None:
+            y = (y.view(add.shape[0], rows_per_add, -1) + add.unsqueeze(1)).view(y.shape)
+        return y
 
     @staticmethod
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
-        gx = torch.mm(gy, w) if ctx.needs_input_grad[0] else None
-        gw = rows_wgrad(gy, x) if ctx.needs_input_grad[1] else None
-        return gx, gw
+        gy = gy.contiguous()
+        gx = gw = gadd = None
+        if ctx.needs_input_grad[0]:
+            gx = rows_gemm(gy, w.detach().t().contiguous()) if _gemm_ok(gy.shape[1]) else torch.mm(gy, w)
+        if ctx.needs_input_grad[1]:
+            gw = rows_wgrad(gy, x)
+        if ctx.has_add and ctx.needs_input_grad[2]:
+            gadd = gy.view(-1, ctx.rows_per_add, gy.shape[1]).sum(1)
+        return gx, gw, gadd, None
 
 
-def linear_rows(x, w):
-    """x [P, C_in] point-major rows, w [C_out, C_in] -> [P, C_out]."""
-    return _LinearRows.apply(x, w)
+def linear_rows(x, w, add=None, rows_per_add=0):
+    """x [P, C_in] point-major rows, w [C_out, C_in] -> [P, C_out]; add [B, C_out] (optional) is added to the
+    rows_per_add rows of each batch element."""
+    return _LinearRows.apply(x, w, add, int(rows_per_add))
 
 
 class _EmbedMax(torch.autograd.Function):
@@ -410,7 +459,7 @@ class _EmbedMax(torch.autograd.Function):
         lib = _lib.load()
         dev = cat.device
         wd = w.detach()
-        u = torch.mm(cat.detach(), wd.t())                                   # plain library GEMM
+        u = rows_gemm(cat.detach(), wd) if _gemm_ok(F_) else torch.mm(cat.detach(), wd.t())
         wc, bc = weight.detach().contiguous(), bias.detach().contiguous()
         bn = _bn_struct(wc, bc, rmean, rvar)
         g = torch.empty((B, C), dtype=torch.float32, device=dev)
@@ -452,7 +501,11 @@ class _EmbedMax(torch.autograd.Function):
         dw = (s.unsqueeze(2) * win_rows).sum(0)                                              # [C, F], fixed order
         if training:
             wb = wd * coef_b.unsqueeze(1)                                                    # diag(B) W
-            dcat = torch.addmm(torch.mv(wd.t(), coef_a), catd, torch.mm(wd.t(), wb))         # 1 (A W)^T + cat M
+            m = torch.mm(wd.t(), wb)                                                         # M = W^T diag(B) W (symmetric)
+            if _gemm_ok(F_):
+                dcat = rows_gemm(catd, m, torch.mv(wd.t(), coef_a).unsqueeze(0), P)          # 1 (A W)^T + cat M
+            else:
+                dcat = torch.addmm(torch.mv(wd.t(), coef_a), catd, m)
             dw.addmm_(wb, rows_wgrad(catd, catd))                                            # + diag(B) W (cat^T cat)
             dw.addr_(coef_a, catd.sum(0))                                                    # + A (sum cat)^T
         else:

@@ -165,6 +165,16 @@ size_t dgcnn_rows_wgrad_workspace_bytes(int M, int N, int P);
 int dgcnn_rows_wgrad(const float *a, int lda, int M, const float *b, int ldb, int N, int P, float *dw, void *workspace,
                      size_t workspace_bytes, void *stream);
 
+/* A 1x1 convolution on point-major rows, y[P][N] = x[P][K] . w[N][K]^T (+ add[row / rows_per_add][N] when add != NULL:
+ * conv7's share of the pooled feature, one row per batch element, model.py:179-184): the forward and input-gradient
+ * products of conv6 .. conv8 (model.py:172, :184, :187; for dL/dx pass w = W^T).  fp32 in / fp32 out on the fp16 matrix
+ * cores with both operands split in two halves at an exact power-of-two scale (three MFMAs per step, fp32 accumulate;
+ * operand error 2^-23 relative) -- see head_gemm.hip.  x rows have leading dimension ldx, w rows ldw, y rows ldy; K a
+ * multiple of 32, ldx and ldw multiples of 4, x and w 16-byte aligned. */
+size_t dgcnn_rows_gemm_workspace_bytes(int P, int K, int N);
+int dgcnn_rows_gemm(const float *x, int ldx, const float *w, int ldw, int P, int K, int N, const float *add,
+                    int rows_per_add, float *y, int ldy, void *workspace, size_t workspace_bytes, void *stream);
+
 /* Backward of conv6 -> bn6 -> LeakyReLU -> max without the dense [B*N][C] gradient (model.py:172-175; host side in
  * ops.py, _EmbedMax).  With u = cat . W^T the BatchNorm mean terms of dL/du are affine in u, dL/du[p][c] = A_c +
  * B_c u[p][c] + (s[b][c] at the winning point), so the backward needs 192-wide library products only.
