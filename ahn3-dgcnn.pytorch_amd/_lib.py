@@ -65,10 +65,11 @@ SIGNATURES = {
     "dgcnn_bn_lrelu_max_bwd": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_int, _c_int, _c_f, _c_vp, _c_vp,
                                         _c_vp, _c_vp, _c_sz, _c_vp]),
     "dgcnn_rows_wgrad_workspace_bytes": (_c_sz, [_c_int, _c_int, _c_int]),
-    "dgcnn_rows_wgrad": (_c_int, [_c_vp, _c_int, _c_int, _c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_sz, _c_vp]),
-    "dgcnn_rows_gemm_workspace_bytes": (_c_sz, [_c_int, _c_int, _c_int]),
-    "dgcnn_rows_gemm": (_c_int, [_c_vp, _c_int, _c_vp, _c_int, _c_int, _c_int, _c_int, _c_vp, _c_int, _c_vp, _c_int, _c_vp,
-                                 _c_sz, _c_vp]),
+    "dgcnn_rows_wgrad": (_c_int, [_c_vp, _c_int, _c_int, _c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_sz,
+                                  _c_vp]),
+    "dgcnn_rows_gemm": (_c_int, [_c_vp, _c_int, _c_vp, _c_int, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_int, _c_vp,
+                                 _c_int, _c_vp]),
+    "dgcnn_rows_absmax": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp]),
     "dgcnn_embed_max_bwd_prepare": (_c_int, [_c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_int, _c_int, _c_f, _c_vp, _c_vp, _c_vp,
                                              _c_vp, _c_vp, _c_vp]),
     "dgcnn_embed_max_bwd_scatter": (_c_int, [_c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_int, _c_int, _c_vp, _c_vp]),

@@ -5,6 +5,8 @@
 // kernels are slow in this layout (945 + 689 us per layer at P = 56 000, C = 1024).
 //
 // Same statistics discipline as the EdgeConv kernels: fp64 partial sums, fixed reduction order.
+#include <stdlib.h>
+
 #include "edge_kernels.h"
 
 namespace dgcnn {
@@ -564,6 +566,26 @@ __global__ __launch_bounds__(256) void rows_wgrad_kernel(const float *__restrict
     }
 }
 
+int dgcnn_rows_wgrad16_launch(const float *a, int lda, int M, const float *b, int ldb, int Nn, int P, int chunk, float *partial,
+                              const unsigned *amax_a, const unsigned *amax_b, unsigned *scratch, hipStream_t st);  // head_gemm.hip
+
+// the fp16-matrix-core product needs 16-byte row pieces of both operands and whole 16-point MFMA steps per stage
+static bool rows_wgrad_fast(const float *a, int lda, int M, const float *b, int ldb, int Nn)
+{
+    static const int off = getenv("DGCNN_WGRAD_F32") ? atoi(getenv("DGCNN_WGRAD_F32")) : 0;  // experiments / tests
+    return !off && (M & 3) == 0 && (Nn & 3) == 0 && (lda & 3) == 0 && (ldb & 3) == 0 && ((uintptr_t)a & 15) == 0 &&
+           ((uintptr_t)b & 15) == 0 && M >= 32 && Nn >= 32;
+}
+static int rows_wgrad16_chunks(int M, int Nn, int P)
+{
+    const int tiles = ceil_div(M, 128) * ceil_div(Nn, 128);
+    int chunks = 768 / tiles;  // about three workgroups per CU
+    if (chunks < 8) chunks = 8;
+    const int most = ceil_div(P, 128);
+    if (chunks > most) chunks = most;
+    return chunks < 1 ? 1 : chunks;
+}
+
 static int rows_wgrad_chunks(int M, int Nn, int P)
 {
     const int tiles = ceil_div(M, RW_MT * 32) * ceil_div(Nn, RW_NT * 32);
@@ -713,11 +735,13 @@ extern "C" int dgcnn_embed_max_bwd_scatter(const int32_t *arg, const float *s, c
 extern "C" size_t dgcnn_rows_wgrad_workspace_bytes(int M, int Nn, int P)
 {
     if (M <= 0 || Nn <= 0 || P <= 0) return 0;
-    return align_up((size_t)rows_wgrad_chunks(M, Nn, P) * M * Nn * sizeof(float), 256);
+    const int c0 = rows_wgrad_chunks(M, Nn, P), c1 = rows_wgrad16_chunks(M, Nn, P);
+    return 256 + align_up((size_t)(c0 > c1 ? c0 : c1) * M * Nn * sizeof(float), 256);
 }
 
-extern "C" int dgcnn_rows_wgrad(const float *a, int lda, int M, const float *b, int ldb, int Nn, int P, float *dw,
-                                void *workspace, size_t workspace_bytes, void *stream)
+extern "C" int dgcnn_rows_wgrad(const float *a, int lda, int M, const float *b, int ldb, int Nn, int P,
+                                const uint32_t *amax_a, const uint32_t *amax_b, float *dw, void *workspace,
+                                size_t workspace_bytes, void *stream)
 {
     DG_REQUIRE(a && b && dw && workspace, "dgcnn_rows_wgrad: null pointer");
     DG_REQUIRE(M > 0 && Nn > 0 && P > 0 && lda >= M && ldb >= Nn, "dgcnn_rows_wgrad: bad shape M=%d N=%d P=%d lda=%d ldb=%d", M,
@@ -725,6 +749,16 @@ extern "C" int dgcnn_rows_wgrad(const float *a, int lda, int M, const float *b, 
     DG_REQUIRE((size_t)M * Nn < ((size_t)1 << 31), "dgcnn_rows_wgrad: output too large");
     DG_REQUIRE(workspace_bytes >= dgcnn_rows_wgrad_workspace_bytes(M, Nn, P), "dgcnn_rows_wgrad: workspace too small");
     hipStream_t st = (hipStream_t)stream;
+    if (rows_wgrad_fast(a, lda, M, b, ldb, Nn)) {
+        const int chunks16 = rows_wgrad16_chunks(M, Nn, P);
+        const int chunk16 = (ceil_div(P, chunks16) + 31) & ~31;  // whole stages of 32 points
+        if (dgcnn_rows_wgrad16_launch(a, lda, M, b, ldb, Nn, P, chunk16, (float *)((char *)workspace + 256), amax_a, amax_b,
+                                      (unsigned *)workspace, st))
+            DG_FAIL("dgcnn_rows_wgrad: hipMemsetAsync failed");
+        launch_sum_partials((const float *)((char *)workspace + 256), ceil_div(P, chunk16), M * Nn, dw, st);
+        DG_CHECK_LAUNCH("dgcnn_rows_wgrad");
+        return 0;
+    }
     const int chunks = rows_wgrad_chunks(M, Nn, P);
     const int chunk = ceil_div(P, chunks);
     const int tn = ceil_div(Nn, RW_NT * 32), tm = ceil_div(M, RW_MT * 32);
@@ -733,11 +767,11 @@ extern "C" int dgcnn_rows_wgrad(const float *a, int lda, int M, const float *b, 
     const dim3 grid((unsigned)align_up((size_t)tm * tn * ceil_div(P, chunk), 8));
     if (vec)
         hipLaunchKernelGGL(rows_wgrad_kernel<true>, grid, dim3(256), 0, st, a, lda, M, b, ldb, Nn, P, chunk, tn,
-                           (float *)workspace);
+                           (float *)((char *)workspace + 256));
     else
         hipLaunchKernelGGL(rows_wgrad_kernel<false>, grid, dim3(256), 0, st, a, lda, M, b, ldb, Nn, P, chunk, tn,
-                           (float *)workspace);
-    launch_sum_partials((const float *)workspace, ceil_div(P, chunk), M * Nn, dw, st);
+                           (float *)((char *)workspace + 256));
+    launch_sum_partials((const float *)((char *)workspace + 256), ceil_div(P, chunk), M * Nn, dw, st);
     DG_CHECK_LAUNCH("dgcnn_rows_wgrad");
     return 0;
 }

@@ -109,7 +109,8 @@ __device__ __forceinline__ void stage_store(const StageRegs &r, float s, _Float1
 // y = x . w^T (+ add[row / rows_per_add][col]);  K a multiple of 32, ldx / ldw multiples of 4, 16-byte aligned bases
 template <bool HAS_ADD>
 __global__ __launch_bounds__(256) void rows_gemm16_kernel(const float *__restrict__ X, int ldx, const float *__restrict__ W,
-                                                          int ldw, int P, int K, int N, const unsigned *__restrict__ amax,
+                                                          int ldw, int P, int K, int N, const unsigned *__restrict__ amax_x,
+                                                          const unsigned *__restrict__ amax_w,
                                                           const float *__restrict__ add, int rows_per_add,
                                                           float *__restrict__ Y, int ldy, int ncb)
 {
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256) void rows_gemm16_kernel(const float *__restric
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, i32 = lane & 31;
     const int cb = (int)blockIdx.x % ncb, rb = (int)blockIdx.x / ncb;  // column blocks of a row block are neighbours
     const int row0 = rb * GM, col0 = cb * GN;
-    const float sx = scale_to(__uint_as_float(amax[0]), 14), sw = scale_to(__uint_as_float(amax[1]), 14);
+    const float sx = scale_to(__uint_as_float(*amax_x), 14), sw = scale_to(__uint_as_float(*amax_w), 14);
 
     f32x16 acc[4];
 #pragma unroll
@@ -169,41 +170,175 @@ __global__ __launch_bounds__(256) void rows_gemm16_kernel(const float *__restric
     }
 }
 
+// ---- weight gradient of a 1x1 convolution on point-major rows: dW[M][Nn] = sum_p A[p][m] B[p][n] --------------------
+// (A = dL/d(conv output) [P][M], B = the conv input [P][Nn]; model.py:172-187 backward).  The contraction runs over the
+// points, so both MFMA operands need runs of consecutive POINTS for a fixed column: a stage of 32 points is loaded in
+// 16-byte row pieces (thread = 4 columns x 4 points), split, and written to LDS TRANSPOSED as fp16 planes [column][point]
+// (one 8-byte write per column and plane), from where the operands are 16-byte reads.  Workgroup = one 128 x 128 tile of
+// dW over one chunk of the points (wave = a 64 x 64 quadrant: 12 MFMAs per 16 points against 8 ds_read_b128); partial
+// tiles are added in chunk order by sum_partials_kernel (fixed association).  Same operand scaling and splitting as
+// rows_gemm16_kernel.  Workgroups are dealt round-robin over the 8 XCDs: the grid index is remapped so that the tiles of
+// one chunk, which read the same rows, run on ONE XCD and share its L2.
+constexpr int WK = 32;          // points per stage
+constexpr int WSTR = WK + 8;    // halves per LDS row
+
+struct WStage {
+    float4 v[4];  // v[i] = row p0 + 4 pq + i, columns c0 + 4 cq .. + 3
+};
+__device__ __forceinline__ void wstage_load(const float *__restrict__ src, int ld, int ncols, int c0, int p0, int pend,
+                                            WStage &r)
+{
+    const int cq = threadIdx.x & 31, pq = threadIdx.x >> 5;
+    const int col = c0 + 4 * cq < ncols ? c0 + 4 * cq : 0;  // columns past the matrix: any valid address (never stored)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int p = p0 + 4 * pq + i;
+        const float4 v = *reinterpret_cast<const float4 *>(src + (size_t)(p < pend ? p : pend - 1) * ld + col);
+        r.v[i] = p < pend ? v : float4{0.0f, 0.0f, 0.0f, 0.0f};  // points past the chunk add nothing
+    }
+}
+__device__ __forceinline__ void wstage_store(const WStage &r, float s, _Float16 (*hi)[WSTR], _Float16 (*lo)[WSTR])
+{
+    const int cq = threadIdx.x & 31, pq = threadIdx.x >> 5;
+    const float4 t[4] = {float4{r.v[0].x, r.v[1].x, r.v[2].x, r.v[3].x}, float4{r.v[0].y, r.v[1].y, r.v[2].y, r.v[3].y},
+                         float4{r.v[0].z, r.v[1].z, r.v[2].z, r.v[3].z}, float4{r.v[0].w, r.v[1].w, r.v[2].w, r.v[3].w}};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        u32x2 h, l;
+        split4(t[c], s, h, l);
+        *reinterpret_cast<u32x2 *>(&hi[4 * cq + c][4 * pq]) = h;
+        *reinterpret_cast<u32x2 *>(&lo[4 * cq + c][4 * pq]) = l;
+    }
+}
+
+__global__ __launch_bounds__(256) void rows_wgrad16_kernel(const float *__restrict__ A, int lda, int M,
+                                                           const float *__restrict__ Bm, int ldb, int Nn, int P, int chunk,
+                                                           int ntiles_n, const unsigned *__restrict__ amax_a,
+                                                           const unsigned *__restrict__ amax_b, float *__restrict__ partial)
+{
+    __shared__ __attribute__((aligned(16))) _Float16 ah[128][WSTR], al[128][WSTR], bh[128][WSTR], bl[128][WSTR];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, i32 = lane & 31;
+    const int tiles = ntiles_n * ((M + 127) / 128);
+    const int v = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);  // gridDim.x is a multiple of 8
+    const int cidx = v / tiles, tile = v - cidx * tiles;
+    if (cidx * chunk >= P) return;  // padding workgroups
+    const int tm = tile / ntiles_n, tn = tile - tm * ntiles_n;
+    const int m0 = tm * 128, n0 = tn * 128;
+    const int pbeg = cidx * chunk, pend = pbeg + chunk < P ? pbeg + chunk : P;
+    const float sa = scale_to(__uint_as_float(*amax_a), 14), sb = scale_to(__uint_as_float(*amax_b), 14);
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a_ = 0; a_ < 2; ++a_)
+#pragma unroll
+        for (int b_ = 0; b_ < 2; ++b_)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a_][b_][r] = 0.0f;
+
+    WStage ra, rb;
+    wstage_load(A, lda, M, m0, pbeg, pend, ra);
+    wstage_load(Bm, ldb, Nn, n0, pbeg, pend, rb);
+    for (int p0 = pbeg; p0 < pend; p0 += WK) {
+        __syncthreads();
+        wstage_store(ra, sa, ah, al);
+        wstage_store(rb, sb, bh, bl);
+        __syncthreads();
+        if (p0 + WK < pend) {
+            wstage_load(A, lda, M, m0, p0 + WK, pend, ra);
+            wstage_load(Bm, ldb, Nn, n0, p0 + WK, pend, rb);
+        }
+#pragma unroll
+        for (int s = 0; s < WK / 16; ++s) {
+            half8 xhi[2], xlo[2], yhi[2], ylo[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                xhi[t] = *reinterpret_cast<const half8 *>(&ah[wm + t * 32 + i32][16 * s + 8 * h]);
+                xlo[t] = *reinterpret_cast<const half8 *>(&al[wm + t * 32 + i32][16 * s + 8 * h]);
+                yhi[t] = *reinterpret_cast<const half8 *>(&bh[wn + t * 32 + i32][16 * s + 8 * h]);
+                ylo[t] = *reinterpret_cast<const half8 *>(&bl[wn + t * 32 + i32][16 * s + 8 * h]);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xhi[mt], yhi[nt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xhi[mt], ylo[nt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xlo[mt], yhi[nt], acc[mt][nt], 0, 0, 0);
+                }
+        }
+    }
+    const float un = 1.0f / (sa * sb);
+    float *out = partial + (size_t)cidx * M * Nn;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int n = n0 + wn + nt * 32 + i32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm + mt * 32 + mfma32_row(r, h);
+                if (m < M && n < Nn) out[(size_t)m * Nn + n] = acc[mt][nt][r] * un;
+            }
+        }
+}
+
 }  // namespace dgcnn
 
 using namespace dgcnn;
 
-extern "C" size_t dgcnn_rows_gemm_workspace_bytes(int P, int K, int N)
+static void launch_absmax(const float *x, int ld, int rows, int cols, unsigned *out, hipStream_t st)
 {
-    (void)P, (void)K, (void)N;
-    return 256;  // the two operand maxima
+    int g = ceil_div((int)(((size_t)rows * cols / 4 + 255) / 256), 8);
+    g = g > 2048 ? 2048 : (g < 1 ? 1 : g);
+    hipLaunchKernelGGL(rows_absmax_kernel, dim3(g), dim3(256), 0, st, x, ld, rows, cols, out);
 }
 
-extern "C" int dgcnn_rows_gemm(const float *x, int ldx, const float *w, int ldw, int P, int K, int N, const float *add,
-                               int rows_per_add, float *y, int ldy, void *workspace, size_t workspace_bytes, void *stream)
+extern "C" int dgcnn_rows_absmax(const float *x, int ld, int rows, int cols, uint32_t *amax, void *stream)
 {
-    DG_REQUIRE(x && w && y && workspace, "dgcnn_rows_gemm: null pointer");
+    DG_REQUIRE(x && amax, "dgcnn_rows_absmax: null pointer");
+    DG_REQUIRE(rows > 0 && cols > 0 && ld >= cols, "dgcnn_rows_absmax: bad shape rows=%d cols=%d ld=%d", rows, cols, ld);
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(amax, 0, 4, st) != hipSuccess) DG_FAIL("dgcnn_rows_absmax: hipMemsetAsync failed");
+    launch_absmax(x, ld, rows, cols, amax, st);
+    DG_CHECK_LAUNCH("dgcnn_rows_absmax");
+    return 0;
+}
+
+extern "C" int dgcnn_rows_gemm(const float *x, int ldx, const float *w, int ldw, int P, int K, int N, const uint32_t *amax_x,
+                               const uint32_t *amax_w, const float *add, int rows_per_add, float *y, int ldy, void *stream)
+{
+    DG_REQUIRE(x && w && y && amax_x && amax_w, "dgcnn_rows_gemm: null pointer");
     DG_REQUIRE(P > 0 && K > 0 && N > 0 && ldx >= K && ldw >= K && ldy >= N, "dgcnn_rows_gemm: bad shape P=%d K=%d N=%d", P, K, N);
     DG_REQUIRE((K & 31) == 0 && (ldx & 3) == 0 && (ldw & 3) == 0, "dgcnn_rows_gemm: K=%d must be a multiple of 32, ldx / ldw of 4", K);
     DG_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0, "dgcnn_rows_gemm: operands must be 16-byte aligned");
     DG_REQUIRE(!add || rows_per_add > 0, "dgcnn_rows_gemm: rows_per_add must be positive");
-    DG_REQUIRE(workspace_bytes >= 256, "dgcnn_rows_gemm: workspace too small");
     hipStream_t st = (hipStream_t)stream;
-    unsigned *amax = (unsigned *)workspace;
-    if (hipMemsetAsync(amax, 0, 16, st) != hipSuccess) DG_FAIL("dgcnn_rows_gemm: hipMemsetAsync failed");
-    int gx = ceil_div((int)(((size_t)P * K / 4 + 255) / 256), 8);
-    gx = gx > 2048 ? 2048 : (gx < 1 ? 1 : gx);
-    hipLaunchKernelGGL(rows_absmax_kernel, dim3(gx), dim3(256), 0, st, x, ldx, P, K, amax);
-    int gw = ceil_div((int)(((size_t)N * K / 4 + 255) / 256), 8);
-    gw = gw > 256 ? 256 : (gw < 1 ? 1 : gw);
-    hipLaunchKernelGGL(rows_absmax_kernel, dim3(gw), dim3(256), 0, st, w, ldw, N, K, amax + 1);
     const int ncb = ceil_div(N, GN), nrb = ceil_div(P, GM);
     if (add)
-        hipLaunchKernelGGL(rows_gemm16_kernel<true>, dim3(ncb * nrb), dim3(256), 0, st, x, ldx, w, ldw, P, K, N, amax, add,
-                           rows_per_add, y, ldy, ncb);
+        hipLaunchKernelGGL(rows_gemm16_kernel<true>, dim3(ncb * nrb), dim3(256), 0, st, x, ldx, w, ldw, P, K, N, amax_x, amax_w,
+                           add, rows_per_add, y, ldy, ncb);
     else
-        hipLaunchKernelGGL(rows_gemm16_kernel<false>, dim3(ncb * nrb), dim3(256), 0, st, x, ldx, w, ldw, P, K, N, amax, add,
-                           rows_per_add, y, ldy, ncb);
+        hipLaunchKernelGGL(rows_gemm16_kernel<false>, dim3(ncb * nrb), dim3(256), 0, st, x, ldx, w, ldw, P, K, N, amax_x, amax_w,
+                           add, rows_per_add, y, ldy, ncb);
     DG_CHECK_LAUNCH("dgcnn_rows_gemm");
     return 0;
 }
+
+// dgcnn_rows_wgrad's product on the fp16 matrix cores (called from head.hip when the operands allow 16-byte row pieces):
+// partial [chunks][M][Nn] in `partial`; amax_a / amax_b: the operand maxima, or NULL -> found here into scratch[0 / 1]
+namespace dgcnn {
+int dgcnn_rows_wgrad16_launch(const float *a, int lda, int M, const float *b, int ldb, int Nn, int P, int chunk, float *partial,
+                              const unsigned *amax_a, const unsigned *amax_b, unsigned *scratch, hipStream_t st)
+{
+    if (!amax_a || !amax_b) {
+        if (hipMemsetAsync(scratch, 0, 16, st) != hipSuccess) return 1;
+        if (!amax_a) launch_absmax(a, lda, P, M, scratch, st), amax_a = scratch;
+        if (!amax_b) launch_absmax(b, ldb, P, Nn, scratch + 1, st), amax_b = scratch + 1;
+    }
+    const int tn = ceil_div(Nn, 128), tm = ceil_div(M, 128);
+    const dim3 grid((unsigned)align_up((size_t)tm * tn * ceil_div(P, chunk), 8));
+    hipLaunchKernelGGL(rows_wgrad16_kernel, grid, dim3(256), 0, st, a, lda, M, b, ldb, Nn, P, chunk, tn, amax_a, amax_b, partial);
+    return 0;
+}
+}  // namespace dgcnn

@@ -346,9 +346,25 @@ def bn_lrelu_max_rows(x, bn, B, N, training, slope=0.2):
     return g
 
 
-def rows_wgrad(a, b):
+def rows_absmax(x):
+    """one int32 word on the device: the bits of max |x| over a 2-d float32 array (rows may be strided) -- the operand
+    magnitude that rows_gemm / rows_wgrad scale by.  Measure a tensor once, pass the word to every product that uses it."""
+    _lib.require_device(x, "x")
+    if x.dtype != torch.float32 or x.dim() != 2:
+        raise TypeError("rows_absmax needs a 2-d float32 tensor")
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    out = torch.empty((1,), dtype=torch.int32, device=x.device)
+    lib = _lib.load()
+    _lib.check(lib.dgcnn_rows_absmax(_lib.ptr(x), x.stride(0), x.shape[0], x.shape[1], _lib.ptr(out),
+                                     _lib.stream_ptr(x.device)), "dgcnn_rows_absmax")
+    return out
+
+
+def rows_wgrad(a, b, amax_a=None, amax_b=None):
     """sum over the rows p of a[p, :]^T b[p, :]:  a [P, M], b [P, N] (rows may be strided views) -> [M, N].
-    The weight-gradient product of a 1x1 convolution on point-major rows, split over the points (dgcnn_rows_wgrad)."""
+    The weight-gradient product of a 1x1 convolution on point-major rows, split over the points (dgcnn_rows_wgrad);
+    amax_a / amax_b: the operands' rows_absmax words, when already known."""
     _lib.require_device(a, "a")
     _lib.require_device(b, "b")
     if a.dtype != torch.float32 or b.dtype != torch.float32:
@@ -365,14 +381,17 @@ def rows_wgrad(a, b):
     dw = torch.empty((M, N), dtype=torch.float32, device=a.device)
     ws_bytes = lib.dgcnn_rows_wgrad_workspace_bytes(M, N, P)
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=a.device)
-    _lib.check(lib.dgcnn_rows_wgrad(_lib.ptr(a), a.stride(0), M, _lib.ptr(b), b.stride(0), N, P, _lib.ptr(dw), _lib.ptr(ws),
-                                    ws_bytes, _lib.stream_ptr(a.device)), "dgcnn_rows_wgrad")
+    _lib.check(lib.dgcnn_rows_wgrad(_lib.ptr(a), a.stride(0), M, _lib.ptr(b), b.stride(0), N, P,
+                                    _lib.ptr(amax_a) if amax_a is not None else None,
+                                    _lib.ptr(amax_b) if amax_b is not None else None, _lib.ptr(dw), _lib.ptr(ws), ws_bytes,
+                                    _lib.stream_ptr(a.device)), "dgcnn_rows_wgrad")
     return dw
 
 
-def rows_gemm(x, w, add=None, rows_per_add=0):
+def rows_gemm(x, w, add=None, rows_per_add=0, amax_x=None, amax_w=None):
     """x [P, K] . w [N, K]^T (+ add[row // rows_per_add]) -> [P, N] on the fp16 matrix cores with split operands
-    (dgcnn_rows_gemm; fp32 in, fp32 out).  x and w may be views with a row stride; K a multiple of 32."""
+    (dgcnn_rows_gemm; fp32 in, fp32 out).  x and w may be views with a row stride; K a multiple of 32.  amax_x / amax_w:
+    the operands' rows_absmax words, when already known."""
     _lib.require_device(x, "x")
     _lib.require_device(w, "w")
     if x.dtype != torch.float32 or w.dtype != torch.float32:
@@ -389,13 +408,15 @@ def rows_gemm(x, w, add=None, rows_per_add=0):
         add = add.contiguous()
         if add.shape[1] != N or add.shape[0] * rows_per_add < P:
             raise ValueError("add must be [ceil(P / rows_per_add), N]")
+    if amax_x is None:
+        amax_x = rows_absmax(x)
+    if amax_w is None:
+        amax_w = rows_absmax(w)
     lib = _lib.load()
     y = torch.empty((P, N), dtype=torch.float32, device=x.device)
-    ws_bytes = lib.dgcnn_rows_gemm_workspace_bytes(P, K, N)
-    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x.device)
-    _lib.check(lib.dgcnn_rows_gemm(_lib.ptr(x), x.stride(0), _lib.ptr(w), w.stride(0), P, K, N,
-                                   _lib.ptr(add) if add is not None else None, int(rows_per_add), _lib.ptr(y), N, _lib.ptr(ws),
-                                   ws_bytes, _lib.stream_ptr(x.device)), "dgcnn_rows_gemm")
+    _lib.check(lib.dgcnn_rows_gemm(_lib.ptr(x), x.stride(0), _lib.ptr(w), w.stride(0), P, K, N, _lib.ptr(amax_x),
+                                   _lib.ptr(amax_w), _lib.ptr(add) if add is not None else None, int(rows_per_add),
+                                   _lib.ptr(y), N, _lib.stream_ptr(x.device)), "dgcnn_rows_gemm")
     return y
 
 
@@ -411,25 +432,32 @@ class _LinearRows(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, add, rows_per_add):
-        ctx.save_for_backward(x, w)
         ctx.rows_per_add = rows_per_add
         ctx.has_add = add is not None
+        xd, wd = x.detach(), w.detach()
+        # the operand magnitudes: measured once here, used again by the two products of the backward
+        ax, aw = rows_absmax(xd), rows_absmax(wd)
+        ctx.save_for_backward(x, w, ax, aw)
         if _gemm_ok(x.shape[1]):
-            return rows_gemm(x.detach(), w.detach(), add.detach() if add is not None else None, rows_per_add)
-        y = torch.mm(x, w.t())
+            return rows_gemm(xd, wd, add.detach() if add is not None else None, rows_per_add, ax, aw)
+        y = torch.mm(xd, wd.t())
         if add is not None:
-            y = (y.view(add.shape[0], rows_per_add, -1) + add.unsqueeze(1)).view(y.shape)
+            y = (y.view(add.shape[0], rows_per_add, -1) + add.detach().unsqueeze(1)).view(y.shape)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, w = ctx.saved_tensors
+        x, w, ax, aw = ctx.saved_tensors
         gy = gy.contiguous()
+        ag = rows_absmax(gy)
         gx = gw = gadd = None
         if ctx.needs_input_grad[0]:
-            gx = rows_gemm(gy, w.detach().t().contiguous()) if _gemm_ok(gy.shape[1]) else torch.mm(gy, w)
+            if _gemm_ok(gy.shape[1]):
+                gx = rows_gemm(gy, w.detach().t().contiguous(), amax_x=ag, amax_w=aw)   # (max |W^T| = max |W|)
+            else:
+                gx = torch.mm(gy, w)
         if ctx.needs_input_grad[1]:
-            gw = rows_wgrad(gy, x)
+            gw = rows_wgrad(gy, x, ag, ax)
         if ctx.has_add and ctx.needs_input_grad[2]:
             gadd = gy.view(-1, ctx.rows_per_add, gy.shape[1]).sum(1)
         return gx, gw, gadd, None
@@ -459,7 +487,8 @@ class _EmbedMax(torch.autograd.Function):
         lib = _lib.load()
         dev = cat.device
         wd = w.detach()
-        u = rows_gemm(cat.detach(), wd) if _gemm_ok(F_) else torch.mm(cat.detach(), wd.t())
+        ac = rows_absmax(cat.detach())     # max |cat|: this product and the two 192-wide ones of the backward
+        u = rows_gemm(cat.detach(), wd, amax_x=ac) if _gemm_ok(F_) else torch.mm(cat.detach(), wd.t())
         wc, bc = weight.detach().contiguous(), bias.detach().contiguous()
         bn = _bn_struct(wc, bc, rmean, rvar)
         g = torch.empty((B, C), dtype=torch.float32, device=dev)
@@ -471,13 +500,13 @@ class _EmbedMax(torch.autograd.Function):
                                               slope, _lib.ptr(g), _lib.ptr(arg), _lib.ptr(stats), _lib.ptr(ws), ws_bytes,
                                               _lib.stream_ptr(dev)), "dgcnn_bn_lrelu_max_fwd")
         uwin = torch.gather(u.view(B, N, C), 1, arg.long().unsqueeze(1)).squeeze(1).contiguous()   # [B, C]
-        ctx.save_for_backward(cat, w, arg, stats, uwin)
+        ctx.save_for_backward(cat, w, arg, stats, uwin, ac)
         ctx.cfg = (B, N, training, slope)
         return g
 
     @staticmethod
     def backward(ctx, gg):
-        cat, w, arg, stats, uwin = ctx.saved_tensors
+        cat, w, arg, stats, uwin, ac = ctx.saved_tensors
         B, N, training, slope = ctx.cfg
         P, F_ = cat.shape
         C = w.shape[0]
@@ -503,10 +532,10 @@ class _EmbedMax(torch.autograd.Function):
             wb = wd * coef_b.unsqueeze(1)                                                    # diag(B) W
             m = torch.mm(wd.t(), wb)                                                         # M = W^T diag(B) W (symmetric)
             if _gemm_ok(F_):
-                dcat = rows_gemm(catd, m, torch.mv(wd.t(), coef_a).unsqueeze(0), P)          # 1 (A W)^T + cat M
+                dcat = rows_gemm(catd, m, torch.mv(wd.t(), coef_a).unsqueeze(0), P, amax_x=ac)   # 1 (A W)^T + cat M
             else:
                 dcat = torch.addmm(torch.mv(wd.t(), coef_a), catd, m)
-            dw.addmm_(wb, rows_wgrad(catd, catd))                                            # + diag(B) W (cat^T cat)
+            dw.addmm_(wb, rows_wgrad(catd, catd, ac, ac))                                    # + diag(B) W (cat^T cat)
             dw.addr_(coef_a, catd.sum(0))                                                    # + A (sum cat)^T
         else:
             dcat = torch.zeros_like(catd)

@@ -160,20 +160,26 @@ int dgcnn_bn_lrelu_max_bwd(const float *x, const float *gg, const int32_t *arg, 
 
 /* Weight gradient of a 1x1 convolution on point-major rows: dw[M][N] = sum over the P rows of a[p][m] * b[p][n]
  * (a = dL/d(output) rows with leading dimension lda >= M, b = the convolution's input rows, ldb >= N).  The
- * contraction over the points is split across workgroups (fp32 MFMA) and folded in a fixed order. */
+ * contraction over the points is split across workgroups and folded in a fixed order.  With 16-byte aligned rows and
+ * M, N, lda, ldb multiples of 4 it runs on the fp16 matrix cores with split operands, like dgcnn_rows_gemm (amax_a /
+ * amax_b: the operands' dgcnn_rows_absmax words, or NULL to have them found here); otherwise on fp32 MFMA. */
 size_t dgcnn_rows_wgrad_workspace_bytes(int M, int N, int P);
-int dgcnn_rows_wgrad(const float *a, int lda, int M, const float *b, int ldb, int N, int P, float *dw, void *workspace,
-                     size_t workspace_bytes, void *stream);
+int dgcnn_rows_wgrad(const float *a, int lda, int M, const float *b, int ldb, int N, int P, const uint32_t *amax_a,
+                     const uint32_t *amax_b, float *dw, void *workspace, size_t workspace_bytes, void *stream);
 
 /* A 1x1 convolution on point-major rows, y[P][N] = x[P][K] . w[N][K]^T (+ add[row / rows_per_add][N] when add != NULL:
  * conv7's share of the pooled feature, one row per batch element, model.py:179-184): the forward and input-gradient
  * products of conv6 .. conv8 (model.py:172, :184, :187; for dL/dx pass w = W^T).  fp32 in / fp32 out on the fp16 matrix
  * cores with both operands split in two halves at an exact power-of-two scale (three MFMAs per step, fp32 accumulate;
- * operand error 2^-23 relative) -- see head_gemm.hip.  x rows have leading dimension ldx, w rows ldw, y rows ldy; K a
- * multiple of 32, ldx and ldw multiples of 4, x and w 16-byte aligned. */
-size_t dgcnn_rows_gemm_workspace_bytes(int P, int K, int N);
-int dgcnn_rows_gemm(const float *x, int ldx, const float *w, int ldw, int P, int K, int N, const float *add,
-                    int rows_per_add, float *y, int ldy, void *workspace, size_t workspace_bytes, void *stream);
+ * operand error 2^-23 relative) -- see head_gemm.hip.  amax_x / amax_w: the operands' dgcnn_rows_absmax words.  x rows
+ * have leading dimension ldx, w rows ldw, y rows ldy; K a multiple of 32, ldx and ldw multiples of 4, x and w 16-byte
+ * aligned. */
+int dgcnn_rows_gemm(const float *x, int ldx, const float *w, int ldw, int P, int K, int N, const uint32_t *amax_x,
+                    const uint32_t *amax_w, const float *add, int rows_per_add, float *y, int ldy, void *stream);
+/* amax[0] <- the bits of max |x[r][c]| over a [rows][cols] array with leading dimension ld: the operand magnitude the
+ * two products above take their power-of-two scale from.  One word per operand; a tensor used by several products
+ * (dL/dy in the input and weight gradients, a layer's input in forward and weight gradient) is measured once. */
+int dgcnn_rows_absmax(const float *x, int ld, int rows, int cols, uint32_t *amax, void *stream);
 
 /* Backward of conv6 -> bn6 -> LeakyReLU -> max without the dense [B*N][C] gradient (model.py:172-175; host side in
  * ops.py, _EmbedMax).  With u = cat . W^T the BatchNorm mean terms of dL/du are affine in u, dL/du[p][c] = A_c +

@@ -27,3 +27,11 @@ for K, N, what in ((192, 1024, "conv6 fwd"), (192, 512, "conv7 fwd"), (512, 256,
     fl = 2.0 * P * K * N
     print("%-12s P=%d K=%4d N=%4d  rows_gemm %7.1f us (%5.1f TF/s)   torch.mm %7.1f us (%5.1f TF/s)" % (
         what, P, K, N, a, fl / a / 1e6, b, fl / b / 1e6), flush=True)
+
+for M, N, what in ((256, 512, "dW8"), (512, 192, "dW7c"), (192, 192, "cat^T cat")):
+    a = torch.randn(P, M, device=dev) * 1e-5
+    b = torch.randn(P, N, device=dev)
+    t16 = t(lambda: ops.rows_wgrad(a, b))
+    os.environ["DGCNN_WGRAD_F32"] = "1"
+    fl = 2.0 * P * M * N
+    print("%-12s P=%d M=%4d N=%4d  rows_wgrad %7.1f us (%5.1f TF/s)" % (what, P, M, N, t16, fl / t16 / 1e6), flush=True)
