@@ -67,33 +67,56 @@ __global__ __launch_bounds__(256) void colstats_kernel(const float *__restrict__
     }
 }
 
-// sum over the chunks of partial[chunk][2][C] for column c: the four waves of the workgroup take every fourth chunk
-// (independent loads in flight instead of one serial chain of `nchunk` dependent adds), then fold in a fixed order
+// sum over the chunks of partial[chunk][2][C] for column c: the FOLD_W waves of the workgroup take every FOLD_W-th chunk,
+// eight chunks in flight per wave (at B = 32, N = 7000 there are 875 chunks: with four waves and one load in flight the
+// finalize kernels took 77-83 us each), added in chunk order; then the wave sums are added in wave order (fixed
+// association: deterministic)
+constexpr int FOLD_W = 16;
 __device__ __forceinline__ void fold_chunks(const double *__restrict__ partial, int nchunk, int C, int c, bool live,
                                             double (*red)[2][64], double &s0, double &s1)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double a = 0.0, b = 0.0;
-    if (live)
-        for (int g = wave; g < nchunk; g += 4) {
+    if (live) {
+        int g = wave;
+        for (; g + 7 * FOLD_W < nchunk; g += 8 * FOLD_W) {
+            double va[8], vb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                va[u] = partial[((size_t)(g + u * FOLD_W) * 2 + 0) * C + c];
+                vb[u] = partial[((size_t)(g + u * FOLD_W) * 2 + 1) * C + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                a += va[u];
+                b += vb[u];
+            }
+        }
+        for (; g < nchunk; g += FOLD_W) {
             a += partial[((size_t)g * 2 + 0) * C + c];
             b += partial[((size_t)g * 2 + 1) * C + c];
         }
+    }
     red[wave][0][lane] = a;
     red[wave][1][lane] = b;
     __syncthreads();
-    s0 = (red[0][0][lane] + red[1][0][lane]) + (red[2][0][lane] + red[3][0][lane]);
-    s1 = (red[0][1][lane] + red[1][1][lane]) + (red[2][1][lane] + red[3][1][lane]);
+    s0 = 0.0;
+    s1 = 0.0;
+#pragma unroll
+    for (int w = 0; w < FOLD_W; ++w) {
+        s0 += red[w][0][lane];
+        s1 += red[w][1][lane];
+    }
 }
 
 // stats[4][C] = mean, rstd, sc = gamma rstd, sh = beta - mean sc; running statistics updated when training.
 // One workgroup of four waves per 64 columns (lane = column); fixed summation order (deterministic).
-__global__ __launch_bounds__(256) void colstats_finalize_kernel(const double *__restrict__ partial, int nchunk, int P, int C, int training,
+__global__ __launch_bounds__(64 * FOLD_W) void colstats_finalize_kernel(const double *__restrict__ partial, int nchunk, int P, int C, int training,
                                          const float *__restrict__ gamma, const float *__restrict__ beta,
                                          float *__restrict__ rmean, float *__restrict__ rvar, float eps,
                                          float momentum, float *__restrict__ stats)
 {
-    __shared__ double red[4][2][64];
+    __shared__ double red[FOLD_W][2][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     double s = 0.0, ss = 0.0;
     if (training) fold_chunks(partial, nchunk, C, c, c < C, red, s, ss);
@@ -185,10 +208,10 @@ __global__ __launch_bounds__(256) void bn_lrelu_bwd_reduce_kernel(const float *_
 }
 
 // gbeta, ggamma and the two mean terms cc[2][C] (zero in eval mode)
-__global__ __launch_bounds__(256) void bn_bwd_finalize_cols_kernel(const double *__restrict__ partial, int nchunk, int P, int C, int training,
+__global__ __launch_bounds__(64 * FOLD_W) void bn_bwd_finalize_cols_kernel(const double *__restrict__ partial, int nchunk, int P, int C, int training,
                                             float *__restrict__ ggamma, float *__restrict__ gbeta, float *__restrict__ cc)
 {
-    __shared__ double red[4][2][64];
+    __shared__ double red[FOLD_W][2][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     double sb, sg;
     fold_chunks(partial, nchunk, C, c, c < C, red, sb, sg);
@@ -622,7 +645,7 @@ extern "C" int dgcnn_bn_lrelu_fwd(const float *x, int P, int C, const dgcnn_bn_p
     const int nchunk = head_chunks(P);
     if (training)
         hipLaunchKernelGGL(colstats_kernel, dim3(ceil_div(C, HEAD_COLS_PER_BLOCK), nchunk), dim3(256), 0, st, x, P, C, partial);
-    hipLaunchKernelGGL(colstats_finalize_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, st, partial, nchunk, P, C, training,
+    hipLaunchKernelGGL(colstats_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64 * FOLD_W), 0, st, partial, nchunk, P, C, training,
                        bn->weight, bn->bias, bn->running_mean, bn->running_var, eps, momentum, stats);
     const size_t n4 = (size_t)P * C / 4;
     hipLaunchKernelGGL(bn_lrelu_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, x, stats, C, slope, n4, y);
@@ -643,7 +666,7 @@ extern "C" int dgcnn_bn_lrelu_bwd(const float *x, const float *y, const float *g
     float *cc = (float *)((char *)workspace + align_up((size_t)nchunk * 2 * C * sizeof(double), 256));
     hipLaunchKernelGGL(bn_lrelu_bwd_reduce_kernel, dim3(ceil_div(C, HEAD_COLS_PER_BLOCK), nchunk), dim3(256), 0, st, x, y, gy, stats, P, C,
                        slope, partial);
-    hipLaunchKernelGGL(bn_bwd_finalize_cols_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, st, partial, nchunk, P, C,
+    hipLaunchKernelGGL(bn_bwd_finalize_cols_kernel, dim3(ceil_div(C, 64)), dim3(64 * FOLD_W), 0, st, partial, nchunk, P, C,
                        training, gweight, gbias, cc);
     const size_t n4 = (size_t)P * C / 4;
     hipLaunchKernelGGL(bn_lrelu_bwd_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, x, y, gy, stats,
@@ -676,7 +699,7 @@ extern "C" int dgcnn_bn_lrelu_max_fwd(const float *x, int B, int N, int C, const
     const int nchunk = head_chunks(P);
     if (training)
         hipLaunchKernelGGL(colstats_kernel, dim3(ceil_div(C, HEAD_COLS_PER_BLOCK), nchunk), dim3(256), 0, st, x, P, C, partial);
-    hipLaunchKernelGGL(colstats_finalize_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, st, partial, nchunk, P, C, training,
+    hipLaunchKernelGGL(colstats_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64 * FOLD_W), 0, st, partial, nchunk, P, C, training,
                        bn->weight, bn->bias, bn->running_mean, bn->running_var, eps, momentum, stats);
     if (hipMemsetAsync(keys, 0, (size_t)B * C * sizeof(hkey), st) != hipSuccess) DG_FAIL("dgcnn_bn_lrelu_max_fwd: memset failed");
     hipLaunchKernelGGL(colmax_kernel, dim3(ceil_div(C, 64), head_chunks(N), B), dim3(256), 0, st, x, stats, N, C, keys);

@@ -306,6 +306,35 @@ def test_get_graph_feature_backward_is_bit_stable(device):
     assert torch.equal(grads[0], grads[1])
 
 
+def test_two_stage_backward_leaves_the_fp16_range(device):
+    """edge_mlp_bwd16_kernel scales its operands by exact powers of two into the fp16 range and checks the range: an
+    activation beyond +-253.9 in front of the second convolution (here: BatchNorm-1 weights x 400) raises its guard word
+    and the fp32 form of the pass, launched behind it, redoes the work -- the results must not notice."""
+    import copy
+    B, C, N, k = 2, 16, 300, 20
+    base = make_stages(2 * C, 2)
+    with torch.no_grad():
+        base[0][1].weight.mul_(400.0)
+    for seed in range(200):
+        x = torch.randn(B, C, N, generator=torch.Generator().manual_seed(seed))
+        idx = ke.knn_exact(x.numpy(), k)
+        if premax_top2_gap(x, idx, base, True) >= 2e-5:
+            break
+    else:
+        raise AssertionError("no near-tie-free input found")
+    R = cotangent((B, 64, N), tag="edge")
+    y0, gx0, st0 = run_oracle(x, idx, copy.deepcopy(base), True, R)
+    with torch.no_grad():
+        e = torch_ref.edge_features(x, k=k, idx=torch.from_numpy(idx.astype(np.int64)))
+        assert float(copy.deepcopy(base[0]).train()(e).abs().max()) > 260.0      # the range IS left
+    y1, gx1, st1 = run_hip(x, idx, base, True, R, device)
+    np.testing.assert_allclose(y1.numpy(), y0.numpy(), rtol=0, atol=ATOL_FWD * float(y0.abs().max()))
+    for a, b, what in [(gx1, gx0, "grad x")] + [(s1[0].weight.grad.cpu(), s0[0].weight.grad, "grad conv weight %d" % i)
+                                                  for i, (s0, s1) in enumerate(zip(st0, st1))] + \
+                      [(s1[1].weight.grad.cpu(), s0[1].weight.grad, "grad bn weight %d" % i) for i, (s0, s1) in enumerate(zip(st0, st1))]:
+        assert float((a - b).abs().max()) <= RTOL_GRAD * float(b.abs().max()), what
+
+
 def test_single_stage_block_k_above_64(device):
     compare(1, 8, 200, 70, 1, True, device)
 
