@@ -16,6 +16,8 @@
 // operands of the next chunk are in flight (registers) while the current one is multiplied, then split and written to
 // LDS as fp16 planes [row][k] (row stride 40 halves = 20 banks: conflict-free 16-byte reads).  Column blocks of one row
 // block are adjacent in the grid, so the x rows of a row block are re-read from L2, not from HBM.
+#include <stdlib.h>
+
 #include "common.h"
 #include "dgcnn_hip.h"
 
@@ -26,8 +28,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int GM = 128, GN = 128, GK = 32;  // workgroup tile, k chunk
-constexpr int GSTR = GK + 8;                // halves per LDS row
+constexpr int GM = 128, GN = 128;  // workgroup tile; the k chunk GK (32 or 64) is a template parameter: LDS rows hold
+                                   // GK + 8 halves (20 or 36 banks: conflict-free 16-byte reads either way)
 
 // ---- operand magnitude: bits of max |x| over a strided [rows][cols] array (non-negative floats order like their
 // bits; the word is zeroed by a memset node ahead of the kernel)
@@ -81,24 +83,27 @@ __device__ __forceinline__ void split4(const float4 v, float s, u32x2 &hi, u32x2
     lo[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{x[2] - h[2], x[3] - h[3]}, f16x2));
 }
 
-// one 128 x 32 fp32 operand tile: thread t holds float4 number t + 256 i (i < 4): row (t + 256 i) / 8, columns 4 ((t + 256 i) % 8)
+// one 128 x GK fp32 operand tile: thread t holds float4 number t + 256 i (i < GK / 8): row f / (GK / 4), columns 4 (f % (GK / 4))
+template <int GK>
 struct StageRegs {
-    float4 v[4];
+    float4 v[GK / 8];
 };
-__device__ __forceinline__ void stage_load(const float *__restrict__ src, int ld, int row0, int nrows, int k0, StageRegs &r)
+template <int GK>
+__device__ __forceinline__ void stage_load(const float *__restrict__ src, int ld, int row0, int nrows, int k0, StageRegs<GK> &r)
 {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int f = threadIdx.x + 256 * i, row = f >> 3, c = (f & 7) * 4;
+    for (int i = 0; i < GK / 8; ++i) {
+        const int f = threadIdx.x + 256 * i, row = f / (GK / 4), c = (f % (GK / 4)) * 4;
         const int rr = row0 + row < nrows ? row0 + row : nrows - 1;  // clamped: rows past the end are never stored
         r.v[i] = *reinterpret_cast<const float4 *>(src + (size_t)rr * ld + k0 + c);
     }
 }
-__device__ __forceinline__ void stage_store(const StageRegs &r, float s, _Float16 (*hi)[GSTR], _Float16 (*lo)[GSTR])
+template <int GK>
+__device__ __forceinline__ void stage_store(const StageRegs<GK> &r, float s, _Float16 (*hi)[GK + 8], _Float16 (*lo)[GK + 8])
 {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int f = threadIdx.x + 256 * i, row = f >> 3, c = (f & 7) * 4;
+    for (int i = 0; i < GK / 8; ++i) {
+        const int f = threadIdx.x + 256 * i, row = f / (GK / 4), c = (f % (GK / 4)) * 4;
         u32x2 h, l;
         split4(r.v[i], s, h, l);
         *reinterpret_cast<u32x2 *>(&hi[row][c]) = h;
@@ -107,13 +112,14 @@ __device__ __forceinline__ void stage_store(const StageRegs &r, float s, _Float1
 }
 
 // y = x . w^T (+ add[row / rows_per_add][col]);  K a multiple of 32, ldx / ldw multiples of 4, 16-byte aligned bases
-template <bool HAS_ADD>
+template <bool HAS_ADD, int GK>
 __global__ __launch_bounds__(256) void rows_gemm16_kernel(const float *__restrict__ X, int ldx, const float *__restrict__ W,
                                                           int ldw, int P, int K, int N, const unsigned *__restrict__ amax_x,
                                                           const unsigned *__restrict__ amax_w,
                                                           const float *__restrict__ add, int rows_per_add,
                                                           float *__restrict__ Y, int ldy, int ncb)
 {
+    constexpr int GSTR = GK + 8;
     __shared__ __attribute__((aligned(16))) _Float16 xh[GM][GSTR], xl[GM][GSTR], wh[GN][GSTR], wl[GN][GSTR];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, i32 = lane & 31;
     const int cb = (int)blockIdx.x % ncb, rb = (int)blockIdx.x / ncb;  // column blocks of a row block are neighbours
@@ -126,17 +132,17 @@ __global__ __launch_bounds__(256) void rows_gemm16_kernel(const float *__restric
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
 
-    StageRegs rx, rw;
-    stage_load(X, ldx, row0, P, 0, rx);
-    stage_load(W, ldw, col0, N, 0, rw);
+    StageRegs<GK> rx, rw;
+    stage_load<GK>(X, ldx, row0, P, 0, rx);
+    stage_load<GK>(W, ldw, col0, N, 0, rw);
     for (int k0 = 0; k0 < K; k0 += GK) {
         __syncthreads();  // the previous chunk's LDS reads are done
-        stage_store(rx, sx, xh, xl);
-        stage_store(rw, sw, wh, wl);
+        stage_store<GK>(rx, sx, xh, xl);
+        stage_store<GK>(rw, sw, wh, wl);
         __syncthreads();
         if (k0 + GK < K) {  // next chunk in flight during the MFMAs
-            stage_load(X, ldx, row0, P, k0 + GK, rx);
-            stage_load(W, ldw, col0, N, k0 + GK, rw);
+            stage_load<GK>(X, ldx, row0, P, k0 + GK, rx);
+            stage_load<GK>(W, ldw, col0, N, k0 + GK, rw);
         }
 #pragma unroll
         for (int s = 0; s < GK / 16; ++s) {
@@ -315,12 +321,19 @@ extern "C" int dgcnn_rows_gemm(const float *x, int ldx, const float *w, int ldw,
     DG_REQUIRE(!add || rows_per_add > 0, "dgcnn_rows_gemm: rows_per_add must be positive");
     hipStream_t st = (hipStream_t)stream;
     const int ncb = ceil_div(N, GN), nrb = ceil_div(P, GM);
-    if (add)
-        hipLaunchKernelGGL(rows_gemm16_kernel<true>, dim3(ncb * nrb), dim3(256), 0, st, x, ldx, w, ldw, P, K, N, amax_x, amax_w,
-                           add, rows_per_add, y, ldy, ncb);
-    else
-        hipLaunchKernelGGL(rows_gemm16_kernel<false>, dim3(ncb * nrb), dim3(256), 0, st, x, ldx, w, ldw, P, K, N, amax_x, amax_w,
-                           add, rows_per_add, y, ldy, ncb);
+    static const int gk_env = getenv("DGCNN_GEMM_GK") ? atoi(getenv("DGCNN_GEMM_GK")) : 0;  // experiments
+    const bool k64 = gk_env == 64 && (K & 63) == 0;  // (measured: 64-wide chunks halve the barriers but cost a workgroup per CU: 5-15 % slower)
+#define DG_GEMM(ADD_, GK_)                                                                                              \
+    hipLaunchKernelGGL((rows_gemm16_kernel<ADD_, GK_>), dim3(ncb * nrb), dim3(256), 0, st, x, ldx, w, ldw, P, K, N, amax_x, \
+                       amax_w, add, rows_per_add, y, ldy, ncb)
+    if (add) {
+        if (k64) DG_GEMM(true, 64);
+        else DG_GEMM(true, 32);
+    } else {
+        if (k64) DG_GEMM(false, 64);
+        else DG_GEMM(false, 32);
+    }
+#undef DG_GEMM
     DG_CHECK_LAUNCH("dgcnn_rows_gemm");
     return 0;
 }

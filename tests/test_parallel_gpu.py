@@ -69,7 +69,7 @@ def test_two_rank_product_step_matches_shardwise_run(tmp_path, device):
         losses.append(float(loss))
     want = want / WORLD
     scale = float(want.abs().max())
-    assert float((got["reduced"] - want).abs().max()) <= 2e-5 * scale     # (the backward's sum order is not fixed)
+    assert float((got["reduced"] - want).abs().max()) <= 1e-6 * scale     # (deterministic kernels; the exchange adds two ranks)
     assert abs(got["loss"] - losses[0]) <= 1e-6 * max(1.0, abs(losses[0]))
     torch.testing.assert_close(got["rm1"], (rms[0] + rms[1]) / 2, rtol=1e-5, atol=1e-6)
     # one FlatAdam step on the averaged gradient from the same initial weights
@@ -106,6 +106,24 @@ def test_bench_starts_its_own_ranks_for_the_train_workload():
     assert out["config"]["global_batch"] == 4 and out["config"]["batch_per_gpu"] == 2
     assert out["allreduce"]["bytes"] == 980864 * 4 and out["allreduce"]["ms"] > 0
     assert out["value"] > 0 and out["unit"] == "points/s"
+
+
+@pytest.mark.timeout(600)
+def test_bench_default_workload_with_two_ranks():
+    """the driver's N > 1 form of the headline line: every rank runs the block on its own shard (weak scaling), one
+    all-reduce of the flat gradient buffer per step, and the line carries the configs[3] leg sharded over the ranks."""
+    p = _bench(["--gpus", "2", "--backend", "gloo", "--same-device", "--batch", "2", "--points", "600", "--k", "10",
+                "--steps", "4", "--warmup", "1", "--train-steps", "2"])
+    assert p.returncode == 0, (p.stdout + p.stderr)[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["ranks"] == 2
+    assert out["value"] > 0 and "cpu_baseline" not in out          # the CPU leg runs at N = 1 only
+    assert out["roofline"]["frac"] <= 1.0 and all(k["frac"] <= 1.0 for k in out["kernels"])
+    leg = out["train_step"]
+    assert leg["rccl_ranks"] == 2 and leg["config"]["global_batch"] == 32 and leg["config"]["batch_per_gpu"] == 16
+    assert leg["scaling"] == "strong" and leg["value"] > 0
 
 
 @pytest.mark.timeout(300)
