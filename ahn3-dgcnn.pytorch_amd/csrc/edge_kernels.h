@@ -65,10 +65,13 @@ void launch_graph_feature_bwd(const float *gout, const int *rowptr, const int *i
 // ---- edge_mlp.hip : per-edge 64 -> 64 contraction on MFMA (second stage of blocks 1, 2) ------
 int mlp_grid(int P);      // backward: number of gW2 / BN1 partial records
 int mlp_grid_fwd(int P);  // forward: number of BN2 partial records
-// fin != NULL (training): BatchNorm-2 batch statistics finished in the same launch (fold.h)
+// fin != NULL (training): BatchNorm-2 batch statistics finished in the same launch (fold.h).  guard: one int, zero at
+// launch -- raised when |a1| or |W2| leaves the fp16 range, in which case the fp32 instance of the kernel (fold counters
+// fs_fallback) redoes the pass in the same call
 void launch_edge_mlp_fwd(const float *TP, const float *TQ, const int32_t *idx, int N, int k, int P,
                          const float *stats1, const float *w2, const float *gamma2, float slope, float *usel2,
-                         uint8_t *hit2, const FoldSet &fs, const BnBatchStats *fin, hipStream_t st);
+                         uint8_t *hit2, const FoldSet &fs, const FoldSet &fs_fallback, const BnBatchStats *fin, int *guard,
+                         hipStream_t st);
 // dv1 [E][64]; dvsum [P][64] = sum over each point's k edges of dv1; partial_dw2 [grid][64][64]; the BatchNorm-1
 // backward sums (sum dv1, sum dv1 * uhat1) are finished in the same launch (fold.h) -> fin1
 // gmax_bits: bits of max |dL/dy . LReLU'| (launch_bwd_point); guard: one int, zero at launch -- raised when an operand

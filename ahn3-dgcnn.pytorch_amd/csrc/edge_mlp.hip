@@ -57,12 +57,12 @@ constexpr float LO_SCALE = 2048.0f, LO_UNSCALE = 1.0f / 2048.0f;
 
 // x = hi + lo / 2^11 up to 2^-21 |x|: hi = x with the low 13 mantissa bits cleared (exactly a fp16 number inside the
 // fp16 normal range), lo = the exact remainder, scaled (and rounded to fp16 by the caller).  |x| beyond the fp16 range
-// saturates (finite garbage instead of NaN); below the normal range the error is at most 2^-25 absolute.
+// becomes an infinity in the conversion and poisons every sum it enters -- which is how the forward kernel notices
+// (no clamp, no per-element range test); below the normal range the error is at most 2^-25 absolute.
 __device__ __forceinline__ void split_f16(float x, float &hi, float &lo)
 {
-    const float xc = __builtin_amdgcn_fmed3f(x, -65504.0f, 65504.0f);
-    hi = __uint_as_float(__float_as_uint(xc) & 0xffffe000u);
-    lo = (xc - hi) * LO_SCALE;
+    hi = __uint_as_float(__float_as_uint(x) & 0xffffe000u);
+    lo = (x - hi) * LO_SCALE;
 }
 // A operand of the 32x32x16 fp16 MFMA from a fp32 [32][TSTR] tile: lane (i, h), step s holds columns 16 s + 8 h .. + 7
 __device__ __forceinline__ void load_a_split(const float (*tile)[TSTR], int i32, int h, half8 (&ahi)[4], half8 (&alo)[4])
@@ -83,31 +83,40 @@ __device__ __forceinline__ void load_a_split(const float (*tile)[TSTR], int i32,
 }
 
 // ---------------------------------------------------------------------------------------------
+// F32 = false: the production kernel (fp16 matrix cores, split operands).  |a1| or |W2| beyond the fp16 range (65504)
+// overflows in the split: the kernel sees it in its sums and raises *guard, its BatchNorm finalizer then stands down, and
+// the F32 = true instance -- the same pass on v_mfma_f32_32x32x2_f32, launched behind it, returning at once while *guard
+// is zero -- redoes the work (usel2, hit2, BatchNorm-2 statistics).
+template <bool F32>
 __global__ __launch_bounds__(256) void edge_mlp_fwd_kernel(const float *__restrict__ TP, const float *__restrict__ TQ,
                                                            const int32_t *__restrict__ idx, int N, int k, int P,
                                                            const float *__restrict__ stats1,
                                                            const float *__restrict__ w2,
                                                            const float *__restrict__ gamma2, float slope,
                                                            float *__restrict__ usel2, uint8_t *__restrict__ hit2,
-                                                           int fin_on, FoldSet fs, BnBatchStats fin)
+                                                           int fin_on, FoldSet fs, BnBatchStats fin, int *__restrict__ guard)
 {
+    if (F32 && *guard == 0) return;
     __shared__ __attribute__((aligned(16))) float tiles[MLP_WAVES][32][TSTR];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, i32 = lane & 31;
     float(*tileA)[TSTR] = tiles[wave];
 
     // B operand: B[k = ci][n = co] = W2[co][ci]; lane (n, h) supplies ci = 16 s + 8 h .. + 7 at step s, split in halves
     half8 whi[2][4], wlo[2][4];
+    if constexpr (!F32) {
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+            for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float a, b;
-                split_f16(w2[(size_t)(nt * 32 + i32) * EC + 16 * s + 8 * h + e], a, b);
-                whi[nt][s][e] = (_Float16)a;
-                wlo[nt][s][e] = (_Float16)b;
-            }
+                for (int e = 0; e < 8; ++e) {
+                    float a, b;
+                    const float w = w2[(size_t)(nt * 32 + i32) * EC + 16 * s + 8 * h + e];
+                    split_f16(w, a, b);
+                    whi[nt][s][e] = (_Float16)a;
+                    wlo[nt][s][e] = (_Float16)b;
+                }
+    }
     unsigned flip[2];  // gamma2 < 0: the activation's maximum is the pre-activation's minimum
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) flip[nt] = gamma2[nt * 32 + i32] < 0.0f ? 0x80000000u : 0u;
@@ -143,22 +152,31 @@ __global__ __launch_bounds__(256) void edge_mlp_fwd_kernel(const float *__restri
                     for (int t = 0; t < 8; ++t) {
                         const bool on = g * 8 + t < kk;
                         const float u = p[t] + q;
-                        tileA[g * 8 + t][lane] = on ? lrelu(__builtin_fmaf(u, sc1, sh1), slope) : 0.0f;
+                        const float a = on ? lrelu(__builtin_fmaf(u, sc1, sh1), slope) : 0.0f;
+                        tileA[g * 8 + t][lane] = a;
                     }
                 }
             }
             half8 ahi[4], alo[4];
-            load_a_split(tileA, i32, h, ahi, alo);
+            if constexpr (!F32) load_a_split(tileA, i32, h, ahi, alo);
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                f32x16 am, ax;  // hi.hi and (hi.lo + lo.hi) 2^11
+                f32x16 am, ax;  // hi.hi and (hi.lo + lo.hi) 2^11   (F32: the whole product in am)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) am[r] = ax[r] = 0.0f;
+                if constexpr (F32) {
+                    float a32[32];
+                    load_a_operand(tileA, i32, h, a32);
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    am = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[s], whi[nt][s], am, 0, 0, 0);
-                    ax = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[s], wlo[nt][s], ax, 0, 0, 0);
-                    ax = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[s], whi[nt][s], ax, 0, 0, 0);
+                    for (int s = 0; s < 32; ++s)
+                        am = __builtin_amdgcn_mfma_f32_32x32x2f32(a32[s], w2[(size_t)(nt * 32 + i32) * EC + 32 * h + s], am, 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        am = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[s], whi[nt][s], am, 0, 0, 0);
+                        ax = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[s], wlo[nt][s], ax, 0, 0, 0);
+                        ax = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[s], whi[nt][s], ax, 0, 0, 0);
+                    }
                 }
                 // extreme of the sign-flipped value (so that it is always a maximum), then the first slot that holds it
                 float best = -__builtin_inff();
@@ -194,6 +212,12 @@ __global__ __launch_bounds__(256) void edge_mlp_fwd_kernel(const float *__restri
     }
     // BN2 batch statistics (training): lane (n, h) holds channel nt * 32 + n; fold the halves -- lane l then carries
     // channel l (nt = h) -- and let the pass finish the sums itself (fold.h)
+    if constexpr (!F32) {
+        // an operand element beyond the fp16 range turned into an infinity in the split and has poisoned the sums of
+        // squares it entered (inf, or NaN against a zero): hand the pass to the fp32 instance behind this launch
+        const bool poisoned = !(sq[0] <= 1.0e300) || !(sq[1] <= 1.0e300);
+        if (__ballot(poisoned) && lane == 0) atomicOr(guard, 1);
+    }
     if (fin_on) {
         const double t0 = sum[0] + shfl_xor_d(sum[0], 32), t1 = sum[1] + shfl_xor_d(sum[1], 32);
         const double q0 = sq[0] + shfl_xor_d(sq[0], 32), q1 = sq[1] + shfl_xor_d(sq[1], 32);
@@ -396,11 +420,17 @@ __global__ __launch_bounds__(512) void edge_mlp_bwd_f32_kernel(
 // ---------------------------------------------------------------------------------------------
 void launch_edge_mlp_fwd(const float *TP, const float *TQ, const int32_t *idx, int N, int k, int P,
                          const float *stats1, const float *w2, const float *gamma2, float slope, float *usel2,
-                         uint8_t *hit2, const FoldSet &fs, const BnBatchStats *fin, hipStream_t st)
+                         uint8_t *hit2, const FoldSet &fs, const FoldSet &fs_fallback, const BnBatchStats *fin, int *guard,
+                         hipStream_t st)
 {
+    BnBatchStats f16 = fin ? *fin : BnBatchStats{}, f32 = f16;
+    f16.guard = guard;   // the fp16 kernel's finalizer stands down when the guard is up
+    f32.guard = nullptr;
     prof_begin(PROF_EDGE_MLP_FWD, st);
-    hipLaunchKernelGGL(edge_mlp_fwd_kernel, dim3(mlp_grid_fwd(P)), dim3(256), 0, st, TP, TQ, idx, N, k, P, stats1, w2,
-                       gamma2, slope, usel2, hit2, fin ? 1 : 0, fs, fin ? *fin : BnBatchStats{});
+    hipLaunchKernelGGL(edge_mlp_fwd_kernel<false>, dim3(mlp_grid_fwd(P)), dim3(256), 0, st, TP, TQ, idx, N, k, P, stats1, w2,
+                       gamma2, slope, usel2, hit2, fin ? 1 : 0, fs, f16, guard);
+    hipLaunchKernelGGL(edge_mlp_fwd_kernel<true>, dim3(mlp_grid_fwd(P)), dim3(256), 0, st, TP, TQ, idx, N, k, P, stats1, w2,
+                       gamma2, slope, usel2, hit2, fin ? 1 : 0, fs_fallback, f32, guard);
     prof_end(PROF_EDGE_MLP_FWD, st);
 }
 

@@ -211,8 +211,9 @@ extern "C" int dgcnn_edgeconv_fwd(const dgcnn_edgeconv_desc *d, const float *x, 
         launch_edge_out(s.usel, s.stats1, d->slope, P, y, st);
     } else {
         if (d->training) launch_edge_reduce(s.TP, s.TQ, idx, N, k, P, d->bn1.weight, nullptr, s.usum, nullptr, fs1, &fin1, st);
-        launch_edge_mlp_fwd(s.TP, s.TQ, idx, N, k, P, s.stats1, d->w2, d->bn2.weight, d->slope, s.usel, s.hitj, fs2,
-                            d->training ? &fin2 : nullptr, st);
+        const FoldSet fs3{w.f2.rec, w.f2.folded, w.zero + Z_FOLD_C};
+        launch_edge_mlp_fwd(s.TP, s.TQ, idx, N, k, P, s.stats1, d->w2, d->bn2.weight, d->slope, s.usel, s.hitj, fs2, fs3,
+                            d->training ? &fin2 : nullptr, w.zero + Z_GUARD, st);
         launch_edge_out(s.usel, s.stats2, d->slope, P, y, st);
     }
     DG_CHECK_LAUNCH("dgcnn_edgeconv_fwd");

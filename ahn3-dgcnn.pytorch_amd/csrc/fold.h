@@ -151,8 +151,10 @@ struct BnBatchStats {
     double count;
     float eps, momentum;
     float *stats;
+    const int *guard = nullptr;  // non-NULL and raised: another launch redoes the pass -- leave the statistics alone
     __device__ __forceinline__ void operator()(const double (&t)[2], int c) const
     {
+        if (guard && __hip_atomic_load((gu32 *)guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
         const double m = t[0] / count;
         double v = t[1] / count - m * m;
         if (v < 0.0) v = 0.0;

@@ -335,6 +335,29 @@ def test_two_stage_backward_leaves_the_fp16_range(device):
         assert float((a - b).abs().max()) <= RTOL_GRAD * float(b.abs().max()), what
 
 
+def test_two_stage_forward_leaves_the_fp16_range(device):
+    """the second convolution's forward splits a1 and W2 into fp16 halves: an element beyond 65504 would saturate there.
+    The kernel notices, its BatchNorm finalizer stands down and the fp32 instance behind it redoes the pass (outputs,
+    batch statistics and running statistics must be the reference's)."""
+    import copy
+    B, C, N, k = 2, 16, 200, 12
+    base = make_stages(2 * C, 2)
+    with torch.no_grad():
+        base[0][1].weight.mul_(1.0e5)          # |a1| up to ~3e5
+    x = torch.randn(B, C, N, generator=torch.Generator().manual_seed(1))
+    idx = ke.knn_exact(x.numpy(), k)
+    R = cotangent((B, 64, N), tag="edge")
+    for train in (True, False):
+        y0, _, st0 = run_oracle(x, idx, copy.deepcopy(base), train, R)
+        y1, _, st1 = run_hip(x, idx, copy.deepcopy(base), train, R, device)
+        # (train mode: BatchNorm-2 renormalises to O(1); eval mode: running statistics, outputs of order 1e5)
+        assert float((y1 - y0).abs().max()) <= ATOL_FWD * max(1.0, 1e-2 * float(y0.abs().max()))
+        if train:
+            np.testing.assert_allclose(st1[1][1].running_mean.cpu().numpy(), st0[1][1].running_mean.numpy(), rtol=2e-5, atol=1e-3)
+            np.testing.assert_allclose(st1[1][1].running_var.cpu().numpy(), st0[1][1].running_var.numpy(), rtol=2e-4)
+            assert int(st1[1][1].num_batches_tracked) == 1
+
+
 def test_single_stage_block_k_above_64(device):
     compare(1, 8, 200, 70, 1, True, device)
 
