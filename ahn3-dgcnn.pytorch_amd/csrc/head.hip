@@ -291,7 +291,8 @@ __global__ __launch_bounds__(256) void colmax_kernel(const float *__restrict__ x
 
 // g[b][c] = LeakyReLU(sc ext + sh), arg[b][c] = the point that supplied the extreme
 __global__ void colmax_finish_kernel(const hkey *__restrict__ keys, const float *__restrict__ stats, int B, int C,
-                                     float slope, float *__restrict__ g, int32_t *__restrict__ arg)
+                                     float slope, float *__restrict__ g, int32_t *__restrict__ arg,
+                                     float *__restrict__ uwin = nullptr)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= B * C) return;
@@ -302,6 +303,7 @@ __global__ void colmax_finish_kernel(const hkey *__restrict__ keys, const float 
     const float ext = __uint_as_float(__float_as_uint(head_unordered((unsigned)(k >> 32))) ^ flip);
     g[t] = lrelu(__builtin_fmaf(ext, sc, sh), slope);
     arg[t] = (int32_t)(0xffffffffu - (unsigned)k);
+    if (uwin) uwin[t] = ext;  // the pre-activation at the winner (the backward of the fused conv6 needs nothing else of u)
 }
 
 // backward sums over the B winners of a column: gbias = sum dv, gweight = sum dv xhat, cc = (c1, c2) = the means over
@@ -705,6 +707,45 @@ extern "C" int dgcnn_bn_lrelu_max_fwd(const float *x, int B, int N, int C, const
     hipLaunchKernelGGL(colmax_kernel, dim3(ceil_div(C, 64), head_chunks(N), B), dim3(256), 0, st, x, stats, N, C, keys);
     hipLaunchKernelGGL(colmax_finish_kernel, dim3(ceil_div(B * C, 256)), dim3(256), 0, st, keys, stats, B, C, slope, g, arg);
     DG_CHECK_LAUNCH("dgcnn_bn_lrelu_max_fwd");
+    return 0;
+}
+
+namespace dgcnn {
+void launch_rows_gemm_colred(const float *x, int ldx, const float *w, int ldw, int P, int K, int N, const unsigned *amax_x,
+                             const unsigned *amax_w, int rows_per_batch, const float *gamma, int want_sums, double *partial,
+                             unsigned long long *keys, hipStream_t st);  // head_gemm.hip
+int rows_gemm_row_blocks(int P);
+}  // namespace dgcnn
+
+extern "C" size_t dgcnn_embed_max_fwd_workspace_bytes(int B, int N, int C)
+{
+    if (B <= 0 || N <= 0 || C <= 0) return 0;
+    return align_up((size_t)rows_gemm_row_blocks(B * N) * 2 * C * sizeof(double), 256) + align_up((size_t)B * C * sizeof(hkey), 256);
+}
+
+extern "C" int dgcnn_embed_max_fwd(const float *cat, int ldc, const float *w, int ldw, int B, int N, int F, int C,
+                                   const uint32_t *amax_cat, const uint32_t *amax_w, const dgcnn_bn_params *bn, int training,
+                                   float eps, float momentum, float slope, float *g, int32_t *arg, float *uwin, float *stats,
+                                   void *workspace, size_t workspace_bytes, void *stream)
+{
+    DG_REQUIRE(cat && w && amax_cat && amax_w && bn && g && arg && uwin && stats && workspace, "dgcnn_embed_max_fwd: null pointer");
+    DG_REQUIRE(B > 0 && N > 0 && F > 0 && C > 0 && ldc >= F && ldw >= F, "dgcnn_embed_max_fwd: bad shape B=%d N=%d F=%d C=%d", B, N, F, C);
+    DG_REQUIRE((F & 31) == 0 && (ldc & 3) == 0 && (ldw & 3) == 0 && ((uintptr_t)cat & 15) == 0 && ((uintptr_t)w & 15) == 0,
+               "dgcnn_embed_max_fwd: F must be a multiple of 32, rows 16-byte aligned");
+    DG_REQUIRE((size_t)B * N < ((size_t)1 << 31), "dgcnn_embed_max_fwd: more than 2^31 rows");
+    DG_REQUIRE(bn->weight && bn->bias, "dgcnn_embed_max_fwd: BatchNorm parameters missing");
+    DG_REQUIRE(training || (bn->running_mean && bn->running_var), "dgcnn_embed_max_fwd: eval mode needs running statistics");
+    DG_REQUIRE(workspace_bytes >= dgcnn_embed_max_fwd_workspace_bytes(B, N, C), "dgcnn_embed_max_fwd: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int P = B * N, nrb = rows_gemm_row_blocks(P);
+    double *partial = (double *)workspace;
+    hkey *keys = (hkey *)((char *)workspace + align_up((size_t)nrb * 2 * C * sizeof(double), 256));
+    if (hipMemsetAsync(keys, 0, (size_t)B * C * sizeof(hkey), st) != hipSuccess) DG_FAIL("dgcnn_embed_max_fwd: memset failed");
+    launch_rows_gemm_colred(cat, ldc, w, ldw, P, F, C, amax_cat, amax_w, N, bn->weight, training, partial, keys, st);
+    hipLaunchKernelGGL(colstats_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64 * FOLD_W), 0, st, partial, nrb, P, C, training,
+                       bn->weight, bn->bias, bn->running_mean, bn->running_var, eps, momentum, stats);
+    hipLaunchKernelGGL(colmax_finish_kernel, dim3(ceil_div(B * C, 256)), dim3(256), 0, st, keys, stats, B, C, slope, g, arg, uwin);
+    DG_CHECK_LAUNCH("dgcnn_embed_max_fwd");
     return 0;
 }
 

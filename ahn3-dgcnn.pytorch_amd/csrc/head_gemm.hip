@@ -176,6 +176,128 @@ __global__ __launch_bounds__(256) void rows_gemm16_kernel(const float *__restric
     }
 }
 
+// ---- conv6 -> bn6 -> LeakyReLU -> max over the points (model.py:172-175) without ever writing u = cat . W6^T ---------
+// The same product as rows_gemm16_kernel, but the [P][C] result stays in the accumulators: the epilogue leaves
+//   * per column the sum and the sum of squares over the tile's rows (fp64 records partial[row block][2][C]: the
+//     BatchNorm1d batch statistics, finished by colstats_finalize_kernel in record order), and
+//   * per (batch element, column) the extreme that survives the max over the points -- BatchNorm + LeakyReLU is monotone
+//     per column (increasing for gamma >= 0, else decreasing), so the extreme of u is enough -- as a 64-bit key
+//     {ordered(u ^ flip), ~point}: larger value first, then the LOWER point index (PyTorch's first maximum); keys of a tile
+//     meet in LDS, then one atomicMax per (batch element, column) and tile on keys[B][C] (a maximum: order-independent).
+// At B = 8, N = 7000 that is 229 MB never written and never re-read twice (column statistics, column maxima).
+typedef unsigned long long hkey64;
+__device__ __forceinline__ unsigned ordered_bits(float f)
+{
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ __launch_bounds__(256) void rows_gemm16_colred_kernel(const float *__restrict__ X, int ldx,
+                                                                 const float *__restrict__ W, int ldw, int P, int K, int N,
+                                                                 const unsigned *__restrict__ amax_x,
+                                                                 const unsigned *__restrict__ amax_w, int rows_per_batch,
+                                                                 const float *__restrict__ gamma, int want_sums,
+                                                                 double *__restrict__ partial, hkey64 *__restrict__ keys,
+                                                                 int ncb)
+{
+    constexpr int GK = 32, GSTR = GK + 8;
+    __shared__ __attribute__((aligned(16))) _Float16 xh[GM][GSTR], xl[GM][GSTR], wh[GN][GSTR], wl[GN][GSTR];
+    __shared__ hkey64 kbest[2][GN];       // the tile's first two batch elements
+    __shared__ double csum[4][2][GN];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, i32 = lane & 31;
+    const int cb = (int)blockIdx.x % ncb, rb = (int)blockIdx.x / ncb;
+    const int row0 = rb * GM, col0 = cb * GN;
+    const float sx = scale_to(__uint_as_float(*amax_x), 14), sw = scale_to(__uint_as_float(*amax_w), 14);
+    for (int t = threadIdx.x; t < 2 * GN; t += 256) kbest[t / GN][t % GN] = 0;
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
+    StageRegs<GK> rx, rw;
+    stage_load<GK>(X, ldx, row0, P, 0, rx);
+    stage_load<GK>(W, ldw, col0, N, 0, rw);
+    for (int k0 = 0; k0 < K; k0 += GK) {
+        __syncthreads();
+        stage_store<GK>(rx, sx, xh, xl);
+        stage_store<GK>(rw, sw, wh, wl);
+        __syncthreads();
+        if (k0 + GK < K) {
+            stage_load<GK>(X, ldx, row0, P, k0 + GK, rx);
+            stage_load<GK>(W, ldw, col0, N, k0 + GK, rw);
+        }
+#pragma unroll
+        for (int s = 0; s < GK / 16; ++s) {
+            const half8 ahi = *reinterpret_cast<const half8 *>(&xh[wave * 32 + i32][16 * s + 8 * h]);
+            const half8 alo = *reinterpret_cast<const half8 *>(&xl[wave * 32 + i32][16 * s + 8 * h]);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const half8 bhi = *reinterpret_cast<const half8 *>(&wh[nt * 32 + i32][16 * s + 8 * h]);
+                const half8 blo = *reinterpret_cast<const half8 *>(&wl[nt * 32 + i32][16 * s + 8 * h]);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, blo, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bhi, acc[nt], 0, 0, 0);
+            }
+        }
+    }
+    // ---- epilogue: lane (n, h) holds column nt 32 + n, rows mfma32_row(r, h) (ascending in r) of this wave's 32 rows
+    const float un = 1.0f / (sx * sw);
+    const int bfirst = row0 / rows_per_batch;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int cl = nt * 32 + i32, col = col0 + cl;
+        const bool cv = col < N;
+        const unsigned flip = cv && gamma[col] < 0.0f ? 0x80000000u : 0u;  // gamma < 0: the activation's maximum is u's minimum
+        float s1 = 0.0f, s2 = 0.0f;
+        hkey64 best = 0;
+        int bcur = -1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row0 + wave * 32 + mfma32_row(r, h);
+            if (row < P && cv) {
+                const float u = acc[nt][r] * un;
+                s1 += u;
+                s2 = __builtin_fmaf(u, u, s2);
+                const int b = row / rows_per_batch, rl = row - b * rows_per_batch;
+                if (b != bcur) {  // the rows of a lane ascend: a batch element's rows are consecutive
+                    if (bcur >= 0) {
+                        if (bcur - bfirst < 2) atomicMax(&kbest[bcur - bfirst][cl], best);
+                        else atomicMax(keys + (size_t)bcur * N + col, best);
+                    }
+                    bcur = b;
+                    best = 0;
+                }
+                const hkey64 key = ((hkey64)ordered_bits(__uint_as_float(__float_as_uint(u) ^ flip)) << 32) |
+                                   (hkey64)(0xffffffffu - (unsigned)rl);
+                best = key > best ? key : best;
+            }
+        }
+        if (bcur >= 0) {
+            if (bcur - bfirst < 2) atomicMax(&kbest[bcur - bfirst][cl], best);
+            else atomicMax(keys + (size_t)bcur * N + col, best);
+        }
+        if (want_sums) {
+            const double d1 = (double)s1 + (double)__shfl_xor(s1, 32), d2 = (double)s2 + (double)__shfl_xor(s2, 32);
+            if (h == 0) {
+                csum[wave][0][cl] = d1;
+                csum[wave][1][cl] = d2;
+            }
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 2 * GN; t += 256) {
+        const int bb = t / GN, cl = t % GN;
+        const hkey64 kv = kbest[bb][cl];
+        if (kv != 0 && col0 + cl < N) atomicMax(keys + (size_t)(bfirst + bb) * N + col0 + cl, kv);
+    }
+    if (want_sums && threadIdx.x < GN && col0 + (int)threadIdx.x < N) {
+        const int cl = threadIdx.x;
+        partial[((size_t)rb * 2 + 0) * N + col0 + cl] = (csum[0][0][cl] + csum[1][0][cl]) + (csum[2][0][cl] + csum[3][0][cl]);
+        partial[((size_t)rb * 2 + 1) * N + col0 + cl] = (csum[0][1][cl] + csum[1][1][cl]) + (csum[2][1][cl] + csum[3][1][cl]);
+    }
+}
+
 // ---- weight gradient of a 1x1 convolution on point-major rows: dW[M][Nn] = sum_p A[p][m] B[p][n] --------------------
 // (A = dL/d(conv output) [P][M], B = the conv input [P][Nn]; model.py:172-187 backward).  The contraction runs over the
 // points, so both MFMA operands need runs of consecutive POINTS for a fixed column: a stage of 32 points is loaded in
@@ -354,4 +476,17 @@ int dgcnn_rows_wgrad16_launch(const float *a, int lda, int M, const float *b, in
     hipLaunchKernelGGL(rows_wgrad16_kernel, grid, dim3(256), 0, st, a, lda, M, b, ldb, Nn, P, chunk, tn, amax_a, amax_b, partial);
     return 0;
 }
+}  // namespace dgcnn
+
+namespace dgcnn {
+// the product + column reductions of dgcnn_embed_max_fwd (head.hip): records partial [ceil(P / 128)][2][C], keys [B][C] (zeroed)
+void launch_rows_gemm_colred(const float *x, int ldx, const float *w, int ldw, int P, int K, int N, const unsigned *amax_x,
+                             const unsigned *amax_w, int rows_per_batch, const float *gamma, int want_sums, double *partial,
+                             unsigned long long *keys, hipStream_t st)
+{
+    const int ncb = ceil_div(N, GN), nrb = ceil_div(P, GM);
+    hipLaunchKernelGGL(rows_gemm16_colred_kernel, dim3(ncb * nrb), dim3(256), 0, st, x, ldx, w, ldw, P, K, N, amax_x, amax_w,
+                       rows_per_batch, gamma, want_sums, partial, keys, ncb);
+}
+int rows_gemm_row_blocks(int P) { return ceil_div(P, GM); }
 }  // namespace dgcnn

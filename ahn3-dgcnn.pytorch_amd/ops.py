@@ -477,8 +477,9 @@ class _EmbedMax(torch.autograd.Function):
         dcat = 1 (A W)^T + cat (W^T diag(B) W) + [winners: s W rows]
         dW   = A (sum_p cat)^T + diag(B) W (cat^T cat) + [winners: s cat rows]
 
-    i.e. two 192 x 192 library products over the points instead of two 1024-wide ones (44 -> 8 GFLOP at B = 8,
-    N = 7000), and the pre-activation u ([B*N, emb], 229 MB there) is dropped right after the forward."""
+    i.e. two 192 x 192 products over the points instead of two 1024-wide ones (44 -> 8 GFLOP at B = 8, N = 7000).  The
+    forward is one kernel pass (dgcnn_embed_max_fwd): the pre-activation u ([B*N, emb], 229 MB there) never leaves the
+    matrix kernel's accumulators -- column sums and the running extreme are its epilogue."""
 
     @staticmethod
     def forward(ctx, cat, w, weight, bias, rmean, rvar, B, N, training, eps, momentum, slope):
@@ -487,19 +488,34 @@ class _EmbedMax(torch.autograd.Function):
         lib = _lib.load()
         dev = cat.device
         wd = w.detach()
-        ac = rows_absmax(cat.detach())     # max |cat|: this product and the two 192-wide ones of the backward
-        u = rows_gemm(cat.detach(), wd, amax_x=ac) if _gemm_ok(F_) else torch.mm(cat.detach(), wd.t())
+        catd = cat.detach()
         wc, bc = weight.detach().contiguous(), bias.detach().contiguous()
         bn = _bn_struct(wc, bc, rmean, rvar)
         g = torch.empty((B, C), dtype=torch.float32, device=dev)
         arg = torch.empty((B, C), dtype=torch.int32, device=dev)
         stats = torch.empty((4, C), dtype=torch.float32, device=dev)
-        ws_bytes = lib.dgcnn_bn_lrelu_max_workspace_bytes(B, N, C)
-        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
-        _lib.check(lib.dgcnn_bn_lrelu_max_fwd(_lib.ptr(u), B, N, C, ctypes.byref(bn), 1 if training else 0, eps, momentum,
-                                              slope, _lib.ptr(g), _lib.ptr(arg), _lib.ptr(stats), _lib.ptr(ws), ws_bytes,
-                                              _lib.stream_ptr(dev)), "dgcnn_bn_lrelu_max_fwd")
-        uwin = torch.gather(u.view(B, N, C), 1, arg.long().unsqueeze(1)).squeeze(1).contiguous()   # [B, C]
+        ac = rows_absmax(catd)     # max |cat|: this product and the two 192-wide ones of the backward
+        fused = _gemm_ok(F_) and C % 4 == 0 and catd.stride(0) % 4 == 0 and catd.data_ptr() % 16 == 0
+        if fused:
+            # ONE pass: the [P, emb] product never leaves the matrix kernel's accumulators (dgcnn_embed_max_fwd)
+            if wd.stride(1) != 1 or wd.stride(0) % 4 or wd.data_ptr() % 16:
+                wd = wd.contiguous()
+            uwin = torch.empty((B, C), dtype=torch.float32, device=dev)
+            ws_bytes = lib.dgcnn_embed_max_fwd_workspace_bytes(B, N, C)
+            ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+            _lib.check(lib.dgcnn_embed_max_fwd(_lib.ptr(catd), catd.stride(0), _lib.ptr(wd), wd.stride(0), B, N, F_, C,
+                                               _lib.ptr(ac), _lib.ptr(rows_absmax(wd)), ctypes.byref(bn), 1 if training else 0,
+                                               eps, momentum, slope, _lib.ptr(g), _lib.ptr(arg), _lib.ptr(uwin),
+                                               _lib.ptr(stats), _lib.ptr(ws), ws_bytes, _lib.stream_ptr(dev)),
+                       "dgcnn_embed_max_fwd")
+        else:
+            u = torch.mm(catd, wd.t())
+            ws_bytes = lib.dgcnn_bn_lrelu_max_workspace_bytes(B, N, C)
+            ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+            _lib.check(lib.dgcnn_bn_lrelu_max_fwd(_lib.ptr(u), B, N, C, ctypes.byref(bn), 1 if training else 0, eps, momentum,
+                                                  slope, _lib.ptr(g), _lib.ptr(arg), _lib.ptr(stats), _lib.ptr(ws), ws_bytes,
+                                                  _lib.stream_ptr(dev)), "dgcnn_bn_lrelu_max_fwd")
+            uwin = torch.gather(u.view(B, N, C), 1, arg.long().unsqueeze(1)).squeeze(1).contiguous()   # [B, C]
         ctx.save_for_backward(cat, w, arg, stats, uwin, ac)
         ctx.cfg = (B, N, training, slope)
         return g

@@ -181,6 +181,18 @@ int dgcnn_rows_gemm(const float *x, int ldx, const float *w, int ldw, int P, int
  * (dL/dy in the input and weight gradients, a layer's input in forward and weight gradient) is measured once. */
 int dgcnn_rows_absmax(const float *x, int ld, int rows, int cols, uint32_t *amax, void *stream);
 
+/* conv6 -> bn6 -> LeakyReLU -> max over the points (model.py:172-175) in one pass over cat [B*N][F] (leading dimension
+ * ldc): the [B*N][C] product is never written -- the matrix kernel's epilogue keeps the column sums (BatchNorm1d batch
+ * statistics; running statistics updated when training) and, per (batch element, column), the extreme that survives the
+ * max (BatchNorm + LeakyReLU is monotone per column) with the first point attaining it.  Outputs: g [B][C], arg [B][C],
+ * uwin [B][C] = the pre-activation at the winner (what dgcnn_embed_max_bwd_prepare needs), stats [4][C].  amax_cat /
+ * amax_w: the operands' dgcnn_rows_absmax words.  F a multiple of 32, ldc / ldw multiples of 4, 16-byte aligned rows. */
+size_t dgcnn_embed_max_fwd_workspace_bytes(int B, int N, int C);
+int dgcnn_embed_max_fwd(const float *cat, int ldc, const float *w, int ldw, int B, int N, int F, int C,
+                        const uint32_t *amax_cat, const uint32_t *amax_w, const dgcnn_bn_params *bn, int training, float eps,
+                        float momentum, float slope, float *g, int32_t *arg, float *uwin, float *stats, void *workspace,
+                        size_t workspace_bytes, void *stream);
+
 /* Backward of conv6 -> bn6 -> LeakyReLU -> max without the dense [B*N][C] gradient (model.py:172-175; host side in
  * ops.py, _EmbedMax).  With u = cat . W^T the BatchNorm mean terms of dL/du are affine in u, dL/du[p][c] = A_c +
  * B_c u[p][c] + (s[b][c] at the winning point), so the backward needs 192-wide library products only.

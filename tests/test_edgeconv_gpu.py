@@ -487,7 +487,8 @@ def test_head_bn_lrelu_max_rows(B, N, C, train, device):
 
 
 @pytest.mark.parametrize("train", [True, False])
-@pytest.mark.parametrize("B,N,F,C", [(3, 700, 192, 64), (2, 1030, 192, 1024), (1, 130, 48, 200), (4, 257, 192, 1024)])
+@pytest.mark.parametrize("B,N,F,C", [(3, 700, 192, 64), (2, 1030, 192, 1024), (1, 130, 48, 200), (4, 257, 192, 1024),
+                                     (6, 40, 64, 128)])   # (the last: a 128-row tile of the fused kernel spans four batch elements)
 def test_head_embed_max_rows(B, N, F, C, train, device):
     # conv6 (1x1) -> bn6 -> LeakyReLU -> max over the points (model.py:172-175) as one node whose backward stays
     # 192-wide: vs the PyTorch-CPU op sequence on the same rows
