@@ -32,9 +32,11 @@ static int slots_override()
     static const int v = getenv("DGCNN_EDGE_SLOTS") ? atoi(getenv("DGCNN_EDGE_SLOTS")) : 0;  // experiments
     return v;
 }
-int edge_grid(int P)  // edge_reduce / edge_bwd: also the number of fp64 partial records (<= PART_MAX)
+int edge_grid(int P)  // edge_reduce: also the number of fp64 partial records (<= PART_MAX)
 {
-    return point_grid(P, EDGE_WAVES, slots_override() ? slots_override() : 512);
+    static const int v = getenv("DGCNN_REDUCE_SLOTS") ? atoi(getenv("DGCNN_REDUCE_SLOTS")) : 0;  // experiments
+    // (measured at B = 8, N = 7000, k = 30 with the in-launch fold: 66.8 / 64.5 / 64.5 / 65.2 us at 512 / 384 / 256 / 192 slots)
+    return point_grid(P, EDGE_WAVES, v ? v : (slots_override() ? slots_override() : 256));
 }
 static int stream_grid(int P)  // passes without partial records
 {

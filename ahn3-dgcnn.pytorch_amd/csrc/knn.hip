@@ -220,13 +220,12 @@ __device__ __forceinline__ float compact_row(u64 *kr, int c, int k, int lane)
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// approximate centre of one batch element (any vector works: distances are translation invariant;
-// centring only tightens the fp16 error bound): mean of the first <= 64 points.
-__global__ __launch_bounds__(256) void knn_center_kernel(const float *__restrict__ x, int N, int C,
-                                                         float *__restrict__ mu)
+// approximate centre of one batch element (any vector works: distances are translation invariant; centring only
+// tightens the fp16 error bound): the mean of the first <= 64 points, computed by every workgroup of knn_prep16_kernel
+// itself in the same fixed order (16 KB of L2-resident reads instead of a launch of its own)
+__device__ __forceinline__ void knn_centre(const float *__restrict__ x, int b, int N, int C, float *red /* [256] */,
+                                           float *ms /* [128] */)
 {
-    __shared__ float red[256];
-    const int b = blockIdx.x;
     const int G = 256 / C > 0 ? 256 / C : 1;  // C <= 128
     const int c = threadIdx.x % C, g = threadIdx.x / C;
     const int n1 = N < 64 ? N : 64;
@@ -235,10 +234,10 @@ __global__ __launch_bounds__(256) void knn_center_kernel(const float *__restrict
         for (int n = g; n < n1; n += G) s += x[((size_t)b * N + n) * C + c];
     red[threadIdx.x] = (g < G) ? s : 0.0f;
     __syncthreads();
-    if (threadIdx.x < C) {
+    if ((int)threadIdx.x < C) {
         float t = 0.0f;
         for (int i = 0; i < G; ++i) t += red[i * C + threadIdx.x];
-        mu[(size_t)b * C + threadIdx.x] = t / (float)n1;
+        ms[threadIdx.x] = t / (float)n1;
     }
 }
 
@@ -266,7 +265,7 @@ __device__ __forceinline__ float batch_max(const unsigned *__restrict__ tmax, in
 //   bmax[b][which][tile] = largest centred (which = 0) / raw (1) norm of the tile, as uint bits of non-negative
 //        floats (NaN bits win the comparison, as they must); batch_max() reduces them where they are needed
 //   rbflag[b][tile] = 0: the fallback flag of the row block, set later by the filter / refine kernels
-__global__ __launch_bounds__(256) void knn_prep16_kernel(const float *__restrict__ x, const float *__restrict__ mu,
+__global__ __launch_bounds__(256) void knn_prep16_kernel(const float *__restrict__ x,
                                                          int N, int C, int Npad, int CP, float *__restrict__ xx,
                                                          float *__restrict__ xxc, half8 *__restrict__ xh,
                                                          float *__restrict__ xt, unsigned *__restrict__ bmax,
@@ -274,14 +273,15 @@ __global__ __launch_bounds__(256) void knn_prep16_kernel(const float *__restrict
 {
     __shared__ float xs[32][129];  // C <= 128; odd stride: conflict-free column walks
     __shared__ float ms[128];
+    __shared__ float cred[256];
     const int tid = threadIdx.x;
     const int b = blockIdx.y, tile = blockIdx.x, q0 = tile * 32;
+    knn_centre(x, b, N, C, cred, ms);
     if (tid == 0) rbflag[(size_t)b * (Npad / 32) + tile] = 0;  // fallback flag of this row block (set by filter / refine)
     for (int i = tid; i < 32 * C; i += 256) {
         const int r = i / C, c = i - r * C;
         xs[r][c] = q0 + r < N ? x[((size_t)b * N + q0) * C + i] : 0.0f;
     }
-    if (tid < C) ms[tid] = mu[(size_t)b * C + tid];
     __syncthreads();
     // norms: wave 0 lanes 0..31 the raw chain, wave 1 lanes 0..31 the centred one
     if ((tid & 63) < 32 && tid < 128) {
@@ -1533,8 +1533,7 @@ extern "C" int dgcnn_knn(const float *x, int B, int N, int C, int k, int32_t *id
     const bool f16path = prepass && CP >= 16 && !f16_off;
     if (prepass && CP >= 16) {
         // one pass over x: norms, fp16 and fp32 operand tiles, norm maxima (after the centre of each batch element)
-        hipLaunchKernelGGL(knn_center_kernel, dim3(B), dim3(256), 0, st, x, N, C, w.mu);
-        hipLaunchKernelGGL(knn_prep16_kernel, dim3(Npad / 32, B), dim3(256), 0, st, x, w.mu, N, C, Npad, CP, xx, w.xxc, w.xh,
+        hipLaunchKernelGGL(knn_prep16_kernel, dim3(Npad / 32, B), dim3(256), 0, st, x, N, C, Npad, CP, xx, w.xxc, w.xh,
                            xt, w.bmax, w.rbflag);
     } else {
         hipLaunchKernelGGL(knn_norm_kernel, dim3(ceil_div(Npad, 256), B), dim3(256), 0, st, x, N, C, Npad, xx);
