@@ -184,14 +184,27 @@ __global__ __launch_bounds__(256) void bwd_point_kernel(const float *__restrict_
     const float sc = stats[ST_SC + lane], sh = stats[ST_SH + lane];
     double acc[2] = {0.0, 0.0};
     float gmax = 0.0f;
-    for (int pt = blockIdx.x * EDGE_WAVES + wave; pt < P; pt += gridDim.x * EDGE_WAVES) {
-        const float us = usel[(size_t)pt * EC + lane];
-        const float v = __builtin_fmaf(us, sc, sh);
-        const float dv = gy[(size_t)pt * EC + lane] * (v > 0.0f ? 1.0f : slope);
-        const float uhat = (us - mean) * rstd;
-        acc[0] += (double)dv;
-        acc[1] = __builtin_fma((double)dv, (double)uhat, acc[1]);
-        gmax = fmaxf(gmax, fabsf(dv));
+    // four points in flight per wave (a wave owns ~100 points at B = 32: one load pair per round trip was 66 us)
+    const int stride = gridDim.x * EDGE_WAVES;
+    for (int pt = blockIdx.x * EDGE_WAVES + wave; pt < P; pt += 4 * stride) {
+        float us[4], g4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = pt + u * stride < P ? pt + u * stride : pt;  // clamped: the load is unconditional, the value masked
+            us[u] = usel[(size_t)p * EC + lane];
+            g4[u] = gy[(size_t)p * EC + lane];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (pt + u * stride < P) {  // (uniform; added in point order)
+                const float v = __builtin_fmaf(us[u], sc, sh);
+                const float dv = g4[u] * (v > 0.0f ? 1.0f : slope);
+                const float uhat = (us[u] - mean) * rstd;
+                acc[0] += (double)dv;
+                acc[1] = __builtin_fma((double)dv, (double)uhat, acc[1]);
+                gmax = fmaxf(gmax, fabsf(dv));
+            }
+        }
     }
     // max |dv| for the operand scale of edge_mlp_bwd16_kernel: non-negative floats order like their bits, and a
     // maximum does not depend on the order of its arguments
