@@ -70,6 +70,9 @@ SIGNATURES = {
     "dgcnn_rows_gemm": (_c_int, [_c_vp, _c_int, _c_vp, _c_int, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_int, _c_vp,
                                  _c_int, _c_vp]),
     "dgcnn_rows_absmax": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp]),
+    "dgcnn_cls_fwd": (_c_int, [_c_vp, _c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp]),
+    "dgcnn_cls_bwd_workspace_bytes": (_c_sz, [_c_int, _c_int, _c_int]),
+    "dgcnn_cls_bwd": (_c_int, [_c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp]),
     "dgcnn_embed_max_fwd_workspace_bytes": (_c_sz, [_c_int, _c_int, _c_int]),
     "dgcnn_embed_max_fwd": (_c_int, [_c_vp, _c_int, _c_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_vp, _c_vp,
                                      ctypes.POINTER(BnParams), _c_int, _c_f, _c_f, _c_f, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_sz,

@@ -490,3 +490,188 @@ void launch_rows_gemm_colred(const float *x, int ldx, const float *w, int ldw, i
 }
 int rows_gemm_row_blocks(int P) { return ceil_div(P, GM); }
 }  // namespace dgcnn
+
+// ---- conv9: the classifier, y[P][NC] = x[P][K] . w[NC][K]^T with NC <= 8 classes (model.py:141,191) -----------------
+// Far too few output columns for a matrix tile (the library's product takes 279 us for 57 GFLOP-less work at B = 32): a
+// streaming pass instead.  A lane owns four consecutive k (one 16-byte load of the row), a wave a row at a time, eight
+// rows in flight; the NC partial dot products are folded across the wave with DPP/shuffle steps.  The backward makes ONE
+// pass over x and dL/dy: dL/dx rows are written as they go (16-byte stores), dL/dw accumulates in registers (NC x 4 per
+// lane) and leaves one record per workgroup, added in record order by sum_partials_kernel.  K a multiple of 4, K <= 1024.
+namespace dgcnn {
+constexpr int CLS_MAX = 8, CLS_ROWS = 8;
+
+template <int NC>
+__global__ __launch_bounds__(256) void cls_fwd_kernel(const float *__restrict__ x, const float *__restrict__ w, int P, int K,
+                                                      float *__restrict__ y)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nk = K / 4;  // float4 pieces per row
+    for (int p0 = (blockIdx.x * 4 + wave) * CLS_ROWS; p0 < P; p0 += gridDim.x * 4 * CLS_ROWS) {
+        float acc[CLS_ROWS][NC];
+#pragma unroll
+        for (int r = 0; r < CLS_ROWS; ++r)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc[r][c] = 0.0f;
+        for (int q = lane; q < nk; q += 64) {
+            float4 wv[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) wv[c] = reinterpret_cast<const float4 *>(w + (size_t)c * K)[q];
+            float4 xv[CLS_ROWS];
+#pragma unroll
+            for (int r = 0; r < CLS_ROWS; ++r) {
+                const int p = p0 + r < P ? p0 + r : P - 1;
+                xv[r] = reinterpret_cast<const float4 *>(x + (size_t)p * K)[q];
+            }
+#pragma unroll
+            for (int r = 0; r < CLS_ROWS; ++r)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    acc[r][c] = __builtin_fmaf(xv[r].x, wv[c].x, acc[r][c]);
+                    acc[r][c] = __builtin_fmaf(xv[r].y, wv[c].y, acc[r][c]);
+                    acc[r][c] = __builtin_fmaf(xv[r].z, wv[c].z, acc[r][c]);
+                    acc[r][c] = __builtin_fmaf(xv[r].w, wv[c].w, acc[r][c]);
+                }
+        }
+#pragma unroll
+        for (int r = 0; r < CLS_ROWS; ++r)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                float v = acc[r][c];
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+                acc[r][c] = v;
+            }
+        if (lane < CLS_ROWS * NC) {
+            const int r = lane / NC, c = lane - r * NC;
+            float v = 0.0f;
+#pragma unroll
+            for (int rr = 0; rr < CLS_ROWS; ++rr)
+#pragma unroll
+                for (int cc = 0; cc < NC; ++cc) v = (rr == r && cc == c) ? acc[rr][cc] : v;
+            if (p0 + r < P) y[(size_t)(p0 + r) * NC + c] = v;
+        }
+    }
+}
+
+// gx[p][k] = sum_c gy[p][c] w[c][k];  partial[block][c][k] = sum over the block's rows of gy[p][c] x[p][k]
+template <int NC>
+__global__ __launch_bounds__(256) void cls_bwd_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                      const float *__restrict__ gy, int P, int K, int rows_per_block,
+                                                      float *__restrict__ gx, float *__restrict__ partial)
+{
+    __shared__ float red[4][CLS_MAX * 4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nk = K / 4;
+    const int pb = blockIdx.x * rows_per_block, pe = pb + rows_per_block < P ? pb + rows_per_block : P;
+    for (int q0 = 0; q0 < nk; q0 += 64) {
+        const int q = q0 + lane;
+        const bool qv = q < nk;
+        float4 wv[NC];
+        float4 dw[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            wv[c] = qv ? reinterpret_cast<const float4 *>(w + (size_t)c * K)[q] : float4{0.0f, 0.0f, 0.0f, 0.0f};
+            dw[c] = float4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+        for (int p0 = pb + wave * 4; p0 < pe; p0 += 16) {  // a wave takes 4 consecutive rows of every 16, in row order
+            float g[4][NC];
+            float4 xv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int p = p0 + r < pe ? p0 + r : pe - 1;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) g[r][c] = p0 + r < pe ? gy[(size_t)p * NC + c] : 0.0f;
+                xv[r] = qv ? reinterpret_cast<const float4 *>(x + (size_t)p * K)[q] : float4{0.0f, 0.0f, 0.0f, 0.0f};
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float4 o = float4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    o.x = __builtin_fmaf(g[r][c], wv[c].x, o.x);
+                    o.y = __builtin_fmaf(g[r][c], wv[c].y, o.y);
+                    o.z = __builtin_fmaf(g[r][c], wv[c].z, o.z);
+                    o.w = __builtin_fmaf(g[r][c], wv[c].w, o.w);
+                    dw[c].x = __builtin_fmaf(g[r][c], xv[r].x, dw[c].x);
+                    dw[c].y = __builtin_fmaf(g[r][c], xv[r].y, dw[c].y);
+                    dw[c].z = __builtin_fmaf(g[r][c], xv[r].z, dw[c].z);
+                    dw[c].w = __builtin_fmaf(g[r][c], xv[r].w, dw[c].w);
+                }
+                if (gx && qv && p0 + r < pe) reinterpret_cast<float4 *>(gx + (size_t)(p0 + r) * K)[q] = o;
+            }
+        }
+        // fold the four waves in wave order, one record per workgroup
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            red[wave][c * 4 + 0][lane] = dw[c].x;
+            red[wave][c * 4 + 1][lane] = dw[c].y;
+            red[wave][c * 4 + 2][lane] = dw[c].z;
+            red[wave][c * 4 + 3][lane] = dw[c].w;
+        }
+        __syncthreads();
+        if (wave == 0 && qv && partial) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                float4 t;
+                t.x = (red[0][c * 4 + 0][lane] + red[1][c * 4 + 0][lane]) + (red[2][c * 4 + 0][lane] + red[3][c * 4 + 0][lane]);
+                t.y = (red[0][c * 4 + 1][lane] + red[1][c * 4 + 1][lane]) + (red[2][c * 4 + 1][lane] + red[3][c * 4 + 1][lane]);
+                t.z = (red[0][c * 4 + 2][lane] + red[1][c * 4 + 2][lane]) + (red[2][c * 4 + 2][lane] + red[3][c * 4 + 2][lane]);
+                t.w = (red[0][c * 4 + 3][lane] + red[1][c * 4 + 3][lane]) + (red[2][c * 4 + 3][lane] + red[3][c * 4 + 3][lane]);
+                reinterpret_cast<float4 *>(partial + ((size_t)blockIdx.x * NC + c) * K)[q] = t;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+void launch_sum_partials(const float *partial, int nchunk, int n, float *out, hipStream_t st);  // pointgemm.hip
+
+static int cls_blocks(int P) { int b = ceil_div(P, 128); return b > 1024 ? 1024 : b; }
+}  // namespace dgcnn
+
+extern "C" size_t dgcnn_cls_bwd_workspace_bytes(int P, int K, int NC)
+{
+    if (P <= 0 || K <= 0 || NC <= 0) return 0;
+    return align_up((size_t)cls_blocks(P) * NC * K * sizeof(float), 256);
+}
+
+#define DG_CLS_DISPATCH(NC_, CALL)      \
+    switch (NC_) {                      \
+        case 1: { constexpr int NCV = 1; CALL; } break; \
+        case 2: { constexpr int NCV = 2; CALL; } break; \
+        case 3: { constexpr int NCV = 3; CALL; } break; \
+        case 4: { constexpr int NCV = 4; CALL; } break; \
+        case 5: { constexpr int NCV = 5; CALL; } break; \
+        case 6: { constexpr int NCV = 6; CALL; } break; \
+        case 7: { constexpr int NCV = 7; CALL; } break; \
+        default: { constexpr int NCV = 8; CALL; } break; \
+    }
+
+extern "C" int dgcnn_cls_fwd(const float *x, const float *w, int P, int K, int NC, float *y, void *stream)
+{
+    DG_REQUIRE(x && w && y, "dgcnn_cls_fwd: null pointer");
+    DG_REQUIRE(P > 0 && K > 0 && (K & 3) == 0 && NC >= 1 && NC <= CLS_MAX, "dgcnn_cls_fwd: bad shape P=%d K=%d NC=%d (K %% 4 == 0, NC <= 8)", P, K, NC);
+    DG_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0, "dgcnn_cls_fwd: operands must be 16-byte aligned");
+    int grid = ceil_div(P, 4 * CLS_ROWS);
+    grid = grid > 4096 ? 4096 : grid;
+    DG_CLS_DISPATCH(NC, hipLaunchKernelGGL((cls_fwd_kernel<NCV>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, w, P, K, y));
+    DG_CHECK_LAUNCH("dgcnn_cls_fwd");
+    return 0;
+}
+
+extern "C" int dgcnn_cls_bwd(const float *x, const float *w, const float *gy, int P, int K, int NC, float *gx, float *gw,
+                             void *workspace, size_t workspace_bytes, void *stream)
+{
+    DG_REQUIRE(x && w && gy && workspace && (gx || gw), "dgcnn_cls_bwd: null pointer");
+    DG_REQUIRE(P > 0 && K > 0 && (K & 3) == 0 && NC >= 1 && NC <= CLS_MAX, "dgcnn_cls_bwd: bad shape P=%d K=%d NC=%d", P, K, NC);
+    DG_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0 && (!gx || ((uintptr_t)gx & 15) == 0),
+               "dgcnn_cls_bwd: operands must be 16-byte aligned");
+    DG_REQUIRE(workspace_bytes >= dgcnn_cls_bwd_workspace_bytes(P, K, NC), "dgcnn_cls_bwd: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int blocks = cls_blocks(P), rows = ceil_div(P, blocks);
+    float *partial = gw ? (float *)workspace : nullptr;
+    DG_CLS_DISPATCH(NC, hipLaunchKernelGGL((cls_bwd_kernel<NCV>), dim3(ceil_div(P, rows)), dim3(256), 0, st, x, w, gy, P, K, rows, gx, partial));
+    if (gw) launch_sum_partials(partial, ceil_div(P, rows), NC * K, gw, st);
+    DG_CHECK_LAUNCH("dgcnn_cls_bwd");
+    return 0;
+}

@@ -170,7 +170,7 @@ class DGCNN(nn.Module):
                                 if depth == 9:
                                     out = ops.from_point_major_autograd(z.view(B, N, -1))
                                 else:
-                                    z = F.linear(self.dp1(z), self.conv9.weight.squeeze(-1))
+                                    z = ops.classifier_rows(self.dp1(z), self.conv9.weight.squeeze(-1))
                                     out = ops.from_point_major_autograd(z.view(B, N, -1))
         if out.device != in_dev:
             out = out.to(in_dev)

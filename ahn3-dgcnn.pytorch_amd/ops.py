@@ -469,6 +469,50 @@ def linear_rows(x, w, add=None, rows_per_add=0):
     return _LinearRows.apply(x, w, add, int(rows_per_add))
 
 
+class _Classifier(torch.autograd.Function):
+    """conv9 (model.py:141, :191): x [P, K] . w [NC, K]^T -> [P, NC] for NC <= 8 classes; streaming kernels
+    (dgcnn_cls_fwd / dgcnn_cls_bwd: dL/dx and dL/dw in one pass over x and dL/dy)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        P, K = x.shape
+        NC = w.shape[0]
+        lib = _lib.load()
+        xd, wd = x.detach().contiguous(), w.detach().contiguous()
+        y = torch.empty((P, NC), dtype=torch.float32, device=x.device)
+        _lib.check(lib.dgcnn_cls_fwd(_lib.ptr(xd), _lib.ptr(wd), P, K, NC, _lib.ptr(y), _lib.stream_ptr(x.device)), "dgcnn_cls_fwd")
+        ctx.save_for_backward(xd, wd)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        xd, wd = ctx.saved_tensors
+        P, K = xd.shape
+        NC = wd.shape[0]
+        lib = _lib.load()
+        gy = gy.contiguous()
+        gx = torch.empty_like(xd) if ctx.needs_input_grad[0] else None
+        gw = torch.empty_like(wd) if ctx.needs_input_grad[1] else None
+        if gx is None and gw is None:
+            return None, None
+        ws_bytes = lib.dgcnn_cls_bwd_workspace_bytes(P, K, NC)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=xd.device)
+        _lib.check(lib.dgcnn_cls_bwd(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(gy), P, K, NC,
+                                     _lib.ptr(gx) if gx is not None else None, _lib.ptr(gw) if gw is not None else None,
+                                     _lib.ptr(ws), ws_bytes, _lib.stream_ptr(xd.device)), "dgcnn_cls_bwd")
+        return gx, gw
+
+
+def classifier_rows(x, w):
+    """the classifier on point-major rows: x [P, K], w [num_classes, K] -> logits [P, num_classes]"""
+    _lib.require_device(x, "x")
+    if x.dtype != torch.float32 or w.dtype != torch.float32:
+        raise TypeError("classifier_rows needs float32 operands")
+    if w.shape[0] > 8 or x.shape[1] % 4:
+        return torch.nn.functional.linear(x, w)   # more classes than the streaming kernel holds: the library product
+    return _Classifier.apply(x, w)
+
+
 class _EmbedMax(torch.autograd.Function):
     """conv6 -> bn6 -> LeakyReLU -> max over the points (model.py:172-175) as ONE autograd node, so that the backward
     never forms the dense [B*N, emb] gradient: with u = cat W^T, dL/du[p, c] = A_c + B_c u[p, c] + (s[b, c] at the

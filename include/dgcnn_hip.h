@@ -181,6 +181,15 @@ int dgcnn_rows_gemm(const float *x, int ldx, const float *w, int ldw, int P, int
  * (dL/dy in the input and weight gradients, a layer's input in forward and weight gradient) is measured once. */
 int dgcnn_rows_absmax(const float *x, int ld, int rows, int cols, uint32_t *amax, void *stream);
 
+/* conv9, the classifier (model.py:141 applied at :191): y[P][NC] = x[P][K] . w[NC][K]^T for NC <= 8 classes as a
+ * streaming pass (too few columns for a matrix tile), and its backward in ONE pass over x and gy: gx[P][K] = gy . w
+ * (may be NULL), gw[NC][K] = gy^T x (may be NULL; per-workgroup records added in a fixed order).  K a multiple of 4,
+ * 16-byte aligned operands. */
+int dgcnn_cls_fwd(const float *x, const float *w, int P, int K, int NC, float *y, void *stream);
+size_t dgcnn_cls_bwd_workspace_bytes(int P, int K, int NC);
+int dgcnn_cls_bwd(const float *x, const float *w, const float *gy, int P, int K, int NC, float *gx, float *gw,
+                  void *workspace, size_t workspace_bytes, void *stream);
+
 /* conv6 -> bn6 -> LeakyReLU -> max over the points (model.py:172-175) in one pass over cat [B*N][F] (leading dimension
  * ldc): the [B*N][C] product is never written -- the matrix kernel's epilogue keeps the column sums (BatchNorm1d batch
  * statistics; running statistics updated when training) and, per (batch element, column), the extreme that survives the

@@ -87,3 +87,35 @@ def test_linear_rows_autograd_matches_torch():
     for got, want in ((yd, yr), (xd.grad, xr.grad), (wd.grad, wr.grad), (ad.grad, ar.grad)):
         err = (got.detach().cpu().double() - want.detach()).abs().max().item()
         assert err <= 1e-5 * want.detach().abs().max().item()
+
+
+@pytest.mark.parametrize("P,K,NC", [(1000, 256, 5), (4097, 256, 2), (333, 64, 8), (7, 512, 3), (20000, 256, 5)])
+def test_classifier_rows_matches_float64(P, K, NC):
+    # conv9 (model.py:141, :191): the streaming forward and the one-pass backward against float64
+    from ahn3_dgcnn_pytorch_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(P + K + NC)
+    x = torch.randn(P, K, generator=g) + 0.2
+    w = torch.randn(NC, K, generator=g) / K ** 0.5
+    R = torch.randn(P, NC, generator=g)
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    yr = xr @ wr.t()
+    (yr * R.double()).sum().backward()
+    xd, wd = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True)
+    yd = ops.classifier_rows(xd, wd)
+    (yd * R.to(dev)).sum().backward()
+    for got, want, scale in ((yd, yr, (x.double().abs() @ w.double().abs().t())),
+                             (xd.grad, xr.grad, (R.double().abs() @ w.double().abs())),
+                             (wd.grad, wr.grad, (R.double().abs().t() @ x.double().abs()))):
+        rel = ((got.detach().cpu().double() - want.detach()).abs() / scale.clamp_min(1e-300)).max().item()
+        assert rel <= 2e-6, rel
+    xd2, wd2 = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True)
+    (ops.classifier_rows(xd2, wd2) * R.to(dev)).sum().backward()
+    assert torch.equal(xd2.grad, xd.grad) and torch.equal(wd2.grad, wd.grad)     # fixed order
+
+
+def test_classifier_rows_many_classes_uses_the_library_product():
+    from ahn3_dgcnn_pytorch_amd import ops
+    dev = torch.device("cuda:0")
+    x, w = torch.randn(100, 64).to(dev), torch.randn(13, 64).to(dev)
+    torch.testing.assert_close(ops.classifier_rows(x, w), x @ w.t(), rtol=1e-5, atol=1e-5)
