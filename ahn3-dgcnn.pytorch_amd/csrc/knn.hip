@@ -220,6 +220,35 @@ __device__ __forceinline__ float compact_row(u64 *kr, int c, int k, int lane)
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// constants and helper of the augmented K slab of the fp16 streams (see "fp16 streams" below)
+constexpr float KNN_AUG_K1 = 32768.0f, KNN_AUG_K2 = 16.0f, KNN_AUG_K3 = 0.0078125f;
+constexpr float KNN_PAD_NORM = 1073741824.0f;  // 2^30: the "norm" of a padding candidate (never a neighbour, no inf - inf)
+constexpr float KNN_F16_CMAX = 1.0e8f;         // largest centred norm the fp16 streams accept (|T| stays below 2^31)
+
+// v = 2^15 p1 + 2^4 p2 + 2^-7 p3 up to max(2^-33 |v|, 2^-32), every piece an fp16 number: each residual is exact in
+// fp32 and is scaled back up by 2^11 before it is rounded, so no piece relies on fp16 subnormals for its precision.
+// |v| >= 2^31 (and +-inf) becomes (+-inf, 0, 0).  v must not be NaN.
+struct Half3 {
+    _Float16 p1, p2, p3;
+};
+__device__ __forceinline__ Half3 knn_split3(float v)
+{
+    Half3 o;
+    if (!(__builtin_fabsf(v) < 2147483648.0f)) {
+        o.p1 = (_Float16)(v > 0.0f ? __builtin_inff() : -__builtin_inff());
+        o.p2 = o.p3 = (_Float16)0.0f;
+        return o;
+    }
+    const float s1 = v * 0x1p-15f;
+    o.p1 = (_Float16)s1;
+    const float s2 = (s1 - (float)o.p1) * 2048.0f;
+    o.p2 = (_Float16)s2;
+    const float s3 = (s2 - (float)o.p2) * 2048.0f;
+    o.p3 = (_Float16)s3;
+    return o;
+}
+
+
 // approximate centre of one batch element (any vector works: distances are translation invariant; centring only
 // tightens the fp16 error bound): the mean of the first <= 64 points, computed by every workgroup of knn_prep16_kernel
 // itself in the same fixed order (16 KB of L2-resident reads instead of a launch of its own)
@@ -260,7 +289,9 @@ __device__ __forceinline__ float batch_max(const unsigned *__restrict__ tmax, in
 //   xx   raw squared norms in the oracle's chain order (+inf for padding rows)
 //   xxc  squared norms of the mean-centred features (any order: they only feed the fp16 streams and their bound)
 //   xh   centred features as fp16 operand tiles of v_mfma_f32_32x32x16_f16: lane (j, h) of a 32-point tile
-//        supplies, at step ks, channels 16 ks + 8 h .. + 7 of point j; xh[tile][ks][lane] is one 16-byte vector
+//        supplies, at step ks, channels 16 ks + 8 h .. + 7 of point j; xh[tile][ks][lane] is one 16-byte vector;
+//        step ks = CP / 16 is the candidate side of the augmented slab (see "fp16 streams"): the three fp16 pieces
+//        of the point's centred norm (2^30 for padding points) and the constants that meet the query side's pieces
 //   xt   raw features as fp32 operand tiles (the layout of knn_tile_kernel<4>) for the fallback kernel
 //   bmax[b][which][tile] = largest centred (which = 0) / raw (1) norm of the tile, as uint bits of non-negative
 //        floats (NaN bits win the comparison, as they must); batch_max() reduces them where they are needed
@@ -274,6 +305,7 @@ __global__ __launch_bounds__(256) void knn_prep16_kernel(const float *__restrict
     __shared__ float xs[32][129];  // C <= 128; odd stride: conflict-free column walks
     __shared__ float ms[128];
     __shared__ float cred[256];
+    __shared__ float yys[32];
     const int tid = threadIdx.x;
     const int b = blockIdx.y, tile = blockIdx.x, q0 = tile * 32;
     knn_centre(x, b, N, C, cred, ms);
@@ -298,6 +330,7 @@ __global__ __launch_bounds__(256) void knn_prep16_kernel(const float *__restrict
         }
         const bool real = q0 + r < N;
         (centred ? xxc : xx)[(size_t)b * Npad + q0 + r] = real ? acc : __builtin_inff();
+        if (centred) yys[r] = real ? acc : KNN_PAD_NORM;
         unsigned m = real ? __float_as_uint(acc) : 0u;
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) {
@@ -316,7 +349,23 @@ __global__ __launch_bounds__(256) void knn_prep16_kernel(const float *__restrict
             const int c = 16 * ks + 8 * h + e;
             out[e] = (_Float16)((q0 + r < N && c < C) ? xs[r][c] - ms[c] : 0.0f);
         }
-        xh[((size_t)b * (Npad / 32) + tile) * KS * 64 + v] = out;
+        xh[((size_t)b * (Npad / 32) + tile) * (KS + 1) * 64 + v] = out;
+    }
+    __syncthreads();  // yys
+    if (tid < 64) {
+        half8 out;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) out[e] = (_Float16)0.0f;
+        if (tid < 32) {
+            const Half3 p = knn_split3(yys[tid]);
+            out[0] = p.p1;
+            out[1] = p.p2;
+            out[2] = p.p3;
+            out[3] = (_Float16)KNN_AUG_K1;
+            out[4] = (_Float16)KNN_AUG_K2;
+            out[5] = (_Float16)KNN_AUG_K3;
+        }
+        xh[((size_t)b * (Npad / 32) + tile) * (KS + 1) * 64 + KS * 64 + tid] = out;
     }
     // fp32 operand tiles (knn_tile_kernel<4>): vector v = g * 64 + lane, element e = channel 2 (4 g + e) + h
     const int G = CP / 8;
@@ -359,13 +408,16 @@ __device__ __forceinline__ void bitonic32_sort(unsigned &key, int lane)
 // fp32 value on the raw features.  Both approximate the real -||x_i - x_l||^2:
 //   fp16 rounding of both operands (rel. 2^-11 each) + fp32 accumulation: |2 d16 - 2 y_i.y_l| <= 2 * 2^-10 * 1.01 * sqrt(yy_i yy_l)
 //   fp16 subnormals (abs. 2^-25 per element):                              <= 1e-6 (sqrt(yy_i) + sqrt(yy_l))
-//   fp32 evaluation of yy and of the final subtractions:                   <= 1e-5 (yy_i + yy_l)
+//   fp32 evaluation of yy; the norms and the filter threshold ride in the matrix product (augmented slab, see
+//   "fp16 streams"), i.e. in up to ~90 fp32 additions of partial sums below 4 (yy_i + yy_l) in magnitude:
+//                                                                          <= 4e-5 (yy_i + yy_l)
+//   their three-piece fp16 representation (knn_split3), absolute:          <= 1e-9
 //   the oracle's own fp32 chain (gamma_66 = 3.9e-6 on |dot| and on xx):    <= 8e-6 (xx_i + xx_l)
 // with yy_l <= cmax, xx_l <= rmax (per batch element).  Worst-case bounds, not estimates.
 __device__ __forceinline__ float knn_f16_eps(float yy_i, float cmax, float xx_i, float rmax)
 {
     return 2.1e-3f * __builtin_sqrtf(yy_i * cmax) + 1e-6f * (__builtin_sqrtf(yy_i) + __builtin_sqrtf(cmax)) +
-           1e-5f * (yy_i + cmax) + 8e-6f * (xx_i + rmax) + 1e-30f;
+           4e-5f * (yy_i + cmax) + 8e-6f * (xx_i + rmax) + 1e-9f;
 }
 
 // Threshold pre-pass for small C (CP = 4, 8) in exact fp32.  One wave = RT x 32 query rows; xop are the fp32 tiles
@@ -483,16 +535,30 @@ __global__ __launch_bounds__(64) void knn_bound_kernel(const void *__restrict__ 
 // wave fetches every candidate tile itself (1760 waves x 0.9 MB = 1.55 GB per pass at B = 8, N = 7000, C = 64).
 // Here a workgroup = KNN_ST_WAVES waves of 32 query rows stages each chunk of KNN_ST_TILES candidate tiles once in LDS
 // (already in MFMA operand order, so the ds_read_b128 of a wave is contiguous and conflict-free) and all four
-// waves consume it: a quarter of the traffic, one barrier per chunk, register-prefetched double buffer.
+// waves consume it: a quarter of the traffic, one barrier per chunk.  The chunks go through a ring of KNN_ST_RING LDS
+// slots: chunk c + 2 is loaded (registers) while chunk c is consumed and written behind it, so a load has a whole
+// iteration to land and the barrier at the end of an iteration only orders slot reuse.
+//
+// The K dimension carries ONE EXTRA 16-wide slab (the "augmented" slab) that puts the additive terms of the distance
+// into the matrix product, so that the accumulator IS the quantity the epilogue tests -- no per-element fma / sub
+// (packed fp32 VALU beside MFMAs is an anti-lever on gfx950, and two VALU instructions per accumulator register made the
+// vector pipe, not the matrix pipe, the bound of both streams):
+//   candidate side (stored in xh by knn_prep16_kernel, lanes h = 0):  { p1, p2, p3, K1, K2, K3, 0, 0 }
+//   query side (built by the stream kernels, lanes h = 0):             { K1, K2, K3, g1, g2, g3, 0, 0 }
+// with K = (2^15, 2^4, 2^-7), (p1, p2, p3) = knn_split3(yy_l) the centred norm of the candidate and (g1, g2, g3) =
+// knn_split3(T_i) a per-row constant (0 in the pre-pass, the filter threshold in the filter).  With the query features
+// scaled by -2 (exact) the accumulator is  acc = T_i + yy_l - 2 d16(i, l) = T_i - t(i, l).
 constexpr int KNN_ST_TILES = 4;  // candidate tiles per staged chunk (Npad / 32 is a multiple of 4)
-
 constexpr int KNN_ST_WAVES = 4;  // waves (32-row tiles) per workgroup of the fp16 streams (2 measured slower: 105 vs 98 us)
 constexpr int KNN_ST_THREADS = KNN_ST_WAVES * 64;
+constexpr int KNN_ST_RING = 3;   // LDS slots of the chunk ring
+constexpr int KNN_ST_RT = 2;     // row tiles per wave: every staged candidate operand feeds RT MFMAs (half the L2 -> CU and LDS traffic)
+constexpr int KNN_ST_ROWS = KNN_ST_WAVES * KNN_ST_RT;  // row tiles per workgroup
 
-template <int KS>
+template <int KS1>
 struct Stage16 {
-    static constexpr int VEC_PER_CHUNK = KNN_ST_TILES * KS * 64;  // half8 vectors per chunk
-    static constexpr int VPT = VEC_PER_CHUNK / KNN_ST_THREADS;    // per thread
+    static constexpr int VEC_PER_CHUNK = KNN_ST_TILES * KS1 * 64;  // half8 vectors per chunk
+    static constexpr int VPT = VEC_PER_CHUNK / KNN_ST_THREADS;     // per thread (= KS1)
     half8 reg[VPT];
     __device__ __forceinline__ void gload(const half8 *__restrict__ xbatch, int chunk, int tid)
     {
@@ -506,87 +572,45 @@ struct Stage16 {
     }
 };
 
-template <int CP>
-__global__ __launch_bounds__(KNN_ST_THREADS) void knn_bound16s_kernel(const half8 *__restrict__ xh, const float *__restrict__ xxc,
-                                                           const float *__restrict__ xx_raw,
-                                                           const unsigned *__restrict__ bmax, int B, int Npad, int k,
-                                                           int parts, unsigned *__restrict__ exch,
-                                                           float *__restrict__ tau0, float *__restrict__ epsr)
+// query-side operand of a wave: the row tile's features times -2 and the augmented slab with the row constant T
+template <int KS1>
+__device__ __forceinline__ void knn_stream_a(const half8 *__restrict__ xbatch, int rb, int lane, float T, half8 (&a)[KS1])
 {
-    constexpr int KS = CP / 16;
-    constexpr int SBUF_BYTES = 2 * Stage16<KS>::VEC_PER_CHUNK * (int)sizeof(half8);
-    constexpr int TR_BYTES = KNN_ST_WAVES * 32 * 65 * (int)sizeof(float);  // epilogue transpose
-    __shared__ __attribute__((aligned(16))) char smem[SBUF_BYTES > TR_BYTES ? SBUF_BYTES : TR_BYTES];
-    half8(*sbuf)[Stage16<KS>::VEC_PER_CHUNK] = reinterpret_cast<half8(*)[Stage16<KS>::VEC_PER_CHUNK]>(smem);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, j32 = lane & 31;
-    // workgroup = (batch element, candidate part, group of KNN_ST_WAVES row tiles); with B a multiple of 8 both
-    // parts of a row group run on the same XCD (blockIdx % 8)
-    const int b = blockIdx.x % B, part = (blockIdx.x / B) % parts;
-    const int rb = (blockIdx.x / B / parts) * KNN_ST_WAVES + wave;  // this wave's row tile
-    const int ntiles = Npad / 32, nchunks = ntiles / KNN_ST_TILES;
-    const int c0 = part * nchunks / parts, c1 = (part + 1) * nchunks / parts;  // this part's candidate chunks
-    const half8 *xbatch = xh + (size_t)b * ntiles * KS * 64;
-    const float *yb = xxc + (size_t)b * Npad;
-
-    half8 a[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) a[ks] = xbatch[((size_t)rb * KS + ks) * 64 + lane];
-    // class maxima of t = 2 d16 - yy_l: candidate tiles 4g, 4g+1 feed m0, tiles 4g+2, 4g+3 feed m1 (64 classes
-    // per row with the 32 candidate lanes); packed fp32 pairs: 8 v_pk_fma + 8 v_max3 per tile pair
-    f32x2 m0[8], m1[8];
+    for (int ks = 0; ks < KS1 - 1; ++ks) a[ks] = xbatch[((size_t)rb * KS1 + ks) * 64 + lane] * (_Float16)(-2.0f);
+    half8 aug;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) m0[i] = m1[i] = f32x2{-__builtin_inff(), -__builtin_inff()};
-
-    Stage16<KS> st;
-    st.gload(xbatch, c0, tid);
-    st.swrite(sbuf[0], tid);
-    float ycur[KNN_ST_TILES], ynext[KNN_ST_TILES];
-#pragma unroll
-    for (int tt = 0; tt < KNN_ST_TILES; ++tt) ycur[tt] = yb[(c0 * KNN_ST_TILES + tt) * 32 + j32];
-    __syncthreads();
-    for (int c = c0; c < c1; ++c) {
-        const int cn = c + 1 < c1 ? c + 1 : c;  // clamped prefetch: no branch around the loads
-        st.gload(xbatch, cn, tid);
-#pragma unroll
-        for (int tt = 0; tt < KNN_ST_TILES; ++tt) ynext[tt] = yb[(cn * KNN_ST_TILES + tt) * 32 + j32];
-        const half8 *cur = sbuf[(c - c0) & 1];
-        f32x16 acc[KNN_ST_TILES];
-#pragma unroll
-        for (int tt = 0; tt < KNN_ST_TILES; ++tt) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[tt][r] = 0.0f;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-                acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks], cur[(tt * KS + ks) * 64 + lane], acc[tt], 0, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const f32x2 two = f32x2{2.0f, 2.0f};
-            const f32x2 t0 = __builtin_elementwise_fma(f32x2{acc[0][2 * i], acc[0][2 * i + 1]}, two, f32x2{-ycur[0], -ycur[0]});
-            const f32x2 t1 = __builtin_elementwise_fma(f32x2{acc[1][2 * i], acc[1][2 * i + 1]}, two, f32x2{-ycur[1], -ycur[1]});
-            const f32x2 t2 = __builtin_elementwise_fma(f32x2{acc[2][2 * i], acc[2][2 * i + 1]}, two, f32x2{-ycur[2], -ycur[2]});
-            const f32x2 t3 = __builtin_elementwise_fma(f32x2{acc[3][2 * i], acc[3][2 * i + 1]}, two, f32x2{-ycur[3], -ycur[3]});
-            m0[i] = __builtin_elementwise_max(m0[i], __builtin_elementwise_max(t0, t1));
-            m1[i] = __builtin_elementwise_max(m1[i], __builtin_elementwise_max(t2, t3));
-        }
-        st.swrite(sbuf[(c - c0 + 1) & 1], tid);
-#pragma unroll
-        for (int tt = 0; tt < KNN_ST_TILES; ++tt) ycur[tt] = ynext[tt];
-        __syncthreads();
+    for (int e = 0; e < 8; ++e) aug[e] = (_Float16)0.0f;
+    if (lane < 32) {
+        const Half3 g = knn_split3(T);
+        aug[0] = (_Float16)KNN_AUG_K1;
+        aug[1] = (_Float16)KNN_AUG_K2;
+        aug[2] = (_Float16)KNN_AUG_K3;
+        aug[3] = g.p1;
+        aug[4] = g.p2;
+        aug[5] = g.p3;
     }
+    a[KS1 - 1] = aug;
+}
 
-    // k-th largest of the 64 class maxima of every row, minus the row's own norm and the error bound.
-    // The maxima are transposed through LDS (row stride 65 words: conflict-free both ways) so that lane
-    // (h, j) holds classes 32h .. 32h+31 of row j in registers; each lane sorts its 32 keys with a register
-    // bitonic network (all 32 rows of the tile at once, no cross-lane traffic), the two halves of a row are
-    // merged with one half-cleaner across lanes j and j + 32, and a 5-stage merge finishes the half that
-    // holds rank k (the upper 32 in lanes h = 0, the lower 32 in lanes h = 1).
-    float *tr = reinterpret_cast<float *>(smem) + wave * (32 * 65);  // all waves are past the last barrier
+// k-th largest of the 64 class maxima of every row of one row tile (m0, m1: the class MINIMA of acc = -t in the
+// accumulator layout), minus the row's own norm and the error bound.  The maxima are transposed through LDS (row stride
+// 65 words: conflict-free both ways) so that lane (h, j) holds classes 32h .. 32h+31 of row j in registers; each lane
+// sorts its 32 keys with a register bitonic network (all 32 rows of the tile at once, no cross-lane traffic), the two
+// halves of a row are merged with one half-cleaner across lanes j and j + 32, and a 5-stage merge finishes the half
+// that holds rank k (the upper 32 in lanes h = 0, the lower 32 in lanes h = 1).
+__device__ __forceinline__ void knn_bound_finish(const float (&m0)[16], const float (&m1)[16], float *tr /* [32 * 65], this wave's */,
+                                                 int b, int rb, int part, int parts, int Npad, int k, float cmax, float rmax,
+                                                 const float *__restrict__ yb, const float *__restrict__ xx_raw,
+                                                 unsigned *__restrict__ exch, float *__restrict__ tau0,
+                                                 float *__restrict__ epsr)
+{
+    const int lane = threadIdx.x & 63, h = lane >> 5, j32 = lane & 31;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = mfma32_row(r, h);
-        tr[row * 65 + j32] = m0[r >> 1][r & 1];
-        tr[row * 65 + 32 + j32] = m1[r >> 1][r & 1];
+        tr[row * 65 + j32] = -m0[r];
+        tr[row * 65 + 32 + j32] = -m1[r];
     }
     unsigned v[32];
 #pragma unroll
@@ -635,7 +659,6 @@ __global__ __launch_bounds__(KNN_ST_THREADS) void knn_bound16s_kernel(const half
     unsigned kth = w[0];
 #pragma unroll
     for (int i = 1; i < 32; ++i) kth = sel == i ? w[i] : kth;
-    const float cmax = batch_max(bmax, b, 0, Npad / 32), rmax = batch_max(bmax, b, 1, Npad / 32);
     if (h == ((k - 1) >> 5)) {
         const float vk = __uint_as_float((kth & 0x80000000u) ? (kth & 0x7fffffffu) : ~kth);
         const int row = rb * 32 + j32;
@@ -645,6 +668,152 @@ __global__ __launch_bounds__(KNN_ST_THREADS) void knn_bound16s_kernel(const half
         tau0[(size_t)b * Npad + row] = (t != t) ? -__builtin_inff() : t;  // NaN -> no bound
         epsr[(size_t)b * Npad + row] = eps;
     }
+}
+
+// Threshold pre-pass on the fp16 matrix cores.  The instruction stream of a wave is laid out by hand, group by group
+// (a group = one staged operand vector and the RT MFMAs it feeds, fenced by sched_barrier): the operand of group g + 3
+// is read from LDS before the MFMAs of group g are issued, and the class minima of the tile finished last (the other
+// accumulator pair) are folded a few registers per group, so that neither an LDS latency nor the vector epilogue ever
+// stands between two MFMAs of the wave.  Measured on the way (B = 8, N = 7000, C = 64; the compiler's own order of the
+// same work: 70 us): MFMAs alone 36 us, + epilogue 42, + LDS reads 55, + staging 62.
+template <int CP>
+__global__ __launch_bounds__(KNN_ST_THREADS, 2) void knn_bound16s_kernel(const half8 *__restrict__ xh, const float *__restrict__ xxc,
+                                                           const float *__restrict__ xx_raw,
+                                                           const unsigned *__restrict__ bmax, int B, int Npad, int k,
+                                                           int parts, unsigned *__restrict__ exch,
+                                                           float *__restrict__ tau0, float *__restrict__ epsr)
+{
+    constexpr int KS1 = CP / 16 + 1, RT = KNN_ST_RT, NG = KNN_ST_TILES * KS1, PD = 3, RING = KNN_ST_RING;
+    constexpr int VPC = Stage16<KS1>::VEC_PER_CHUNK;
+    constexpr int SBUF_BYTES = RING * VPC * (int)sizeof(half8);
+    constexpr int TR_BYTES = KNN_ST_WAVES * 32 * 65 * (int)sizeof(float);  // epilogue transpose
+    static_assert(RT == 2 && KNN_ST_TILES == 4 && RING == 3, "the hand-laid stream below assumes these");
+    __shared__ __attribute__((aligned(16))) char smem[SBUF_BYTES > TR_BYTES ? SBUF_BYTES : TR_BYTES];
+    half8 *sbuf = reinterpret_cast<half8 *>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // workgroup = (batch element, candidate part, group of KNN_ST_ROWS row tiles); with B a multiple of 8 all
+    // parts of a row group run on the same XCD (blockIdx % 8)
+    const int b = blockIdx.x % B, part = (blockIdx.x / B) % parts;
+    const int rb0 = (blockIdx.x / B / parts) * KNN_ST_ROWS + wave * RT;  // this wave's first row tile
+    const int ntiles = Npad / 32, nchunks = ntiles / KNN_ST_TILES;
+    const int c0 = part * nchunks / parts, c1 = (part + 1) * nchunks / parts;  // this part's candidate chunks
+    const half8 *xbatch = xh + (size_t)b * ntiles * KS1 * 64;
+    const float *yb = xxc + (size_t)b * Npad;
+
+    // (a row tile beyond the batch element -- ntiles is a multiple of 4, a workgroup covers KNN_ST_ROWS -- repeats the
+    // last real one and is not written: its wave still takes part in the staging)
+#ifdef KNN_STAMP
+    const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+#endif
+    half8 a[RT][KS1];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) knn_stream_a<KS1>(xbatch, rb0 + rt < ntiles ? rb0 + rt : ntiles - 1, lane, 0.0f, a[rt]);
+    // class minima of acc = yy_l - 2 d16 = -t: even candidate tiles feed m0, odd ones m1 (64 classes per row with the
+    // 32 candidate lanes)
+    float m0[RT][16], m1[RT][16];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) m0[rt][i] = m1[rt][i] = __builtin_inff();
+
+    // chunk ring: iteration c consumes slot c % 3, reads ahead into slot (c + 1) % 3 (written during iteration c - 1,
+    // behind that iteration's barrier), writes chunk c + 2 (registers, loaded during iteration c - 1) to slot (c + 2) % 3
+    // -- last read in iteration c - 1 -- and loads chunk c + 3
+    const int last = c1 - 1;
+    Stage16<KS1> st;
+    st.gload(xbatch, c0, tid);
+    st.swrite(sbuf, tid);
+    st.gload(xbatch, c0 + 1 < last ? c0 + 1 : last, tid);
+    st.swrite(sbuf + VPC, tid);
+    st.gload(xbatch, c0 + 2 < last ? c0 + 2 : last, tid);
+    __syncthreads();
+    // accumulators: even tiles in accE, odd tiles in accO; the tile pending across the barrier is the odd tile 3 of the
+    // chunk before (+inf, the neutral element, in the first iteration)
+    f32x16 accE[RT], accO[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accE[rt][r] = accO[rt][r] = __builtin_inff();
+    half8 bq[PD + 1];
+#pragma unroll
+    for (int g = 0; g < PD; ++g) bq[g] = sbuf[g * 64 + lane];
+    int scur = 0, snxt = 1, swr = 2;
+#ifdef KNN_STAMP
+    const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
+#endif
+    for (int c = c0; c < c1; ++c) {
+        const half8 *cur = sbuf + scur * VPC, *nxt = sbuf + snxt * VPC;
+        half8 *wr = sbuf + swr * VPC;
+        const int cload = c + 3 < last ? c + 3 : last;  // clamped: no branch around the loads
+        static_for<NG>([&](auto G) {
+            constexpr int g = G.value, t = g / KS1, ks = g % KS1, gp = g + PD;
+            // operand of group g + PD (the first PD groups of the next chunk at the end)
+            bq[gp % (PD + 1)] = gp < NG ? cur[gp * 64 + lane] : nxt[(gp - NG) * 64 + lane];
+            // staging, one vector per group: registers -> ring (groups 0 ..), then global -> registers
+            if constexpr (g < KS1) wr[g * KNN_ST_THREADS + tid] = st.reg[g];
+            else if constexpr (g < 2 * KS1)
+                st.reg[g - KS1] = xbatch[(size_t)cload * VPC + (g - KS1) * KNN_ST_THREADS + tid];
+            // the MFMAs of the group
+            if constexpr ((t & 1) == 0) {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    if constexpr (ks == 0) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) accE[rt][r] = 0.0f;
+                    }
+                    accE[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rt][ks], bq[g % (PD + 1)], accE[rt], 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    if constexpr (ks == 0) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) accO[rt][r] = 0.0f;
+                    }
+                    accO[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rt][ks], bq[g % (PD + 1)], accO[rt], 0, 0, 0);
+                }
+            }
+            // a share of the pending tile's epilogue (the other accumulator pair), none in the tile's first group (its
+            // last MFMAs are still in the pipe).  Inline asm: as __builtin_fminf the compiler either joins the folds of
+            // two tiles into one v_min3 -- and keeps eight accumulator tiles alive for it -- or, pinned by an empty
+            // asm, canonicalises both operands first (three instructions per fold)
+            if constexpr (ks > 0) {
+                constexpr int e0 = (ks - 1) * (RT * 16) / (KS1 - 1), e1 = ks * (RT * 16) / (KS1 - 1);
+#pragma unroll
+                for (int e = e0; e < e1; ++e) {
+                    const int rt = e / 16, r = e % 16;
+                    if constexpr ((t & 1) == 0) asm volatile("v_min_f32 %0, %0, %1" : "+v"(m1[rt][r]) : "v"(accO[rt][r]));
+                    else asm volatile("v_min_f32 %0, %0, %1" : "+v"(m0[rt][r]) : "v"(accE[rt][r]));
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        scur = snxt;
+        snxt = swr;
+        swr = swr + 1 == RING ? 0 : swr + 1;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m1[rt][r] = __builtin_fminf(m1[rt][r], accO[rt][r]);
+
+#ifdef KNN_STAMP
+    const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
+#endif
+    float *tr = reinterpret_cast<float *>(smem) + wave * (32 * 65);  // all waves are past the last barrier
+    const float cmax = batch_max(bmax, b, 0, Npad / 32), rmax = batch_max(bmax, b, 1, Npad / 32);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        if (rb0 + rt >= ntiles) break;  // uniform over the wave
+        knn_bound_finish(m0[rt], m1[rt], tr, b, rb0 + rt, part, parts, Npad, k, cmax, rmax, yb, xx_raw, exch, tau0, epsr);
+    }
+#ifdef KNN_STAMP
+    const unsigned long long ts3 = __builtin_amdgcn_s_memtime();
+    if ((blockIdx.x % 97) == 5 && lane == 0)
+        printf("bound blk %d wave %d: start %llu prologue %llu loop %llu (%d chunks, %llu per chunk) finish %llu\n", (int)blockIdx.x, wave,
+               ts0, ts1 - ts0, ts2 - ts1, c1 - c0, (ts2 - ts1) / (c1 - c0), ts3 - ts2);
+#endif
 }
 
 // Threshold of a row from the two parts' sorted class maxima A, B (64 each, descending): the top 64 of the
@@ -926,159 +1095,240 @@ constexpr int KNN_MAXPARTS = 4;   // candidate parts of the filter (list segment
 constexpr int KNN_LISTCAP = 4096;  // survivor list per 32-row block in HBM (128 per row on average)
 
 template <int CP>
-__global__ __launch_bounds__(KNN_ST_THREADS) void knn_filter16_kernel(const half8 *__restrict__ xh, const float *__restrict__ xxc,
+__global__ __launch_bounds__(KNN_ST_THREADS, 2) void knn_filter16_kernel(const half8 *__restrict__ xh, const float *__restrict__ xxc,
                                                            const float *__restrict__ tau0,
                                                            const float *__restrict__ epsr,
                                                            const unsigned *__restrict__ bmax, int B, int Npad,
                                                            int parts, unsigned *__restrict__ lists,
                                                            int *__restrict__ lcount, int *__restrict__ rbflag)
 {
-    constexpr int KS = CP / 16;
-    __shared__ half8 sbuf[2][Stage16<KS>::VEC_PER_CHUNK];
-    __shared__ unsigned queues[KNN_ST_WAVES][KNN_QCAP];
+    constexpr int KS1 = CP / 16 + 1, RT = KNN_ST_RT, NG = KNN_ST_TILES * KS1, PD = 3, RING = KNN_ST_RING;
+    constexpr int VPC = Stage16<KS1>::VEC_PER_CHUNK;
+    static_assert(RT == 2 && KNN_ST_TILES == 4 && RING == 3, "the hand-laid stream below assumes these");
+    __shared__ half8 sbuf[RING * VPC];
+    __shared__ unsigned queues[KNN_ST_WAVES][RT][KNN_QCAP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, j32 = lane & 31;
     // workgroup = (batch element, candidate part, group of row blocks) as in knn_bound16s_kernel; every
     // (row block, part) owns 1 / parts of the row block's list.  rbflag is zero-filled by the launcher.
     const int b = blockIdx.x % B, part = (blockIdx.x / B) % parts;
-    const int rb = (blockIdx.x / B / parts) * KNN_ST_WAVES + wave;  // this wave's row block
+    const int rb0 = (blockIdx.x / B / parts) * KNN_ST_ROWS + wave * RT;  // this wave's first row block
     const int ntiles = Npad / 32, nchunks = ntiles / KNN_ST_TILES;
     const int c0 = part * nchunks / parts, c1 = (part + 1) * nchunks / parts;
-    const int wid = b * ntiles + rb;
     const int listcap = KNN_LISTCAP / parts;
-    // centred features must fit fp16 (|y| <= sqrt(cmax) < 65504) with room; NaN/inf norms fail the test
-    if (!(batch_max(bmax, b, 0, Npad / 32) < 1.0e9f)) {  // uniform over the workgroup
-        if (lane == 0) {
-            rbflag[wid] = 1;
-            lcount[KNN_MAXPARTS * wid + part] = 0;
+#ifdef KNN_STAMP
+    const unsigned long long tsA = __builtin_amdgcn_s_memtime();
+#endif
+    // centred features must fit fp16 with room for the factor -2 and the threshold must fit the augmented slab
+    // (|T| < 2^31); NaN/inf norms fail the test
+    if (!(batch_max(bmax, b, 0, Npad / 32) < KNN_F16_CMAX)) {  // uniform over the workgroup
+        if (lane < RT && rb0 + lane < ntiles) {
+            rbflag[b * ntiles + rb0 + lane] = 1;
+            lcount[KNN_MAXPARTS * (b * ntiles + rb0 + lane) + part] = 0;
         }
         return;
     }
-    const int q0 = rb * 32;
-    const half8 *xbatch = xh + (size_t)b * ntiles * KS * 64;
+    const half8 *xbatch = xh + (size_t)b * ntiles * KS1 * 64;
     const float *yb = xxc + (size_t)b * Npad;
-    unsigned *list = lists + (size_t)wid * KNN_LISTCAP + part * listcap;
-    unsigned *queue = queues[wave];
 
-    half8 a[KS];
+    // filter threshold on t = 2 d16 - yy_l:  t > (tau0 - eps) + yy_i, lowered by the rounding of this very sum; it
+    // rides in the query side of the augmented slab (row 32 rb + j32 is the A row of lanes j32), so that the accumulator
+    // is T - t and a pair survives iff its sign bit is set.  A row block beyond the batch element (a workgroup covers
+    // KNN_ST_ROWS of them, ntiles is a multiple of 4) gets T = +inf: nothing passes, nothing is written.
+    half8 a[RT][KS1];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) a[ks] = xbatch[((size_t)rb * KS + ks) * 64 + lane];
-    // filter threshold on t = 2 d16 - yy_l:  t > (tau0 - eps) + yy_i, lowered by the rounding of this very sum
-    f32x2 thrp[8];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = q0 + mfma32_row(r, h);
+    for (int rt = 0; rt < RT; ++rt) {
+        const bool real = rb0 + rt < ntiles;
+        const int rbc = real ? rb0 + rt : ntiles - 1;
+        const int row = rbc * 32 + j32;
         const float tau = tau0[(size_t)b * Npad + row], yy = yb[row];
         const float v = (tau - epsr[(size_t)b * Npad + row]) + yy;
         const float thr = v - (__builtin_fabsf(v) + __builtin_fabsf(tau) + yy) * 2.4e-7f;
-        // padding rows (yy = +inf) give NaN: nothing may pass there, and the sign test below needs a real number
-        thrp[r >> 1][r & 1] = thr != thr ? __builtin_inff() : thr;
+        // padding rows (yy = +inf) give NaN: nothing may pass there (T = +inf: the accumulator is +inf)
+        knn_stream_a<KS1>(xbatch, rbc, lane, (thr != thr || !real) ? __builtin_inff() : thr, a[rt]);
     }
 
-    // staged survivors: a ring in LDS (no data movement on flush), entries already in the HBM list
-    int qhead = 0, qn = 0, lpos = 0;
-    bool overflow = false;
-    auto flush = [&](int n) {  // move the oldest n (<= 64) staged entries to the list
-        if (lpos + n > listcap) {
-            overflow = true;
+    // staged survivors: a ring in LDS per row block (no data movement on flush), entries already in the HBM list
+    int qhead[RT], qn[RT], lpos[RT];
+    bool overflow[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        qhead[rt] = qn[rt] = lpos[rt] = 0;
+        overflow[rt] = false;
+    }
+    auto flush = [&](int rt, int n) {  // move the oldest n (<= 64) staged entries of row block rt to its list
+        unsigned *list = lists + (size_t)(b * ntiles + rb0 + rt) * KNN_LISTCAP + part * listcap;
+        if (lpos[rt] + n > listcap) {
+            overflow[rt] = true;
         } else if (lane < n) {
-            list[lpos + lane] = queue[(qhead + lane) & (KNN_QCAP - 1)];
+            list[lpos[rt] + lane] = queues[wave][rt][(qhead[rt] + lane) & (KNN_QCAP - 1)];
         }
-        lpos += n;
-        qhead = (qhead + n) & (KNN_QCAP - 1);
-        qn -= n;
+        lpos[rt] += n;
+        qhead[rt] = (qhead[rt] + n) & (KNN_QCAP - 1);
+        qn[rt] -= n;
+    };
+    // Extraction in passes: every lane hands in up to three survivors of each row block per pass; an inclusive scan over
+    // the wave (DPP, both blocks' counts packed in one word) gives every lane its slots in the two staging rings, so a
+    // pass costs one scan and three short predicated steps instead of a ballot / mbcnt / popcount round per survivor
+    // (about 24 survivors per block and chunk over 64 lanes: one pass unless a lane holds more than three).  Bit 16 s + r
+    // of a block's mask = slot s, accumulator register r; slot s holds candidates cand + 32 off(s).
+    auto wave_scan = [&](unsigned v) {  // inclusive prefix sum over the 64 lanes
+        v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);  // row_shr:1
+        v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);  // row_shr:2
+        v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);  // row_shr:4
+        v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);  // row_shr:8
+        v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1, 3
+        v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2, 3
+        return v;
+    };
+    auto rounds = [&](u64 bits0, u64 bits1, int cand, unsigned offs /* four signed bytes: off(s) */) {
+        bool more = __ballot((bits0 | bits1) != 0ull) != 0ull;
+        while (more) {
+            const int p0 = __popcll(bits0), p1 = __popcll(bits1);
+            const int n0 = p0 < 3 ? p0 : 3, n1 = p1 < 3 ? p1 : 3;
+            const unsigned packed = (unsigned)n0 | ((unsigned)n1 << 16);
+            const unsigned incl = wave_scan(packed);
+            const unsigned tot = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+            const unsigned excl = incl - packed;
+            more = __ballot(p0 > 3 || p1 > 3) != 0ull;
+            // a pass adds at most 192 entries to a ring of KNN_QCAP = 256
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+                while (qn[rt] > KNN_QCAP - 192) flush(rt, 64);
+            const unsigned base0 = (unsigned)(qhead[0] + qn[0]) + (excl & 0xffffu), base1 = (unsigned)(qhead[1] + qn[1]) + (excl >> 16);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                if (i < n0) {
+                    const int pos = __builtin_ctzll(bits0), r = pos & 15;
+                    bits0 &= bits0 - 1ull;
+                    queues[wave][0][(base0 + i) & (KNN_QCAP - 1)] =
+                        ((unsigned)((r & 3) + 8 * (r >> 2) + 4 * h) << 27) | (unsigned)(cand + 32 * (int)(signed char)(offs >> (8 * (pos >> 4))));
+                }
+                if (i < n1) {
+                    const int pos = __builtin_ctzll(bits1), r = pos & 15;
+                    bits1 &= bits1 - 1ull;
+                    queues[wave][1][(base1 + i) & (KNN_QCAP - 1)] =
+                        ((unsigned)((r & 3) + 8 * (r >> 2) + 4 * h) << 27) | (unsigned)(cand + 32 * (int)(signed char)(offs >> (8 * (pos >> 4))));
+                }
+            }
+            qn[0] += (int)(tot & 0xffffu);
+            qn[1] += (int)(tot >> 16);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+                while (qn[rt] >= 64) flush(rt, 64);
+        }
     };
 
-    // MFMA chains of two candidate tiles, interleaved (the matrix pipe stays busy although each chain is serial)
-    auto mfma_pair = [&](const half8 *buf, int t0, f32x16 &c0, f32x16 &c1) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) c0[r] = c1[r] = 0.0f;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks], buf[(t0 * KS + ks) * 64 + lane], c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks], buf[((t0 + 1) * KS + ks) * 64 + lane], c1, 0, 0, 0);
-        }
-    };
-    // t > thr  <=>  sign(thr - t): the 16 sign bits of a lane are packed with one v_alignbit each (bit r =
-    // accumulator register r): 8 v_pk_fma + 8 v_pk_add + 16 v_alignbit per tile, no per-register ballot/branch
-    auto signs = [&](const f32x16 &acc, float y) {
-        unsigned bits = 0u;
-        // (plain fp32 fma / sub instead of the packed forms: 101 against 104 us -- not worth the doubled issue slots)
-#pragma unroll
-        for (int i = 7; i >= 0; --i) {
-            const f32x2 t = __builtin_elementwise_fma(f32x2{acc[2 * i], acc[2 * i + 1]}, f32x2{2.0f, 2.0f}, f32x2{-y, -y});
-            const f32x2 d = thrp[i] - t;
-            bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(d[1]), 31);
-            bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(d[0]), 31);
-        }
-        return bits;
-    };
-    // rounds: every lane that still holds survivors appends its lowest one (uniform loop).  The sign bits of the
-    // four tiles handled in one iteration are extracted together (bit 16 t + r = tile t, register r; tile t holds
-    // candidates cand + 32 t): ~24 survivors over 64 lanes need ~3 rounds, against ~2.3 per tile one by one.
-    auto rounds = [&](u64 bits, int cand) {
-        u64 m = __ballot(bits != 0ull);
-        while (m != 0) {
-            if (qn > KNN_QCAP - 64) {  // room for a full round of survivors (loose thresholds only)
-                while (qn >= 64) flush(64);
-            }
-            if (bits != 0ull) {
-                const int pos = __builtin_ctzll(bits);
-                const int r = pos & 15;
-                const int off = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-                queue[(qhead + qn + off) & (KNN_QCAP - 1)] =
-                    ((unsigned)((r & 3) + 8 * (r >> 2) + 4 * h) << 27) | (unsigned)(cand + (pos >> 4) * 32);
-                bits &= bits - 1ull;
-            }
-            qn += __popcll(m);
-            m = __ballot(bits != 0ull);
-        }
-        if (qn >= 64) flush(64);
-    };
-
-    // Software pipeline over pairs of tiles: the MFMA chains of one pair are issued in the same basic block as
-    // the sign packing of the pair before it, so the matrix pipe works under the vector epilogue.  The pair
-    // pending across the chunk barrier is tiles 2, 3 of the previous chunk.
-    Stage16<KS> st;
+    // chunk ring and hand-laid groups as in knn_bound16s_kernel; the epilogue share of a group packs sign bits of the
+    // pending tile (the other accumulator pair) with one v_alignbit per register.  Two tiles share a 32-bit word (the
+    // later one in the low half): w01 = {tile 3 of the chunk before, tile 0}, w23 = {tile 1, tile 2}.
+    const int last = c1 - 1;
+    Stage16<KS1> st;
     st.gload(xbatch, c0, tid);
-    st.swrite(sbuf[0], tid);
-    float ycur[KNN_ST_TILES], ynext[KNN_ST_TILES];
-#pragma unroll
-    for (int tt = 0; tt < KNN_ST_TILES; ++tt) ycur[tt] = yb[(c0 * KNN_ST_TILES + tt) * 32 + j32];
-    f32x16 pa0, pa1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) pa0[r] = pa1[r] = 0.0f;
-    float py0 = 0.0f, py1 = 0.0f;
+    st.swrite(sbuf, tid);
+    st.gload(xbatch, c0 + 1 < last ? c0 + 1 : last, tid);
+    st.swrite(sbuf + VPC, tid);
+    st.gload(xbatch, c0 + 2 < last ? c0 + 2 : last, tid);
     __syncthreads();
+    f32x16 accE[RT], accO[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accE[rt][r] = accO[rt][r] = 0.0f;  // +0: no survivor in the pending tile of the first chunk
+    half8 bq[PD + 1];
+#pragma unroll
+    for (int g = 0; g < PD; ++g) bq[g] = sbuf[g * 64 + lane];
+    int scur = 0, snxt = 1, swr = 2;
+#ifdef KNN_STAMP
+    unsigned long long tg = 0, tr = 0, tb = 0;
+    const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
+#endif
     for (int c = c0; c < c1; ++c) {
-        const int cn = c + 1 < c1 ? c + 1 : c;  // clamped prefetch: no branch around the loads
-        st.gload(xbatch, cn, tid);
+#ifdef KNN_STAMP
+        const unsigned long long u0 = __builtin_amdgcn_s_memtime();
+#endif
+        const half8 *cur = sbuf + scur * VPC, *nxt = sbuf + snxt * VPC;
+        half8 *wr = sbuf + swr * VPC;
+        const int cload = c + 3 < last ? c + 3 : last;  // clamped: no branch around the loads
+        unsigned w01[RT] = {0u, 0u}, w23[RT] = {0u, 0u};
+        static_for<NG>([&](auto G) {
+            constexpr int g = G.value, t = g / KS1, ks = g % KS1, gp = g + PD;
+            bq[gp % (PD + 1)] = gp < NG ? cur[gp * 64 + lane] : nxt[(gp - NG) * 64 + lane];
+            if constexpr (g < KS1) wr[g * KNN_ST_THREADS + tid] = st.reg[g];
+            else if constexpr (g < 2 * KS1)
+                st.reg[g - KS1] = xbatch[(size_t)cload * VPC + (g - KS1) * KNN_ST_THREADS + tid];
+            if constexpr ((t & 1) == 0) {
 #pragma unroll
-        for (int tt = 0; tt < KNN_ST_TILES; ++tt) ynext[tt] = yb[(cn * KNN_ST_TILES + tt) * 32 + j32];
-        const half8 *cur = sbuf[(c - c0) & 1];
-        const int cand0 = c * KNN_ST_TILES * 32 + j32;
-        f32x16 a0, a1;
-        mfma_pair(cur, 0, a0, a1);
-        const unsigned keep = c > c0 ? ~0u : 0u;  // nothing is pending in the first iteration
-        const unsigned bp0 = signs(pa0, py0) & keep, bp1 = signs(pa1, py1) & keep;
-        mfma_pair(cur, 2, pa0, pa1);
-        const unsigned b0 = signs(a0, ycur[0]), b1 = signs(a1, ycur[1]);
-        rounds(((u64)(b0 | (b1 << 16)) << 32) | (bp0 | (bp1 << 16)), cand0 - 64);
-        py0 = ycur[2];
-        py1 = ycur[3];
-        st.swrite(sbuf[(c - c0 + 1) & 1], tid);
+                for (int rt = 0; rt < RT; ++rt) {
+                    if constexpr (ks == 0) {
 #pragma unroll
-        for (int tt = 0; tt < KNN_ST_TILES; ++tt) ycur[tt] = ynext[tt];
+                        for (int r = 0; r < 16; ++r) accE[rt][r] = 0.0f;
+                    }
+                    accE[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rt][ks], bq[g % (PD + 1)], accE[rt], 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    if constexpr (ks == 0) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) accO[rt][r] = 0.0f;
+                    }
+                    accO[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[rt][ks], bq[g % (PD + 1)], accO[rt], 0, 0, 0);
+                }
+            }
+            // a share of the pending tile's sign packing (tile t - 1; none in the tile's first group: its last MFMAs
+            // are still in the pipe); register 15 first, so that bit r of the tile's half word is register r
+            if constexpr (ks > 0) {
+                constexpr int e0 = (ks - 1) * (RT * 16) / (KS1 - 1), e1 = ks * (RT * 16) / (KS1 - 1);
+#pragma unroll
+                for (int e = e0; e < e1; ++e) {
+                    const int rt = e / 16, r = 15 - e % 16;
+                    if constexpr (t == 0) asm volatile("v_alignbit_b32 %0, %0, %1, 31" : "+v"(w01[rt]) : "v"(accO[rt][r]));   // tile 3 of the chunk before
+                    else if constexpr (t == 1) asm volatile("v_alignbit_b32 %0, %0, %1, 31" : "+v"(w01[rt]) : "v"(accE[rt][r]));  // tile 0
+                    else if constexpr (t == 2) asm volatile("v_alignbit_b32 %0, %0, %1, 31" : "+v"(w23[rt]) : "v"(accO[rt][r]));  // tile 1
+                    else asm volatile("v_alignbit_b32 %0, %0, %1, 31" : "+v"(w23[rt]) : "v"(accE[rt][r]));                         // tile 2
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+#ifdef KNN_STAMP
+        const unsigned long long u1 = __builtin_amdgcn_s_memtime();
+#endif
+        // slots: 0 = tile 0 (+0), 1 = tile 3 of the chunk before (-32), 2 = tile 2 (+64), 3 = tile 1 (+32)
+        rounds(((u64)w23[0] << 32) | w01[0], ((u64)w23[1] << 32) | w01[1], c * KNN_ST_TILES * 32 + j32, 0x0102ff00u);
+        scur = snxt;
+        snxt = swr;
+        swr = swr + 1 == RING ? 0 : swr + 1;
+#ifdef KNN_STAMP
+        const unsigned long long u2 = __builtin_amdgcn_s_memtime();
+#endif
         __syncthreads();
+#ifdef KNN_STAMP
+        const unsigned long long u3 = __builtin_amdgcn_s_memtime();
+        tg += u1 - u0; tr += u2 - u1; tb += u3 - u2;
+#endif
     }
+#ifdef KNN_STAMP
+    if ((blockIdx.x % 197) == 5 && lane == 0)
+        printf("filter blk %d wave %d: prologue %llu, %d chunks: groups %llu rounds %llu barrier %llu per chunk; lpos %d %d\n", (int)blockIdx.x, wave,
+               ts1 - tsA, c1 - c0, tg / (c1 - c0), tr / (c1 - c0), tb / (c1 - c0), lpos[0] + qn[0], lpos[1] + qn[1]);
+#endif
     {
-        const int cand0 = c1 * KNN_ST_TILES * 32 + j32;
-        const unsigned b0 = signs(pa0, py0), b1 = signs(pa1, py1);
-        rounds((u64)(b0 | (b1 << 16)), cand0 - 64);
+        // tile 3 of the last chunk
+        unsigned w[RT] = {0u, 0u};
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 15; r >= 0; --r) w[rt] = __builtin_amdgcn_alignbit(w[rt], __float_as_uint(accO[rt][r]), 31);
+        rounds((u64)(w[0] & 0xffffu), (u64)(w[1] & 0xffffu), (c1 - 1) * KNN_ST_TILES * 32 + 96 + j32, 0u);
     }
-    while (qn > 0) flush(qn < 64 ? qn : 64);
-    if (lane == 0) {
-        lcount[KNN_MAXPARTS * wid + part] = overflow ? 0 : lpos;
-        if (overflow) rbflag[wid] = 1;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        while (qn[rt] > 0) flush(rt, qn[rt] < 64 ? qn[rt] : 64);
+        if (lane == 0 && rb0 + rt < ntiles) {
+            const int wid = b * ntiles + rb0 + rt;
+            lcount[KNN_MAXPARTS * wid + part] = overflow[rt] ? 0 : lpos[rt];
+            if (overflow[rt]) rbflag[wid] = 1;
+        }
     }
 }
 
@@ -1467,7 +1717,7 @@ static KnnWs knn_ws(int B, int C, int N, void *base)
     w.tau0 = (float *)take((size_t)B * npad * sizeof(float));
     w.eps = (float *)take((size_t)B * npad * sizeof(float));
     w.mu = (float *)take((size_t)B * cp * sizeof(float));
-    w.xh = (half8 *)take((size_t)B * npad * cp * sizeof(_Float16));
+    w.xh = (half8 *)take((size_t)B * npad * (cp + 16) * sizeof(_Float16));  // + the augmented slab
     w.lcount = (int *)take((size_t)B * (npad / 32) * KNN_MAXPARTS * sizeof(int));
     w.bmax = (unsigned *)take((size_t)B * 2 * (npad / 32) * sizeof(unsigned));
     w.rbflag = (int *)take((size_t)B * (npad / 32) * sizeof(int));
@@ -1483,7 +1733,7 @@ static void knn_f16_launch(int cap, int parts, const KnnWs &w, const float *x, i
 {
     const dim3 grid(B * (Npad / 32)), block(64);
     prof_begin(PROF_KNN_FILTER, st);
-    hipLaunchKernelGGL((knn_filter16_kernel<CP>), dim3(B * parts * (Npad / (32 * KNN_ST_WAVES))), dim3(KNN_ST_THREADS), 0,
+    hipLaunchKernelGGL((knn_filter16_kernel<CP>), dim3(B * parts * ceil_div(Npad / 32, KNN_ST_ROWS)), dim3(KNN_ST_THREADS), 0,
                        st, w.xh, w.xxc, w.tau0, w.eps, w.bmax, B, Npad, parts, w.lists, w.lcount, w.rbflag);
     prof_end(PROF_KNN_FILTER, st);
     prof_begin(PROF_KNN_REFINE, st);
@@ -1558,7 +1808,7 @@ extern "C" int dgcnn_knn(const float *x, int B, int N, int C, int k, int32_t *id
     if (prepass) {
         // (knn_bound_kernel writes tau0 for every row, padded rows included)
         if (CP >= 16) {
-            const dim3 bgrid(B * parts * (Npad / (32 * KNN_ST_WAVES))), bblock(KNN_ST_THREADS);
+            const dim3 bgrid(B * parts * ceil_div(Npad / 32, KNN_ST_ROWS)), bblock(KNN_ST_THREADS);
             prof_begin(PROF_KNN_BOUND, st);
 #define DG_BOUND16(CP_)                                                                                              \
     hipLaunchKernelGGL((knn_bound16s_kernel<CP_>), bgrid, bblock, 0, st, w.xh, w.xxc, xx, w.bmax, B, Npad, k, parts, \
