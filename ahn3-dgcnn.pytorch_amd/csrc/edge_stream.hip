@@ -54,12 +54,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
                                                           float *__restrict__ usum, uint8_t *__restrict__ hitj,
                                                           FoldSet fs, BnBatchStats fin)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // (visibly uniform)
     const bool neg = WANT_EXT ? (gamma[lane] < 0.0f) : false;
+    // the extreme is tracked on sign-flipped values where gamma < 0: s p + s q is the exact negation of u = p + q (one
+    // fma with s = +-1), so one comparison serves both directions; the sums are flipped back at the end
+    const float sgn = neg ? -1.0f : 1.0f;
     double acc[2] = {0.0, 0.0};
     const PointIter it = point_iter(P, wave, EDGE_WAVES);
     // The pass is latency-bound (index row -> neighbour rows -> arithmetic), so every point's loads are issued
     // as one batch of up to 32 rows, and the next point's index row and TQ row are fetched one point ahead.
+    // Once the loads are batched the vector instructions per gathered row bound it (measured: 12.6 per row, 62 % VALU
+    // issue): now eight -- v_readlane for the row index (the address is scalar arithmetic on it plus the lane offset),
+    // the fma above, three for the fp64 BatchNorm sums, compare + two selects for the first extreme; usum falls out of the fp64 sum (difference of the running sum across the point).
     int pt = it.cur;
     int nv_next = 0;
     float q_next = 0.0f;
@@ -69,10 +75,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     }
     for (; pt < it.end; pt += it.step) {
         const int b = pt / N;
-        // wave-uniform table base + 32-bit element offsets: each row load is v_readlane, one v_lshl_add and a
-        // global_load with scalar base (64-bit address arithmetic per row costs ~10 scalar instructions)
         const float *Pb = TP + (size_t)b * N * EC;
-        const float q = q_next;
+        const float qs = q_next * sgn;
         int nv = nv_next;  // neighbours 0..63 of this point (lane j holds idx[pt][j])
         const int32_t *ip = idx + (size_t)pt * k;
         const int ptn = pt + it.step;
@@ -80,22 +84,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
             nv_next = lane < k ? __builtin_nontemporal_load(&idx[(size_t)ptn * k + lane]) : 0;
             q_next = __builtin_nontemporal_load(&TQ[(size_t)ptn * EC + lane]);
         }
-        // the extreme is tracked on sign-flipped values where gamma < 0 (exact negation), so one comparison serves
-        // both directions
-        const unsigned sgn = neg ? 0x80000000u : 0u;
         float ext = -__builtin_inff();
-        float us = 0.0f;
         int hit = 0;
+        const double acc0_before = acc[0];
         auto row = [&](float pv, int slot) {
-            const float u = pv + q;
+            const float u = __builtin_fmaf(pv, sgn, qs);
             acc[0] += (double)u;
             acc[1] = __builtin_fma((double)u, (double)u, acc[1]);
-            us += u;
             if (WANT_EXT) {
-                const float uf = __uint_as_float(__float_as_uint(u) ^ sgn);
-                const bool better = uf > ext;  // strict: the first edge attaining the extreme wins
-                ext = better ? uf : ext;
-                hit = better ? slot : hit;
+                const bool keep = !(u > ext);  // strict: the first edge attaining the extreme wins
+                ext = keep ? ext : u;
+                hit = keep ? hit : slot;
             }
         };
         for (int j0 = 0; j0 < k; j0 += 64) {
@@ -113,7 +112,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
                         for (int t = 0; t < 8; ++t) {
                             const int tt = j + g * 8 + t < kk ? j + g * 8 + t : kk - 1;
                             const unsigned n = (unsigned)__builtin_amdgcn_readlane(nv, tt);
-                            p[g * 8 + t] = Pb[n * (unsigned)EC + (unsigned)lane];
+                            p[g * 8 + t] = (Pb + (size_t)n * EC)[(unsigned)lane];  // scalar row base + lane offset
                         }
                     }
                 }
@@ -131,12 +130,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
             }
         }
         // streaming outputs bypass the cache hierarchy's retention: the gather table must stay in L2
-        __builtin_nontemporal_store(us, &usum[(size_t)pt * EC + lane]);
+        __builtin_nontemporal_store((float)(acc[0] - acc0_before) * sgn, &usum[(size_t)pt * EC + lane]);
         if (WANT_EXT) {
-            __builtin_nontemporal_store(__uint_as_float(__float_as_uint(ext) ^ sgn), &usel[(size_t)pt * EC + lane]);
+            __builtin_nontemporal_store(ext * sgn, &usel[(size_t)pt * EC + lane]);
             __builtin_nontemporal_store((uint8_t)hit, &hitj[(size_t)pt * EC + lane]);
         }
     }
+    acc[0] *= (double)sgn;
     if (FIN) fold_and_finalize<2, EDGE_WAVES>(acc, fs, fin);
 }
 
