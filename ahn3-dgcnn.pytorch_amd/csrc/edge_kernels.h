@@ -16,7 +16,7 @@ void launch_rowgemm_fwd(const float *x, int C, const float *w1, float *TP, float
 void launch_rowgemm(const float *A0, int K0, const float *A1, int K1, const float *W, int NO, float *Y0, int NO0,
                     float *Y1, int P, hipStream_t st);
 // partial[chunk][m][n] = sum_{p in chunk} A(p, m) X[p][n];  A = [A0 | A1] (M0 + M1 <= 128 columns)
-int wgrad_chunks(int P);
+int wgrad_chunks(int P, int C);
 void launch_wgrad(const float *A0, int M0, const float *A1, int M1, const float *X, int C, int P, float *partial,
                   hipStream_t st);
 // G [128][C] = sum of the partials, then gw1[o][c]:  c < C: G[o][c] - G[64 + o][c];  c >= C: G[64 + o][c - C]

@@ -121,7 +121,7 @@ static BwdWs bwd_ws(const dgcnn_edgeconv_desc *d, void *p)
     w.cc2 = c.take<float>(128);
     w.dR = c.take<float>(P * EC);
     w.dD = c.take<float>(P * EC);
-    w.wg_partial = c.take<float>((size_t)wgrad_chunks((int)P) * 128 * d->C);
+    w.wg_partial = c.take<float>((size_t)wgrad_chunks((int)P, d->C) * 128 * d->C);
     w.cnt = c.take<int>((size_t)d->B * rev_chunks(d->B, d->N, d->k) * d->N);
     w.indeg = c.take<int>(P);
     w.rowptr = c.take<int>(P);
@@ -263,7 +263,7 @@ extern "C" int dgcnn_edgeconv_bwd(const dgcnn_edgeconv_desc *d, const float *x, 
             return 1;
     }
     launch_wgrad(w.dR, EC, w.dD, EC, x, C, P, w.wg_partial, st);
-    launch_finish_dw1(w.wg_partial, wgrad_chunks(P), C, g->gw1, st);
+    launch_finish_dw1(w.wg_partial, wgrad_chunks(P, C), C, g->gw1, st);
     if (g->gx) launch_rowgemm(w.dR, EC, w.dD, EC, s.wcat, C, g->gx, C, nullptr, P, st);
     DG_CHECK_LAUNCH("dgcnn_edgeconv_bwd");
     return 0;

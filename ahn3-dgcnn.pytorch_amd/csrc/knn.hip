@@ -50,18 +50,6 @@
 
 namespace dgcnn {
 
-template <typename F, int... I>
-__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>)
-{
-    (f(std::integral_constant<int, I>{}), ...);
-}
-// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>), fully unrolled with constant indices
-template <int N, typename F>
-__device__ __forceinline__ void static_for(F &&f)
-{
-    static_for_impl(f, std::make_integer_sequence<int, N>{});
-}
-
 constexpr int KNN_ROWPAD = 128;  // query/candidate rows are padded to a multiple of this
 
 typedef unsigned long long u64;

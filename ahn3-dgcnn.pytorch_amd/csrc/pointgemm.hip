@@ -389,74 +389,70 @@ void launch_rowgemm(const float *A0, int K0, const float *A1, int K1, const floa
                            nullptr, 0);
 }
 
-// wgrad_kernel for M0 = M1 = 64, C = 64 (the 64-channel blocks): no operand guards, only the row clamp
-__global__ __launch_bounds__(64) void wgrad_fast64_kernel(const float *__restrict__ A0, const float *__restrict__ A1,
-                                                          const float *__restrict__ X, int P, float *__restrict__ partial)
+// wgrad_kernel for M0 = M1 = 64, C = 64 (the 64-channel blocks): a workgroup of FOUR waves takes 256 points, wave w
+// the 32 output rows w of [A0 | A1]^T X (two accumulator tiles), so a workgroup leaves ONE 128 x 64 partial per 256
+// points.  (One wave per 64 points, the first form, wrote 28 MB of partials at P = 56 000 -- more than the 43 MB the
+// product reads -- and finish_dw1_kernel read them back: 27 + 11 us.)
+constexpr int WGRAD_FAST_POINTS = 256;
+__global__ __launch_bounds__(256) void wgrad_fast64_kernel(const float *__restrict__ A0, const float *__restrict__ A1,
+                                                           const float *__restrict__ X, int P, float *__restrict__ partial)
 {
-    constexpr int MT = 4, NT = 2, UN = 4;
-    const int lane = threadIdx.x, h = lane >> 5, i32 = lane & 31;
-    const int pbeg = blockIdx.x * WGRAD_CHUNK;
-    const int pend = pbeg + WGRAD_CHUNK < P ? pbeg + WGRAD_CHUNK : P;
-    f32x16 acc[MT][NT];
+    constexpr int UN = 8, DEPTH = 2;  // point pairs per step; steps in the register ring (one step of 16 MFMAs ahead; four
+                                      // steps of 8 in flight measured the same: 22.0 against 20.8 us -- the pass is as long
+                                      // as its 43 MB take to arrive)
+    const int lane = threadIdx.x & 63, mt = threadIdx.x >> 6, h = lane >> 5, i32 = lane & 31;
+    const int pbeg = blockIdx.x * WGRAD_FAST_POINTS;
+    const int pend = pbeg + WGRAD_FAST_POINTS < P ? pbeg + WGRAD_FAST_POINTS : P;
+    const float *A = (mt < 2 ? A0 : A1) + (mt & 1) * 32;
+    f32x16 acc[2];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
-    // operands of 8 points per step; the next step's loads are issued before this step's 32 MFMAs (the wave is
-    // alone on its SIMD: without the prefetch every step pays a full load round trip)
-    float a[UN][MT], b[UN][NT], an[UN][MT], bn[UN][NT];
-    auto fetch = [&](int p, float(&fa)[UN][MT], float(&fb)[UN][NT]) {
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
+    float a[DEPTH][UN], b[DEPTH][UN][2];
+    auto fetch = [&](int p, float(&fa)[UN], float(&fb)[UN][2]) {
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int pp = p + 2 * u + h;
             const bool pv = pp < pend;
             const size_t ro = (size_t)(pv ? pp : pbeg) * 64 + i32;  // clamped row: unconditional loads, masked values
-            const float a0 = A0[ro], a1 = A0[ro + 32], a2 = A1[ro], a3 = A1[ro + 32], b0 = X[ro], b1 = X[ro + 32];
-            fa[u][0] = pv ? a0 : 0.0f;
-            fa[u][1] = pv ? a1 : 0.0f;
-            fa[u][2] = pv ? a2 : 0.0f;
-            fa[u][3] = pv ? a3 : 0.0f;
+            const float a0 = A[ro], b0 = X[ro], b1 = X[ro + 32];
+            fa[u] = pv ? a0 : 0.0f;
             fb[u][0] = pv ? b0 : 0.0f;
             fb[u][1] = pv ? b1 : 0.0f;
         }
     };
-    fetch(pbeg, a, b);
-    for (int p = pbeg; p < pend; p += 2 * UN) {
-        fetch(p + 2 * UN, an, bn);  // past the chunk end: all rows masked
 #pragma unroll
-        for (int u = 0; u < UN; ++u)
+    for (int d = 0; d < DEPTH - 1; ++d) fetch(pbeg + d * 2 * UN, a[d], b[d]);
+    static_assert(WGRAD_FAST_POINTS % (DEPTH * 2 * UN) == 0, "whole rounds of DEPTH steps");  // ring slots static
+    for (int p = pbeg; p < pend; p += DEPTH * 2 * UN) {
+        static_for<DEPTH>([&](auto D) {
+            constexpr int d = D.value, dn = (d + DEPTH - 1) % DEPTH;
+            fetch(p + (d + DEPTH - 1) * 2 * UN, a[dn], b[dn]);  // past the chunk end: all rows masked
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][mt], b[u][nt], acc[mt][nt], 0, 0, 0);
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) a[u][mt] = an[u][mt];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) b[u][nt] = bn[u][nt];
-        }
+            for (int u = 0; u < UN; ++u) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[d][u], b[d][u][0], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[d][u], b[d][u][1], acc[1], 0, 0, 0);
+            }
+        });
     }
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                partial[((size_t)blockIdx.x * 128 + mt * 32 + mfma32_row(r, h)) * 64 + nt * 32 + i32] = acc[mt][nt][r];
+        for (int r = 0; r < 16; ++r)
+            partial[((size_t)blockIdx.x * 128 + mt * 32 + mfma32_row(r, h)) * 64 + nt * 32 + i32] = acc[nt][r];
 }
 
-int wgrad_chunks(int P) { return ceil_div(P, WGRAD_CHUNK); }
+// partials of launch_wgrad (the caller sizes the buffer and passes the count to launch_finish_dw1)
+int wgrad_chunks(int P, int C) { return ceil_div(P, C == 64 ? WGRAD_FAST_POINTS : WGRAD_CHUNK); }
 
 void launch_wgrad(const float *A0, int M0, const float *A1, int M1, const float *X, int C, int P, float *partial,
                   hipStream_t st)
 {
-    const dim3 grid(wgrad_chunks(P)), block(64);
-    if (M0 == 64 && M1 == 64 && C == 64) {
-        hipLaunchKernelGGL(wgrad_fast64_kernel, grid, block, 0, st, A0, A1, X, P, partial);
+    // (M0 = M1 = 64 always: the stage widths of the model; C = 64 takes the four-wave kernel)
+    const dim3 grid(wgrad_chunks(P, C)), block(64);
+    if (C == 64) {
+        hipLaunchKernelGGL(wgrad_fast64_kernel, grid, dim3(256), 0, st, A0, A1, X, P, partial);
         return;
     }
     const int mt = ceil_div(M0 + M1, 32), nt = ceil_div(C, 32);
