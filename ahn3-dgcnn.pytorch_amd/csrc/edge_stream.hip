@@ -184,18 +184,20 @@ __global__ __launch_bounds__(256) void bwd_point_kernel(const float *__restrict_
     const float sc = stats[ST_SC + lane], sh = stats[ST_SH + lane];
     double acc[2] = {0.0, 0.0};
     float gmax = 0.0f;
-    // four points in flight per wave (a wave owns ~100 points at B = 32: one load pair per round trip was 66 us)
+    // sixteen points in flight per wave (a wave owns 27 points at B = 8, ~100 at B = 32: one load pair per round trip
+    // was 66 us at B = 32, four pairs 19 us at B = 8 -- seven dependent round trips)
+    constexpr int INF = 16;
     const int stride = gridDim.x * EDGE_WAVES;
-    for (int pt = blockIdx.x * EDGE_WAVES + wave; pt < P; pt += 4 * stride) {
-        float us[4], g4[4];
+    for (int pt = blockIdx.x * EDGE_WAVES + wave; pt < P; pt += INF * stride) {
+        float us[INF], g4[INF];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < INF; ++u) {
             const int p = pt + u * stride < P ? pt + u * stride : pt;  // clamped: the load is unconditional, the value masked
             us[u] = usel[(size_t)p * EC + lane];
             g4[u] = gy[(size_t)p * EC + lane];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < INF; ++u) {
             if (pt + u * stride < P) {  // (uniform; added in point order)
                 const float v = __builtin_fmaf(us[u], sc, sh);
                 const float dv = g4[u] * (v > 0.0f ? 1.0f : slope);

@@ -637,10 +637,13 @@ __device__ __forceinline__ void knn_bound_finish(const float (&m0)[16], const fl
     if (parts == 2) {
         // Candidate halves: each part publishes its 64 sorted class maxima per row (lanes h = 0 the upper 32,
         // h = 1 the lower 32) and knn_bound_merge_kernel finishes the row from both lists.
+        // (k <= 32: the k-th largest of the union lies in the union of the parts' upper 32 -- the lower halves stay home)
         unsigned *mine = exch + (((size_t)b * Npad + rb * 32 + j32) * 2 + part) * 64 + h * 32;
+        if (k > 32 || h == 0) {
 #pragma unroll
-        for (int i = 0; i < 32; i += 4)
-            *reinterpret_cast<uint4 *>(mine + i) = uint4{w[i], w[i + 1], w[i + 2], w[i + 3]};
+            for (int i = 0; i < 32; i += 4)
+                *reinterpret_cast<uint4 *>(mine + i) = uint4{w[i], w[i + 1], w[i + 2], w[i + 3]};
+        }
         return;
     }
     const int sel = (k - 1) & 31;
@@ -808,6 +811,51 @@ __global__ __launch_bounds__(KNN_ST_THREADS, 2) void knn_bound16s_kernel(const h
 // union is the bitonic sequence max(A[i], B[63 - i]); one cross-lane half-cleaner and the in-lane merge sort
 // it.  128 classes per row instead of 64 also tighten the threshold.  One wave = 32 rows, lane (h, j) = half h
 // of row j as in the epilogue of knn_bound16s_kernel.
+// k <= 32: only the parts' upper halves A, B (32 each, descending) were published; the top 32 of their union is the
+// bitonic sequence max(A[i], B[31 - i]), sorted by the in-lane merge.  One lane = one row.
+__global__ __launch_bounds__(64) void knn_bound_merge32_kernel(const unsigned *__restrict__ exch,
+                                                               const float *__restrict__ xxc,
+                                                               const float *__restrict__ xx_raw,
+                                                               const unsigned *__restrict__ bmax, int B, int Npad, int k,
+                                                               float *__restrict__ tau0, float *__restrict__ epsr)
+{
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x % B, rb = blockIdx.x / B;  // rb: group of 64 rows
+    const size_t row = (size_t)b * Npad + rb * 64 + lane;
+    const uint4 *pa = reinterpret_cast<const uint4 *>(exch + (row * 2 + 0) * 64);
+    const uint4 *pb = reinterpret_cast<const uint4 *>(exch + (row * 2 + 1) * 64);
+    unsigned w[32];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint4 va = pa[i], vb = pb[7 - i];  // B reversed: element 31 - (4 i + e) is vb[3 - e]
+        w[4 * i + 0] = va.x > vb.w ? va.x : vb.w;
+        w[4 * i + 1] = va.y > vb.z ? va.y : vb.z;
+        w[4 * i + 2] = va.z > vb.y ? va.z : vb.y;
+        w[4 * i + 3] = va.w > vb.x ? va.w : vb.x;
+    }
+#pragma unroll
+    for (int stride = 16; stride > 0; stride >>= 1) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            if ((i ^ stride) > i) {
+                const unsigned x = w[i], y = w[i ^ stride];
+                w[i] = x > y ? x : y;
+                w[i ^ stride] = x > y ? y : x;
+            }
+        }
+    }
+    unsigned kth = w[0];
+#pragma unroll
+    for (int i = 1; i < 32; ++i) kth = k - 1 == i ? w[i] : kth;
+    const float cmax = batch_max(bmax, b, 0, Npad / 32), rmax = batch_max(bmax, b, 1, Npad / 32);
+    const float vk = __uint_as_float((kth & 0x80000000u) ? (kth & 0x7fffffffu) : ~kth);
+    const float xi = xxc[row], xr = xx_raw[row];
+    const float eps = knn_f16_eps(xi, cmax, xr, rmax);
+    const float t = (vk - xi) - eps;
+    tau0[row] = (t != t) ? -__builtin_inff() : t;  // NaN -> no bound
+    epsr[row] = eps;
+}
+
 __global__ __launch_bounds__(64) void knn_bound_merge_kernel(const unsigned *__restrict__ exch,
                                                              const float *__restrict__ xxc,
                                                              const float *__restrict__ xx_raw,
@@ -1808,7 +1856,10 @@ extern "C" int dgcnn_knn(const float *x, int B, int N, int C, int k, int32_t *id
                 default: DG_BOUND16(128); break;
             }
 #undef DG_BOUND16
-            if (parts == 2)
+            if (parts == 2 && k <= 32)  // (Npad is a multiple of 128)
+                hipLaunchKernelGGL(knn_bound_merge32_kernel, dim3(B * (Npad / 64)), dim3(64), 0, st, w.exch, w.xxc, xx, w.bmax, B,
+                                   Npad, k, w.tau0, w.eps);
+            else if (parts == 2)
                 hipLaunchKernelGGL(knn_bound_merge_kernel, dim3(B * (Npad / 32)), dim3(64), 0, st, w.exch, w.xxc, xx, w.bmax, B,
                                    Npad, k, w.tau0, w.eps);
             prof_end(PROF_KNN_BOUND, st);
