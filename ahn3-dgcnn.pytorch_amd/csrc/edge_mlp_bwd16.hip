@@ -265,7 +265,8 @@ __global__ __launch_bounds__(512) void edge_mlp_bwd16_kernel(
                         const float v = __builtin_fmaf(u, sc1[nt], sh1[nt]);
                         const float d = acc[nt][r] * (v > 0.0f ? un_da1 : un_da1s);
                         const float uhat = __builtin_fmaf(u, rstd1[nt], nmr1[nt]);
-                        dv1[((size_t)pt * k + j0 + row) * EC + nt * 32 + i32] = d;
+                        // (streaming: 430 MB of dv1 must not sweep the TP table out of the XCD's L2: 395 -> 351 us)
+                        __builtin_nontemporal_store(d, &dv1[((size_t)pt * k + j0 + row) * EC + nt * 32 + i32]);
                         dcol[nt] += d;
                         dhat[nt] = __builtin_fmaf(d, uhat, dhat[nt]);
                     }
