@@ -372,7 +372,7 @@ __global__ __launch_bounds__(512) void edge_mlp_bwd_f32_kernel(
                     if (row < kk) {
                         const float d = acc[nt][r] * (ba[nt][r] > 0.0f ? 1.0f : slope);
                         const float uhat = (tileU[row][nt * 32 + i32] - mean1[nt]) * rstd1[nt];
-                        dv1[((size_t)pt * k + j0 + row) * EC + nt * 32 + i32] = d;
+                        __builtin_nontemporal_store(d, &dv1[((size_t)pt * k + j0 + row) * EC + nt * 32 + i32]);
                         dcol[nt] += d;
                         dhat[nt] = __builtin_fmaf(d, uhat, dhat[nt]);
                     }

@@ -593,7 +593,8 @@ __device__ __forceinline__ void rgather_segment(const float *__restrict__ TQ, in
             const int tt = t + u < cnt ? t + u : t;  // clamped: no branch around the loads
             const int i = __builtin_amdgcn_readlane(src, tt);
             q[u] = TQ[(unsigned)i * (unsigned)EC + (unsigned)lane];  // scalar base + 32-bit offset
-            if (DENSE) d[u] = dv[(size_t)__builtin_amdgcn_readlane(ev, tt) * EC + lane];
+            // (dv1 rows are read once: streamed past the L2 that holds the TQ table)
+            if (DENSE) d[u] = __builtin_nontemporal_load(&dv[(size_t)__builtin_amdgcn_readlane(ev, tt) * EC + lane]);
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
