@@ -397,9 +397,8 @@ constexpr int WGRAD_FAST_POINTS = 256;
 __global__ __launch_bounds__(256) void wgrad_fast64_kernel(const float *__restrict__ A0, const float *__restrict__ A1,
                                                            const float *__restrict__ X, int P, float *__restrict__ partial)
 {
-    constexpr int UN = 8, DEPTH = 2;  // point pairs per step; steps in the register ring (one step of 16 MFMAs ahead; four
-                                      // steps of 8 in flight measured the same: 22.0 against 20.8 us -- the pass is as long
-                                      // as its 43 MB take to arrive)
+    constexpr int UN = 4, DEPTH = 4;  // point pairs per step; steps in the register ring (three steps of 8 MFMAs ahead: 22 us;
+                                      // a ring of two steps of 16 measured 32 - 38 us)
     const int lane = threadIdx.x & 63, mt = threadIdx.x >> 6, h = lane >> 5, i32 = lane & 31;
     const int pbeg = blockIdx.x * WGRAD_FAST_POINTS;
     const int pend = pbeg + WGRAD_FAST_POINTS < P ? pbeg + WGRAD_FAST_POINTS : P;
