@@ -26,6 +26,18 @@ __device__ __forceinline__ PointIter point_iter(int P, int wave, int waves_per_w
     it.step = nslots * waves_per_wg;
     return it;
 }
+// the same split over `nblocks` workgroups of a launch that carries other workgroups too (block = index among them)
+__device__ __forceinline__ PointIter point_iter_at(int P, int wave, int waves_per_wg, int block, int nblocks)
+{
+    const int xcd = block & 7, slot = block >> 3, nslots = nblocks >> 3;
+    const int per = (P + 7) >> 3;
+    const int beg = xcd * per;
+    PointIter it;
+    it.end = beg + per < P ? beg + per : P;
+    it.cur = beg + slot * waves_per_wg + wave;
+    it.step = nslots * waves_per_wg;
+    return it;
+}
 static inline int point_grid(int P, int waves_per_wg, int max_slots)
 {
     const int per = (P + 7) / 8;

@@ -38,16 +38,35 @@ void launch_bn_eval_stats(const dgcnn_bn_params &bn, float eps, float *stats, hi
 void launch_edge_out(const float *usel, const float *stats, float slope, int P, float *y, hipStream_t st);
 // last-stage BN backward sums from per-point quantities, finished in the same launch: gbn_w, gbn_b and cc = [c1 | c2]
 // gmax_bits (zero at launch): receives the bits of max |gy . LReLU'| (an atomic max: order-independent)
+struct RevSlotsArgs;
 void launch_bwd_point(const float *gy, const float *usel, const float *stats, float slope, int P, double count,
                       int training, const FoldSet &fs, float *gbn_w, float *gbn_b, float *cc, unsigned *gmax_bits,
-                      hipStream_t st);
+                      const struct RevSlotsArgs *slots, hipStream_t st);
 // Reverse adjacency of the neighbour graph (depends on idx only), every list sorted by edge id.  Scratch: cnt
 // [B * rev_chunks][N]; results: rowptr [P] (list start), indeg [P], segbase [P], pcnt [P] (zeroed), rev [E], alloc [2]
 // (alloc[1] = number of extra (point, segment) pairs), extra [2 (E / REV_SEG + 1)] ints.  The first kernel also zeroes
 // zero_words[0 .. nzero) (which must contain alloc).
 int rev_chunks(int B, int N, int k);
+// with_slots / with_place = false: the caller runs those passes itself -- the list-space pass inside launch_bwd_point's
+// launch (rev_slots_args), the placement with launch_rev_place.
+struct RevSlotsArgs {
+    int N, chunks, P;
+    int *cnt, *rowptr, *indeg, *segbase, *pcnt, *alloc;
+    int2 *extra;
+};
+RevSlotsArgs rev_slots_args(int B, int N, int k, int *cnt, int *indeg, int *rowptr, int *segbase, int *pcnt, int *alloc,
+                            int *extra);
 int launch_rev_build(const int32_t *idx, int B, int N, int k, int *cnt, int *indeg, int *rowptr, int *segbase, int *pcnt,
-                     int32_t *rev, int *alloc, int *extra, int *zero_words, int nzero, hipStream_t st);
+                     int32_t *rev, int *alloc, int *extra, int *zero_words, int nzero, bool with_slots, bool with_place,
+                     hipStream_t st);
+int launch_rev_place(const int32_t *idx, int B, int N, int k, const int *cnt, int32_t *rev, hipStream_t st);
+struct RevPlaceArgs {
+    const int32_t *idx;
+    int N, k, chunks, rows_per, nblocks;  // nblocks = B * chunks
+    const int *cnt;
+    int32_t *rev;
+};
+
 // stage-1 backward as a gather over the reverse lists (see edge_stream.hip): dR and dD are overwritten.
 // dv == NULL: sparse dv from (gy, y, hitj) -- hits [E] x 32 bytes and G [P][64] are scratch; else dense dv [E][64] with
 // dvsum [P][64] = its sums over k.  part0 [P][128], partx [E / REV_SEG + 1][128] floats: segment partials of long lists.

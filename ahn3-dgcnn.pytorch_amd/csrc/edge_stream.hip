@@ -170,6 +170,95 @@ __global__ void edge_out_kernel(const float *__restrict__ usel, const float *__r
     reinterpret_cast<float4 *>(y)[t] = o;
 }
 
+// alloc[0]: list space handed out so far, alloc[1]: number of extra (point, segment) pairs (both zeroed by
+// rev_count_kernel).  Per point: rowptr (list start), indeg, segbase (index of its first pair in `extra`), pcnt = 0 (the
+// arrival counter of its segments in edge_rgather_kernel).
+// (A device function: the pass rides in the launch of bwd_point_kernel -- both are short passes that leave most of the
+// chip idle on their own -- as the workgroups behind that kernel's own; `block` = index among the pass's workgroups.)
+__device__ __forceinline__ void rev_slots_pass(const RevSlotsArgs &a, int block)
+{
+    const int N = a.N, chunks = a.chunks, P = a.P;
+    int *__restrict__ cnt = a.cnt, *__restrict__ rowptr = a.rowptr, *__restrict__ indeg = a.indeg;
+    int *__restrict__ segbase = a.segbase, *__restrict__ pcnt = a.pcnt, *__restrict__ alloc = a.alloc;
+    int2 *__restrict__ extra = a.extra;
+    const int g = block * 256 + threadIdx.x;
+    int deg = 0;
+    int *cb = nullptr;
+    if (g < P) {
+        const int b = g / N, m = g - b * N;
+        cb = cnt + (size_t)b * chunks * N + m;
+        int c = 0;
+        for (; c + 16 <= chunks; c += 16) {  // 16 loads in flight (one workgroup per CU: nothing else hides them)
+            int v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = cb[(size_t)(c + u) * N];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) deg += v[u];
+        }
+        for (; c < chunks; ++c) deg += cb[(size_t)c * N];
+    }
+    const int nseg = deg > REV_SEG ? (deg - 1) / REV_SEG : 0;  // segments beyond the first
+    // exclusive scans of deg and nseg over the workgroup; ONE atomic each on the global counters per workgroup
+    __shared__ int wtot[4][2], wbase[4][2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc_d = deg, inc_s = nseg;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int td = __shfl_up(inc_d, o), ts = __shfl_up(inc_s, o);
+        if (lane >= o) {
+            inc_d += td;
+            inc_s += ts;
+        }
+    }
+    if (lane == 63) {
+        wtot[wave][0] = inc_d;
+        wtot[wave][1] = inc_s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int td = 0, ts = 0;
+        for (int w = 0; w < 4; ++w) {
+            wbase[w][0] = td;
+            wbase[w][1] = ts;
+            td += wtot[w][0];
+            ts += wtot[w][1];
+        }
+        const int bd = td ? atomicAdd(&alloc[0], td) : 0;
+        const int bs = ts ? atomicAdd(&alloc[1], ts) : 0;
+        for (int w = 0; w < 4; ++w) {
+            wbase[w][0] += bd;
+            wbase[w][1] += bs;
+        }
+    }
+    __syncthreads();
+    if (g < P) {
+        int slot = wbase[wave][0] + inc_d - deg;
+        const int sb = wbase[wave][1] + inc_s - nseg;
+        rowptr[g] = slot;
+        indeg[g] = deg;
+        segbase[g] = sb;
+        pcnt[g] = 0;
+        int c = 0;
+        for (; c + 16 <= chunks; c += 16) {
+            int v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = cb[(size_t)(c + u) * N];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                cb[(size_t)(c + u) * N] = slot;
+                slot += v[u];
+            }
+        }
+        for (; c < chunks; ++c) {
+            const int n = cb[(size_t)c * N];
+            cb[(size_t)c * N] = slot;
+            slot += n;
+        }
+        for (int sg = 0; sg < nseg; ++sg) extra[sb + sg] = int2{g, sg + 1};
+    }
+}
+
+
 // ---------------------------------------------------------------------------------------------
 // Backward of the LAST BatchNorm of the block.  Only the arg-max edge of each (point, channel)
 // carries gradient through max-over-k, so  sum dv  and  sum dv * uhat  over all edges reduce to
@@ -177,8 +266,15 @@ __global__ void edge_out_kernel(const float *__restrict__ usel, const float *__r
 // the sums itself (fold.h): gbn_b, gbn_w and the two mean terms cc.
 __global__ __launch_bounds__(256) void bwd_point_kernel(const float *__restrict__ gy, const float *__restrict__ usel,
                                                         const float *__restrict__ stats, float slope, int P,
-                                                        FoldSet fs, BnBackwardSums fin, unsigned *__restrict__ gmax_bits)
+                                                        FoldSet fs, BnBackwardSums fin, unsigned *__restrict__ gmax_bits,
+                                                        int nbp, RevSlotsArgs slots)
 {
+    // workgroups nbp .. : the list-space pass of the reverse adjacency (rev_slots_pass), which only needs rev_count_kernel
+    // before it and nothing of this pass
+    if ((int)blockIdx.x >= nbp) {
+        rev_slots_pass(slots, (int)blockIdx.x - nbp);
+        return;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float mean = stats[ST_MEAN + lane], rstd = stats[ST_RSTD + lane];
     const float sc = stats[ST_SC + lane], sh = stats[ST_SH + lane];
@@ -187,7 +283,7 @@ __global__ __launch_bounds__(256) void bwd_point_kernel(const float *__restrict_
     // sixteen points in flight per wave (a wave owns 27 points at B = 8, ~100 at B = 32: one load pair per round trip
     // was 66 us at B = 32, four pairs 19 us at B = 8 -- seven dependent round trips)
     constexpr int INF = 16;
-    const int stride = gridDim.x * EDGE_WAVES;
+    const int stride = nbp * EDGE_WAVES;
     for (int pt = blockIdx.x * EDGE_WAVES + wave; pt < P; pt += INF * stride) {
         float us[INF], g4[INF];
 #pragma unroll
@@ -224,7 +320,7 @@ __global__ __launch_bounds__(256) void bwd_point_kernel(const float *__restrict_
             if (bits > __hip_atomic_load(gmax_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(gmax_bits, bits);
         }
     }
-    fold_and_finalize<2, EDGE_WAVES>(acc, fs, fin);
+    fold_and_finalize<2, EDGE_WAVES>(acc, fs, fin, nbp);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -321,101 +417,18 @@ __global__ __launch_bounds__(64) void rev_count_kernel(const int32_t *__restrict
     }
 }
 
-// alloc[0]: list space handed out so far, alloc[1]: number of extra (point, segment) pairs (both zeroed by
-// rev_count_kernel).  Per point: rowptr (list start), indeg, segbase (index of its first pair in `extra`), pcnt = 0 (the
-// arrival counter of its segments in edge_rgather_kernel).
-__global__ __launch_bounds__(256) void rev_slots_kernel(int N, int chunks, int P, int *__restrict__ cnt,
-                                                        int *__restrict__ rowptr, int *__restrict__ indeg,
-                                                        int *__restrict__ segbase, int *__restrict__ pcnt,
-                                                        int *__restrict__ alloc, int2 *__restrict__ extra)
-{
-    const int g = blockIdx.x * 256 + threadIdx.x;
-    int deg = 0;
-    int *cb = nullptr;
-    if (g < P) {
-        const int b = g / N, m = g - b * N;
-        cb = cnt + (size_t)b * chunks * N + m;
-        int c = 0;
-        for (; c + 16 <= chunks; c += 16) {  // 16 loads in flight (one workgroup per CU: nothing else hides them)
-            int v[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = cb[(size_t)(c + u) * N];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) deg += v[u];
-        }
-        for (; c < chunks; ++c) deg += cb[(size_t)c * N];
-    }
-    const int nseg = deg > REV_SEG ? (deg - 1) / REV_SEG : 0;  // segments beyond the first
-    // exclusive scans of deg and nseg over the workgroup; ONE atomic each on the global counters per workgroup
-    __shared__ int wtot[4][2], wbase[4][2];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int inc_d = deg, inc_s = nseg;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int td = __shfl_up(inc_d, o), ts = __shfl_up(inc_s, o);
-        if (lane >= o) {
-            inc_d += td;
-            inc_s += ts;
-        }
-    }
-    if (lane == 63) {
-        wtot[wave][0] = inc_d;
-        wtot[wave][1] = inc_s;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int td = 0, ts = 0;
-        for (int w = 0; w < 4; ++w) {
-            wbase[w][0] = td;
-            wbase[w][1] = ts;
-            td += wtot[w][0];
-            ts += wtot[w][1];
-        }
-        const int bd = td ? atomicAdd(&alloc[0], td) : 0;
-        const int bs = ts ? atomicAdd(&alloc[1], ts) : 0;
-        for (int w = 0; w < 4; ++w) {
-            wbase[w][0] += bd;
-            wbase[w][1] += bs;
-        }
-    }
-    __syncthreads();
-    if (g < P) {
-        int slot = wbase[wave][0] + inc_d - deg;
-        const int sb = wbase[wave][1] + inc_s - nseg;
-        rowptr[g] = slot;
-        indeg[g] = deg;
-        segbase[g] = sb;
-        pcnt[g] = 0;
-        int c = 0;
-        for (; c + 16 <= chunks; c += 16) {
-            int v[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = cb[(size_t)(c + u) * N];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                cb[(size_t)(c + u) * N] = slot;
-                slot += v[u];
-            }
-        }
-        for (; c < chunks; ++c) {
-            const int n = cb[(size_t)c * N];
-            cb[(size_t)c * N] = slot;
-            slot += n;
-        }
-        for (int sg = 0; sg < nseg; ++sg) extra[sb + sg] = int2{g, sg + 1};
-    }
-}
-
+// (A device function of one wave; block = index among the pass's B chunks workgroups.)
 template <bool K2>
-__global__ __launch_bounds__(64) void rev_place_kernel(const int32_t *__restrict__ idx, int N, int k, int chunks,
-                                                       int rows_per, const int *__restrict__ cnt,
-                                                       int32_t *__restrict__ rev)
+__device__ __forceinline__ void rev_place_pass(const RevPlaceArgs &a, int block, int *table)
 {
-    extern __shared__ int table[];
-    const int lane = threadIdx.x;
-    // workgroups are dealt round-robin over the 8 XCDs: batch element = blockIdx % B keeps all writers of a batch
+    const int32_t *__restrict__ idx = a.idx;
+    const int N = a.N, k = a.k, chunks = a.chunks, rows_per = a.rows_per;
+    const int *__restrict__ cnt = a.cnt;
+    int32_t *__restrict__ rev = a.rev;
+    const int lane = threadIdx.x & 63;
+    // workgroups are dealt round-robin over the 8 XCDs: batch element = block % B keeps all writers of a batch
     // element's lists (scattered 4-byte stores into one region of `rev`) behind ONE L2, where they merge into whole lines
-    const int B_ = (int)gridDim.x / chunks, b = (int)blockIdx.x % B_, chunk = (int)blockIdx.x / B_;
+    const int B_ = a.nblocks / chunks, b = block % B_, chunk = block / B_;
     const int row = b * chunks + chunk;  // this chunk's row of cnt
     const int *first = cnt + (size_t)row * N;
     const int r0 = chunk * rows_per, r1 = r0 + rows_per < N ? r0 + rows_per : N;
@@ -447,6 +460,13 @@ __global__ __launch_bounds__(64) void rev_place_kernel(const int32_t *__restrict
     }
 }
 
+template <bool K2>
+__global__ __launch_bounds__(64) void rev_place_kernel(RevPlaceArgs a)
+{
+    extern __shared__ int table[];
+    rev_place_pass<K2>(a, (int)blockIdx.x, table);
+}
+
 int rev_chunks(int B, int N, int k)
 {
     (void)k;
@@ -463,8 +483,16 @@ int rev_chunks(int B, int N, int k)
     return c < 1 ? 1 : c;
 }
 
+RevSlotsArgs rev_slots_args(int B, int N, int k, int *cnt, int *indeg, int *rowptr, int *segbase, int *pcnt, int *alloc,
+                            int *extra)
+{
+    return RevSlotsArgs{N, rev_chunks(B, N, k), B * N, cnt, rowptr, indeg, segbase, pcnt, alloc, reinterpret_cast<int2 *>(extra)};
+}
+__global__ __launch_bounds__(256) void rev_slots_kernel(RevSlotsArgs a) { rev_slots_pass(a, (int)blockIdx.x); }
+
 int launch_rev_build(const int32_t *idx, int B, int N, int k, int *cnt, int *indeg, int *rowptr, int *segbase, int *pcnt,
-                     int32_t *rev, int *alloc, int *extra, int *zero_words, int nzero, hipStream_t st)
+                     int32_t *rev, int *alloc, int *extra, int *zero_words, int nzero, bool with_slots, bool with_place,
+                     hipStream_t st)
 {
     DG_REQUIRE(N <= REV_MAX_N, "dgcnn: N=%d > %d unsupported in the backward", N, REV_MAX_N);
     const int P = B * N, chunks = rev_chunks(B, N, k), rows_per = ceil_div(N, chunks);
@@ -483,12 +511,19 @@ int launch_rev_build(const int32_t *idx, int B, int N, int k, int *cnt, int *ind
     else
         hipLaunchKernelGGL((rev_count_kernel<false>), dim3(B * chunks), dim3(64), lds, st, idx, N, k, chunks, rows_per, cnt,
                            zero_words, nzero);
-    hipLaunchKernelGGL(rev_slots_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, st, N, chunks, P, cnt, rowptr, indeg, segbase,
-                       pcnt, alloc, reinterpret_cast<int2 *>(extra));
-    if (k > 64)
-        hipLaunchKernelGGL((rev_place_kernel<true>), dim3(B * chunks), dim3(64), lds, st, idx, N, k, chunks, rows_per, cnt, rev);
-    else
-        hipLaunchKernelGGL((rev_place_kernel<false>), dim3(B * chunks), dim3(64), lds, st, idx, N, k, chunks, rows_per, cnt, rev);
+    if (!with_slots) return 0;  // (the caller carries the list-space pass in its next launch: launch_bwd_point)
+    hipLaunchKernelGGL(rev_slots_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, st, rev_slots_args(B, N, k, cnt, indeg, rowptr, segbase, pcnt, alloc, extra));
+    if (!with_place) return 0;
+    return launch_rev_place(idx, B, N, k, cnt, rev, st);
+}
+
+int launch_rev_place(const int32_t *idx, int B, int N, int k, const int *cnt, int32_t *rev, hipStream_t st)
+{
+    const int chunks = rev_chunks(B, N, k), rows_per = ceil_div(N, chunks);
+    const size_t lds = (size_t)N * sizeof(int);
+    const RevPlaceArgs a{idx, N, k, chunks, rows_per, B * chunks, cnt, rev};
+    if (k > 64) hipLaunchKernelGGL((rev_place_kernel<true>), dim3(B * chunks), dim3(64), lds, st, a);
+    else hipLaunchKernelGGL((rev_place_kernel<false>), dim3(B * chunks), dim3(64), lds, st, a);
     return 0;
 }
 
@@ -828,6 +863,9 @@ int launch_edge_bwd(const float *TP, const float *TQ, int B, int N, int k, const
 {
     const int P = B * N;
     const dim3 grid(stream_grid(P)), block(256);
+    // (measured: the placement pass of the reverse adjacency as extra workgroups of this launch -- as the list-space
+    // pass rides with bwd_point -- gains nothing: 47.9 us against 28.0 + 17.3; its N-int LDS table is then reserved by
+    // every workgroup of the launch and thins out the point pass)
     if (dv)
         hipLaunchKernelGGL((edge_point_bwd_kernel<true>), grid, block, 0, st, TQ, k, P, stats, cc, slope, gy, y, hitj, usum,
                            dvsum, (HitRec *)hits, G, dD);
@@ -922,12 +960,16 @@ void launch_edge_out(const float *usel, const float *stats, float slope, int P, 
 
 void launch_bwd_point(const float *gy, const float *usel, const float *stats, float slope, int P, double count,
                       int training, const FoldSet &fs, float *gbn_w, float *gbn_b, float *cc, unsigned *gmax_bits,
-                      hipStream_t st)
+                      const RevSlotsArgs *slots, hipStream_t st)
 {
     int grid = ceil_div(P, EDGE_WAVES * 8);
     if (grid > 512) grid = 512;
     const BnBackwardSums fin{count, training, gbn_w, gbn_b, cc};
-    hipLaunchKernelGGL(bwd_point_kernel, dim3(grid), dim3(256), 0, st, gy, usel, stats, slope, P, fs, fin, gmax_bits);
+    // (slots: the list-space pass of the reverse adjacency rides behind this pass's workgroups, see rev_slots_pass)
+    const RevSlotsArgs none{0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const int extra_wgs = slots ? ceil_div(slots->P, 256) : 0;
+    hipLaunchKernelGGL(bwd_point_kernel, dim3(grid + extra_wgs), dim3(256), 0, st, gy, usel, stats, slope, P, fs, fin, gmax_bits,
+                       grid, slots ? *slots : none);
 }
 
 void launch_graph_feature_fwd(const float *x, const int32_t *idx, int B, int N, int C, int k, float *out,

@@ -238,19 +238,24 @@ extern "C" int dgcnn_edgeconv_bwd(const dgcnn_edgeconv_desc *d, const float *x, 
 
     // (measured: building the lists on a side stream, concurrently with the BatchNorm-backward sums and the
     // per-point pass, costs more in cross-stream barriers than it hides: 0.776 ms against 0.725 ms per step)
+    // The reverse adjacency: its counting pass first (it also zeroes the call's counters), its list-space pass inside the
+    // launch of bwd_point (two short passes that leave most of the chip idle on their own), then the placement.
     if (launch_rev_build(idx, d->B, N, k, w.cnt, w.indeg, w.rowptr, w.segbase, w.pcnt, w.rev, w.zero + Z_ALLOC, w.extra,
-                         w.zero, Z_WORDS, st))
+                         w.zero, Z_WORDS, false, false, st))
         return 1;
+    const RevSlotsArgs slots = rev_slots_args(d->B, N, k, w.cnt, w.indeg, w.rowptr, w.segbase, w.pcnt, w.zero + Z_ALLOC, w.extra);
     const FoldSet fsa{w.fa.rec, w.fa.folded, w.zero + Z_FOLD_A}, fsb{w.fb.rec, w.fb.folded, w.zero + Z_FOLD_B};
     if (d->n_stage == 1) {
-        launch_bwd_point(gy, s.usel, s.stats1, d->slope, P, E, d->training, fsa, g->gbn1_w, g->gbn1_b, w.cc1, nullptr, st);
+        launch_bwd_point(gy, s.usel, s.stats1, d->slope, P, E, d->training, fsa, g->gbn1_w, g->gbn1_b, w.cc1, nullptr, &slots, st);
+        if (launch_rev_place(idx, d->B, N, k, w.cnt, w.rev, st)) return 1;
         if (launch_edge_bwd(s.TP, s.TQ, d->B, N, k, s.stats1, w.cc1, d->slope, gy, y, s.hitj, s.usum, nullptr, nullptr,
                             w.rowptr, w.indeg, w.segbase, w.pcnt, w.rev, w.zero + Z_ALLOC, w.extra, w.hits, w.G, w.part0,
                             w.partx, w.dR, w.dD, st))
             return 1;
     } else {
         launch_bwd_point(gy, s.usel, s.stats2, d->slope, P, E, d->training, fsa, g->gbn2_w, g->gbn2_b, w.cc2,
-                         reinterpret_cast<unsigned *>(w.zero + Z_GMAX), st);
+                         reinterpret_cast<unsigned *>(w.zero + Z_GMAX), &slots, st);
+        if (launch_rev_place(idx, d->B, N, k, w.cnt, w.rev, st)) return 1;
         const BnBackwardSums fin1{E, d->training, g->gbn1_w, g->gbn1_b, w.cc1};
         const FoldSet fsc{w.fb.rec, w.fb.folded, w.zero + Z_FOLD_C};
         launch_edge_mlp_bwd(s.TP, s.TQ, idx, N, k, P, s.stats1, s.stats2, w.cc2, d->w2, d->slope, d->training, gy, y,
@@ -318,7 +323,7 @@ extern "C" int dgcnn_graph_feature_bwd(const float *gout, const int32_t *idx, in
                w.bytes);
     hipStream_t st = (hipStream_t)stream;
     if (launch_rev_build(idx, B, N, k, w.cnt, w.indeg, w.rowptr, w.segbase, w.pcnt, w.rev, w.zero + Z_ALLOC, w.extra, w.zero,
-                         Z_WORDS, st))
+                         Z_WORDS, true, true, st))
         return 1;
     launch_graph_feature_bwd(gout, w.rowptr, w.indeg, w.rev, B, N, C, k, gx, st);
     DG_CHECK_LAUNCH("graph_feature_bwd_kernel");

@@ -92,14 +92,16 @@ __device__ __forceinline__ void fold_span(const double *src, int n, double (*red
 // Called by ALL threads of every workgroup (NW waves) at the end of a statistics pass; v = this thread's partial sums
 // for channel `lane`.  fin(total, channel) runs once per launch, on the first wave of the last workgroup to arrive.
 // `red` ([NW][NV][64] doubles) and `role` (one int) are LDS scratch of the caller (free at that point).
+// nrec_in: number of workgroups that take part (the first nrec_in of the launch) when the launch also carries
+// workgroups of another pass; < 0: the whole grid.
 template <int NV, int NW, typename Fin>
 __device__ __forceinline__ void fold_and_finalize(const double (&v)[NV], const FoldSet fs, Fin fin,
-                                                  double (*red)[NV][64], int *role)
+                                                  double (*red)[NV][64], int *role, int nrec_in = -1)
 {
     static_assert(FOLD_GS % NW == 0, "waves per workgroup");
     int &s_role = *role;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nrec = (int)gridDim.x, ngroups = (nrec + FOLD_GS - 1) / FOLD_GS, g = (int)blockIdx.x / FOLD_GS;
+    const int nrec = nrec_in < 0 ? (int)gridDim.x : nrec_in, ngroups = (nrec + FOLD_GS - 1) / FOLD_GS, g = (int)blockIdx.x / FOLD_GS;
     const int members = nrec - g * FOLD_GS < FOLD_GS ? nrec - g * FOLD_GS : FOLD_GS;
 #pragma unroll
     for (int i = 0; i < NV; ++i) red[wave][i][lane] = v[i];
@@ -135,11 +137,11 @@ __device__ __forceinline__ void fold_and_finalize(const double (&v)[NV], const F
 }
 
 template <int NV, int NW, typename Fin>
-__device__ __forceinline__ void fold_and_finalize(const double (&v)[NV], const FoldSet fs, Fin fin)
+__device__ __forceinline__ void fold_and_finalize(const double (&v)[NV], const FoldSet fs, Fin fin, int nrec_in = -1)
 {
     __shared__ double red[NW][NV][64];
     __shared__ int role;
-    fold_and_finalize<NV, NW, Fin>(v, fs, fin, red, &role);
+    fold_and_finalize<NV, NW, Fin>(v, fs, fin, red, &role, nrec_in);
 }
 
 // ---- the two finalizers of the EdgeConv block ------------------------------------------------------------------------
