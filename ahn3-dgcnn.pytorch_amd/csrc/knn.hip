@@ -1128,7 +1128,13 @@ __global__ __launch_bounds__(64, 2) void knn_kernel(const float *__restrict__ xt
 // result never depends on the filter.
 constexpr int KNN_QCAP = 256;     // LDS staging ring of the filter kernel (entries: row << 27 | candidate)
 constexpr int KNN_MAXPARTS = 4;   // candidate parts of the filter (list segments per row block)
-constexpr int KNN_LISTCAP = 4096;  // survivor list per 32-row block in HBM (128 per row on average)
+// survivor list per (32-row block, candidate part) in HBM: 4096 entries = 128 per row, so that a row block whose
+// neighbours all lie in ONE candidate part (spatially ordered points: the neighbours of consecutive rows are close in
+// index) fits, with room for the filter's slack on low-dimensional data (points on a sheet: the fp16 error bound is of
+// the order of the neighbour distances and about twice the usual survivors pass).  Only written entries cost traffic.
+// (One list of 4096 entries cut into `parts` segments, the first form, overflowed -- and fell back to the exact fp32
+// kernel -- as soon as ~1000 survivors of a block met in one quarter of the candidates.)
+constexpr int KNN_LISTCAP = 4096;
 
 template <int CP>
 __global__ __launch_bounds__(KNN_ST_THREADS, 2) void knn_filter16_kernel(const half8 *__restrict__ xh, const float *__restrict__ xxc,
@@ -1150,7 +1156,7 @@ __global__ __launch_bounds__(KNN_ST_THREADS, 2) void knn_filter16_kernel(const h
     const int rb0 = (blockIdx.x / B / parts) * KNN_ST_ROWS + wave * RT;  // this wave's first row block
     const int ntiles = Npad / 32, nchunks = ntiles / KNN_ST_TILES;
     const int c0 = part * nchunks / parts, c1 = (part + 1) * nchunks / parts;
-    const int listcap = KNN_LISTCAP / parts;
+    const int listcap = KNN_LISTCAP;
 #ifdef KNN_STAMP
     const unsigned long long tsA = __builtin_amdgcn_s_memtime();
 #endif
@@ -1192,7 +1198,7 @@ __global__ __launch_bounds__(KNN_ST_THREADS, 2) void knn_filter16_kernel(const h
         overflow[rt] = false;
     }
     auto flush = [&](int rt, int n) {  // move the oldest n (<= 64) staged entries of row block rt to its list
-        unsigned *list = lists + (size_t)(b * ntiles + rb0 + rt) * KNN_LISTCAP + part * listcap;
+        unsigned *list = lists + ((size_t)(b * ntiles + rb0 + rt) * KNN_MAXPARTS + part) * KNN_LISTCAP;
         if (lpos[rt] + n > listcap) {
             overflow[rt] = true;
         } else if (lane < n) {
@@ -1389,11 +1395,11 @@ __global__ __launch_bounds__(256) void knn_filter32_kernel(const float *__restri
     if (rb >= ntiles) return;
     const int c0 = part * nchunks / parts, c1 = (part + 1) * nchunks / parts;
     const int wid = b * ntiles + rb;
-    const int listcap = KNN_LISTCAP / parts;
+    const int listcap = KNN_LISTCAP;
     const int q0 = rb * 32;
     const vecf *xtb = reinterpret_cast<const vecf *>(xt + (size_t)b * Npad * CP);
     const float *yb = xx + (size_t)b * Npad;
-    unsigned *list = lists + (size_t)wid * KNN_LISTCAP + part * listcap;
+    unsigned *list = lists + ((size_t)wid * KNN_MAXPARTS + part) * KNN_LISTCAP;
     unsigned *queue = queues[wave];
 
     const vecf a = xtb[(size_t)rb * 64 + lane];
@@ -1522,9 +1528,9 @@ __global__ __launch_bounds__(64) void knn_refine_kernel(const float *__restrict_
     const float *xxb = xx + (size_t)b * Npad;
     const float *xraw = x + (size_t)b * N * C;
     // the survivor list comes in `parts` segments (one per candidate part of the filter)
-    const unsigned *list = lists + (size_t)wid * KNN_LISTCAP;
+    const unsigned *list = lists + (size_t)wid * KNN_MAXPARTS * KNN_LISTCAP;
     // (entry e of the concatenation lives in segment p at list[p * listcap + e - (entries before segment p)])
-    const int listcap = KNN_LISTCAP / parts;
+    const int listcap = KNN_LISTCAP;
     int ncum[KNN_MAXPARTS + 1];
     ncum[0] = 0;
 #pragma unroll
@@ -1758,7 +1764,7 @@ static KnnWs knn_ws(int B, int C, int N, void *base)
     w.bmax = (unsigned *)take((size_t)B * 2 * (npad / 32) * sizeof(unsigned));
     w.rbflag = (int *)take((size_t)B * (npad / 32) * sizeof(int));
     w.exch = (unsigned *)take(cp >= 16 ? (size_t)B * npad * 2 * 64 * sizeof(unsigned) : 0);
-    w.lists = (unsigned *)take((size_t)B * (npad / 32) * KNN_LISTCAP * sizeof(unsigned));
+    w.lists = (unsigned *)take((size_t)B * (npad / 32) * KNN_MAXPARTS * KNN_LISTCAP * sizeof(unsigned));
     w.bytes = off;
     return w;
 }
