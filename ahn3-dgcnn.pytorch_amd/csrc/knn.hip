@@ -210,6 +210,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // constants and helper of the augmented K slab of the fp16 streams (see "fp16 streams" below)
 constexpr float KNN_AUG_K1 = 32768.0f, KNN_AUG_K2 = 16.0f, KNN_AUG_K3 = 0.0078125f;
+// per-pair slack of the fp16 dot product: 2 * 2^-10 * 1.01 = 1.973e-3, with room for the fp16 rounding of its two factors
+constexpr float KNN_PAIR_SLACK = 2.1e-3f;
 constexpr float KNN_PAD_NORM = 1073741824.0f;  // 2^30: the "norm" of a padding candidate (never a neighbour, no inf - inf)
 constexpr float KNN_F16_CMAX = 1.0e8f;         // largest centred norm the fp16 streams accept (|T| stays below 2^31)
 
@@ -352,6 +354,7 @@ __global__ __launch_bounds__(256) void knn_prep16_kernel(const float *__restrict
             out[3] = (_Float16)KNN_AUG_K1;
             out[4] = (_Float16)KNN_AUG_K2;
             out[5] = (_Float16)KNN_AUG_K3;
+            out[6] = (_Float16)(q0 + tid < N ? __builtin_sqrtf(yys[tid]) : 0.0f);  // candidate factor of the pair slack
         }
         xh[((size_t)b * (Npad / 32) + tile) * (KS + 1) * 64 + KS * 64 + tid] = out;
     }
@@ -395,6 +398,9 @@ __device__ __forceinline__ void bitonic32_sort(unsigned &key, int lane)
 // centred features (d16 = fp32-accumulated fp16 MFMA dot, yy = fp32 centred norms) and pd32 is the oracle's
 // fp32 value on the raw features.  Both approximate the real -||x_i - x_l||^2:
 //   fp16 rounding of both operands (rel. 2^-11 each) + fp32 accumulation: |2 d16 - 2 y_i.y_l| <= 2 * 2^-10 * 1.01 * sqrt(yy_i yy_l)
+//       -- this one, the largest, is a rank-1 term and rides PER PAIR in the matrix product (KNN_PAIR_SLACK sqrt(yy_i)
+//       sqrt(yy_l), augmented slab): against the worst candidate's norm (sqrt(yy_i cmax), the first form) it is what
+//       decides the number of survivors on data whose neighbour distances are small against its norms
 //   fp16 subnormals (abs. 2^-25 per element):                              <= 1e-6 (sqrt(yy_i) + sqrt(yy_l))
 //   fp32 evaluation of yy; the norms and the filter threshold ride in the matrix product (augmented slab, see
 //   "fp16 streams"), i.e. in up to ~90 fp32 additions of partial sums below 4 (yy_i + yy_l) in magnitude:
@@ -404,8 +410,7 @@ __device__ __forceinline__ void bitonic32_sort(unsigned &key, int lane)
 // with yy_l <= cmax, xx_l <= rmax (per batch element).  Worst-case bounds, not estimates.
 __device__ __forceinline__ float knn_f16_eps(float yy_i, float cmax, float xx_i, float rmax)
 {
-    return 2.1e-3f * __builtin_sqrtf(yy_i * cmax) + 1e-6f * (__builtin_sqrtf(yy_i) + __builtin_sqrtf(cmax)) +
-           4e-5f * (yy_i + cmax) + 8e-6f * (xx_i + rmax) + 1e-9f;
+    return 1e-6f * (__builtin_sqrtf(yy_i) + __builtin_sqrtf(cmax)) + 4e-5f * (yy_i + cmax) + 8e-6f * (xx_i + rmax) + 1e-9f;
 }
 
 // Threshold pre-pass for small C (CP = 4, 8) in exact fp32.  One wave = RT x 32 query rows; xop are the fp32 tiles
@@ -531,11 +536,11 @@ __global__ __launch_bounds__(64) void knn_bound_kernel(const void *__restrict__ 
 // into the matrix product, so that the accumulator IS the quantity the epilogue tests -- no per-element fma / sub
 // (packed fp32 VALU beside MFMAs is an anti-lever on gfx950, and two VALU instructions per accumulator register made the
 // vector pipe, not the matrix pipe, the bound of both streams):
-//   candidate side (stored in xh by knn_prep16_kernel, lanes h = 0):  { p1, p2, p3, K1, K2, K3, 0, 0 }
-//   query side (built by the stream kernels, lanes h = 0):             { K1, K2, K3, g1, g2, g3, 0, 0 }
+//   candidate side (stored in xh by knn_prep16_kernel, lanes h = 0):  { p1, p2, p3, K1, K2, K3, sqrt(yy_l), 0 }
+//   query side (built by the stream kernels, lanes h = 0):             { K1, K2, K3, g1, g2, g3, +-c sqrt(yy_i), 0 }
 // with K = (2^15, 2^4, 2^-7), (p1, p2, p3) = knn_split3(yy_l) the centred norm of the candidate and (g1, g2, g3) =
 // knn_split3(T_i) a per-row constant (0 in the pre-pass, the filter threshold in the filter).  With the query features
-// scaled by -2 (exact) the accumulator is  acc = T_i + yy_l - 2 d16(i, l) = T_i - t(i, l).
+// scaled by -2 (exact) the accumulator is  acc = T_i + yy_l - 2 d16(i, l) +- c sqrt(yy_i yy_l) = T_i - (t(i, l) -+ slack(i, l)).
 constexpr int KNN_ST_TILES = 4;  // candidate tiles per staged chunk (Npad / 32 is a multiple of 4)
 constexpr int KNN_ST_WAVES = 4;  // waves (32-row tiles) per workgroup of the fp16 streams (2 measured slower: 105 vs 98 us)
 constexpr int KNN_ST_THREADS = KNN_ST_WAVES * 64;
@@ -561,8 +566,10 @@ struct Stage16 {
 };
 
 // query-side operand of a wave: the row tile's features times -2 and the augmented slab with the row constant T
+// cs: the row's factor of the per-pair slack, +-KNN_PAIR_SLACK sqrt(yy_i) (+: the pre-pass lowers every candidate's
+// value by its slack; -: the filter raises it), 0 for padding rows
 template <int KS1>
-__device__ __forceinline__ void knn_stream_a(const half8 *__restrict__ xbatch, int rb, int lane, float T, half8 (&a)[KS1])
+__device__ __forceinline__ void knn_stream_a(const half8 *__restrict__ xbatch, int rb, int lane, float T, float cs, half8 (&a)[KS1])
 {
 #pragma unroll
     for (int ks = 0; ks < KS1 - 1; ++ks) a[ks] = xbatch[((size_t)rb * KS1 + ks) * 64 + lane] * (_Float16)(-2.0f);
@@ -577,6 +584,7 @@ __device__ __forceinline__ void knn_stream_a(const half8 *__restrict__ xbatch, i
         aug[3] = g.p1;
         aug[4] = g.p2;
         aug[5] = g.p3;
+        aug[6] = (_Float16)cs;
     }
     a[KS1 - 1] = aug;
 }
@@ -698,7 +706,11 @@ __global__ __launch_bounds__(KNN_ST_THREADS, 2) void knn_bound16s_kernel(const h
 #endif
     half8 a[RT][KS1];
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) knn_stream_a<KS1>(xbatch, rb0 + rt < ntiles ? rb0 + rt : ntiles - 1, lane, 0.0f, a[rt]);
+    for (int rt = 0; rt < RT; ++rt) {
+        const int rbc = rb0 + rt < ntiles ? rb0 + rt : ntiles - 1;
+        const float yy = yb[rbc * 32 + (lane & 31)];  // (+inf for padding rows)
+        knn_stream_a<KS1>(xbatch, rbc, lane, 0.0f, yy < KNN_PAD_NORM ? KNN_PAIR_SLACK * __builtin_sqrtf(yy) : 0.0f, a[rt]);
+    }
     // class minima of acc = yy_l - 2 d16 = -t: even candidate tiles feed m0, odd ones m1 (64 classes per row with the
     // 32 candidate lanes)
     float m0[RT][16], m1[RT][16];
@@ -1186,7 +1198,8 @@ __global__ __launch_bounds__(KNN_ST_THREADS, 2) void knn_filter16_kernel(const h
         const float v = (tau - epsr[(size_t)b * Npad + row]) + yy;
         const float thr = v - (__builtin_fabsf(v) + __builtin_fabsf(tau) + yy) * 2.4e-7f;
         // padding rows (yy = +inf) give NaN: nothing may pass there (T = +inf: the accumulator is +inf)
-        knn_stream_a<KS1>(xbatch, rbc, lane, (thr != thr || !real) ? __builtin_inff() : thr, a[rt]);
+        knn_stream_a<KS1>(xbatch, rbc, lane, (thr != thr || !real) ? __builtin_inff() : thr,
+                          yy < KNN_PAD_NORM ? -KNN_PAIR_SLACK * __builtin_sqrtf(yy) : 0.0f, a[rt]);
     }
 
     // staged survivors: a ring in LDS per row block (no data movement on flush), entries already in the HBM list
