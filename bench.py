@@ -306,9 +306,12 @@ def run_block(args, rank, world, dev):
     # Algorithmic work of one launch of each large kernel.
     work = {
         "knn_bound16s_kernel": ("mfma", knn_flops, PEAK_F16_MFMA_TFLOPS,
-                                "all B N^2 pairs once on fp16 MFMA (threshold pre-pass), 2 B N^2 C flops"),
+                                "all B N^2 pairs once on fp16 MFMA (threshold pre-pass), 2 B N^2 C flops; the kernel executes "
+                                "(C + 16) / C of that: one extra 16-wide K slab carries the norms, the threshold and the per-pair "
+                                "slack, so that the accumulator is the tested quantity (DESIGN.md section 5)"),
         "knn_filter16_kernel": ("mfma", knn_flops, PEAK_F16_MFMA_TFLOPS,
-                                "all B N^2 pairs once on fp16 MFMA (exact filter), 2 B N^2 C flops"),
+                                "all B N^2 pairs once on fp16 MFMA (exact filter), 2 B N^2 C flops; executed (C + 16) / C of that "
+                                "(augmented K slab, as the pre-pass)"),
         "knn_refine_kernel": ("l2-gather", E * (4.0 * C + 4 + 4 + 4), PEAK_L2_GATHER_GBS,
                               "exact fp32 distance of at least the k winners of every row: one C-float row, its norm and "
                               "its list entry per winner, the index written; rows come from L2 (latency / VALU chain bound)"),
