@@ -1,4 +1,5 @@
 #!/bin/bash
+# dev helper: SQ / LDS counters of the two fp16 kNN streams (three --pmc passes).  usage: scripts/pmc_knn_streams.sh TAG
 export TMPDIR=/tmp
 OUT=gpurun_out/pmc_knn_$1; shift
 rm -rf $OUT; mkdir -p $OUT

@@ -1,4 +1,5 @@
 #!/bin/bash
+# dev helper: per-kernel statistics of the configs[3] training step (rocprofv3 --stats).  usage: scripts/train_kernels.sh TAG
 export TMPDIR=/tmp
 OUT=gpurun_out/train_prof_$1
 rm -rf $OUT; mkdir -p $OUT
