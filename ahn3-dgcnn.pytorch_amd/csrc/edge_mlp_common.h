@@ -30,7 +30,7 @@ __device__ __forceinline__ void gather_rows(const float *__restrict__ Pb, int nv
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
                 const int tt = g * 8 + t < kk ? g * 8 + t : kk - 1;
-                p[g * 8 + t] = Pb[(unsigned)__builtin_amdgcn_readlane(nv, tt) * (unsigned)EC + (unsigned)lane];
+                p[g * 8 + t] = (Pb + (size_t)(unsigned)__builtin_amdgcn_readlane(nv, tt) * EC)[(unsigned)lane];  // scalar row base
             }
         }
     }
