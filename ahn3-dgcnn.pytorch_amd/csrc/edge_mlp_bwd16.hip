@@ -86,6 +86,8 @@ __global__ __launch_bounds__(512) void edge_mlp_bwd16_kernel(
     __shared__ __attribute__((aligned(16))) unsigned w2w[64][TSTR];  // {hi | lo} of sW W2 [co][ci]
     __shared__ __attribute__((aligned(16))) float tiles[MLP_BWD_WAVES][2][32][TSTR];
     __shared__ float s_red[MLP_BWD_WAVES];
+    __shared__ float cst[4][64];  // per-channel constants of the last epilogue (rstd1, -mean1 rstd1, sc1, sh1): read there,
+                                  // not held in eight registers through the three products (the kernel spills)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, i32 = lane & 31;
     unsigned(*tileA)[TSTR] = reinterpret_cast<unsigned(*)[TSTR]>(tiles[wave][0]);  // a1' words, then du2' words
     float(*tileU)[TSTR] = tiles[wave][1];                                         // u1 [edge][ci]
@@ -106,19 +108,22 @@ __global__ __launch_bounds__(512) void edge_mlp_bwd16_kernel(
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) scmax = fmaxf(scmax, __shfl_xor(scmax, o));
     const float sD = scale_to(__uint_as_float(*gmax_bits) * scmax, 10);
+    if (threadIdx.x < 64) {
+        const float r = stats1[ST_RSTD + threadIdx.x];
+        cst[0][threadIdx.x] = r;
+        cst[1][threadIdx.x] = -stats1[ST_MEAN + threadIdx.x] * r;  // uhat1 = fma(u, rstd, -mean rstd)
+        cst[2][threadIdx.x] = stats1[ST_SC + threadIdx.x];
+        cst[3][threadIdx.x] = stats1[ST_SH + threadIdx.x];
+    }
     __syncthreads();
 
     // gather-phase constants (lane = channel) and accumulator-layout constants (lane (n, h) = channel nt 32 + n)
     // (LeakyReLU is positively homogeneous: a1' = 2^8 a1 = LReLU(2^8 sc1 u + 2^8 sh1))
     const float sc1g = stats1[ST_SC + lane] * MB_SA, sh1g = stats1[ST_SH + lane] * MB_SA;
-    float nmr1[2], rstd1[2], sc1[2], sh1[2], sc2[2], cA[2], cB[2];
+    float sc2[2], cA[2], cB[2];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int c = nt * 32 + i32;
-        rstd1[nt] = stats1[ST_RSTD + c];
-        nmr1[nt] = -stats1[ST_MEAN + c] * rstd1[nt];  // uhat1 = fma(u, rstd, -mean rstd)
-        sc1[nt] = stats1[ST_SC + c];
-        sh1[nt] = stats1[ST_SH + c];
         sc2[nt] = stats2[ST_SC + c];
         // du2' = sD (cA + cB u2 + [winner] dvs) with u2 = u2raw / (2^8 sW): the scales are folded into the constants
         const float cb = training ? -sc2[nt] * cc2[64 + c] * stats2[ST_RSTD + c] : 0.0f;
@@ -256,21 +261,24 @@ __global__ __launch_bounds__(512) void edge_mlp_bwd16_kernel(
             }
             // ---- dv1 = da1 * LReLU'(v1), BN1 sums
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+            for (int nt = 0; nt < 2; ++nt) {
+                const float rstd1_ = cst[0][nt * 32 + i32], nmr1_ = cst[1][nt * 32 + i32];
+                const float sc1_ = cst[2][nt * 32 + i32], sh1_ = cst[3][nt * 32 + i32];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = mfma32_row(r, h);
                     if (row < kk) {
                         const float u = tileU[row][nt * 32 + i32];
-                        const float v = __builtin_fmaf(u, sc1[nt], sh1[nt]);
+                        const float v = __builtin_fmaf(u, sc1_, sh1_);
                         const float d = acc[nt][r] * (v > 0.0f ? un_da1 : un_da1s);
-                        const float uhat = __builtin_fmaf(u, rstd1[nt], nmr1[nt]);
+                        const float uhat = __builtin_fmaf(u, rstd1_, nmr1_);
                         // (streaming: 430 MB of dv1 must not sweep the TP table out of the XCD's L2: 395 -> 351 us)
                         __builtin_nontemporal_store(d, &dv1[((size_t)pt * k + j0 + row) * EC + nt * 32 + i32]);
                         dcol[nt] += d;
                         dhat[nt] = __builtin_fmaf(d, uhat, dhat[nt]);
                     }
                 }
+            }
         }
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
