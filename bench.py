@@ -46,9 +46,9 @@ PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md, dense fp16/bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md, "HBM3E peak BW" (spec; ~6.3 TB/s achievable)
 PEAK_L2_GATHER_GBS = 18800.0   # MI355X_MICROARCH.md, "Indexed rows": rows shared by every workgroup, served by the
                                # XCD's L2: 16.8-18.8 TB/s chip-wide
-                               # (measured here: the three gather passes of the step -- knn_refine, edge_reduce,
-                               # edge_rgather, 256-byte rows -- all run at 6.5-7.3 TB/s whatever their instruction mix:
-                               # the practical rate for rows of that size)
+                               # (scripts/microbench/row_gather.hip reaches 20-28 TB/s for random 256-byte rows of a
+                               # 1.8 MB table per XCD; the three gather passes of the step run at 6.5-7.3 TB/s, bound by
+                               # the work and the dependencies around each row: DESIGN.md section 5)
 TRAFFIC_FILE = os.path.join("profiles", "hbm_traffic.json")
 
 
