@@ -24,32 +24,62 @@ namespace dgcnn {
 constexpr float MB_SA = 256.0f;
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+typedef __fp16 fp16x4v __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef __attribute__((address_space(3))) fp16x4v lds_fp16x4v;
 
-__device__ __forceinline__ unsigned pack_split(float x)  // x already scaled
+// LDS images (no padding; 8- or 16-byte chunks of a row are XOR-swizzled so that every access below is conflict-free):
+//   W2 planes  [co 64][ci 64] fp16, hi plane then lo plane (W2_PLANE bytes each); 16-byte chunk ch of row co sits at
+//              chunk ch ^ w2_swz(co).  Read by rows (ds_read_b128: B operand of u2 = a1 . W2^T) and by columns
+//              (ds_read_b64_tr_b16: B operand of da1 = du2 . W2) -- one image serves both products.
+//   T planes   [channel 64][edge 32] fp16 per wave, hi then lo (T_PLANE bytes each): a1' first, du2' later; 8-byte chunk
+//              (4 edges) ch of row c at chunk ch ^ t_swz(c).  Written 4 edges at a time by the lane that owns the channel
+//              (ds_write_b64), read by columns (tr: the A operand [edge][channel] of u2 and of da1) and by rows
+//              (ds_read_b64: the B operand [edge][ci] of the weight gradient, edges in accumulator order).
+//   U          [edge 32][channel 64] fp32 per wave: u1, for the last epilogue.
+constexpr int W2_PLANE = 64 * 64 * 2, T_PLANE = 64 * 32 * 2, WAVE_TILE = 2 * T_PLANE + 32 * 64 * 4;
+__device__ __forceinline__ constexpr int w2_swz(int co) { return (((co >> 1) & 1) << 2) | ((co >> 2) & 3); }
+__device__ __forceinline__ constexpr int t_swz(int c) { return ((c >> 2) & 3) | ((((c >> 1) ^ (c >> 4)) & 1) << 2); }
+
+// two scaled values -> H = {hi(x0), hi(x1)}, L = {lo(x0), lo(x1)}: hi = x rounded TOWARDS ZERO to fp16 (one
+// v_cvt_pkrtz for the pair), lo = fp16(x - hi) (x - hi is exact in fp32; v_fma_mix{lo,hi}_f16 takes hi as an fp16
+// source and rounds the difference to nearest): 1.5 instructions per element
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned &H, unsigned &L)
 {
-    const float hi = __uint_as_float(__float_as_uint(x) & 0xffffe000u);
-    // v_cvt_pk_f16_f32: hi is exact, the remainder is rounded to nearest (no bias towards zero in the operands)
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{hi, x - hi}, f16x2));
+    H = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x0, x1));
+    unsigned l;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(H), "v"(x0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(H), "v"(x1));
+    L = l;
 }
-// eight packed words -> the hi halves and the lo halves as two MFMA operands (element j = word j)
-__device__ __forceinline__ void words_to_operands(const unsigned (&w)[8], half8 &hi, half8 &lo)
+// gather one M-tile (edges j0 .. j0 + 31 of a point) through a buffer descriptor of the batch element's TP table: the
+// row offset is the instruction's scalar offset and the lane's column its one address register -- no address
+// arithmetic on the vector unit and no 64-bit address pairs (rows past the list end repeat its last row)
+__device__ __forceinline__ void gather_rows_buf(const float *__restrict__ Pb, int N, int nv, int kk, int lane, float (&p)[32])
 {
-    u32x4 h, l;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)Pb, 0, N * EC * 4, 0x00020000);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        h[j] = __builtin_amdgcn_perm(w[2 * j + 1], w[2 * j], 0x05040100u);
-        l[j] = __builtin_amdgcn_perm(w[2 * j + 1], w[2 * j], 0x07060302u);
+    for (int g = 0; g < 4; ++g) {
+        if (g * 8 < kk) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int tt = g * 8 + t < kk ? g * 8 + t : kk - 1;
+                const unsigned row = (unsigned)__builtin_amdgcn_readlane(nv, tt);
+                p[g * 8 + t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, lane * 4, row * (EC * 4), 0));
+            }
+        }
     }
-    hi = __builtin_bit_cast(half8, h);
-    lo = __builtin_bit_cast(half8, l);
 }
-__device__ __forceinline__ void load_row_words(const unsigned (*tile)[TSTR], int row, int col, unsigned (&w)[8])
+__device__ __forceinline__ half8 words_as_half8(unsigned a, unsigned b, unsigned c, unsigned d)
 {
-    const uint4 a = *reinterpret_cast<const uint4 *>(&tile[row][col]);
-    const uint4 b = *reinterpret_cast<const uint4 *>(&tile[row][col + 4]);
-    w[0] = a.x, w[1] = a.y, w[2] = a.z, w[3] = a.w, w[4] = b.x, w[5] = b.y, w[6] = b.z, w[7] = b.w;
+    return __builtin_bit_cast(half8, u32x4{a, b, c, d});
+}
+// eight consecutive k of an operand from two transposed reads (4 k each)
+__device__ __forceinline__ half8 tr_read8(const unsigned char *p0, const unsigned char *p1)
+{
+    struct Two { fp16x4v a, b; };
+    return __builtin_bit_cast(half8, Two{__builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp16x4v *)p0),
+                                         __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp16x4v *)p1)});
 }
 __device__ __forceinline__ f32x16 mfma3(const half8 &ahi, const half8 &alo, const half8 &bhi, const half8 &blo, f32x16 c)
 {
@@ -70,11 +100,10 @@ __device__ __forceinline__ float scale_to(float m, int top)
     return pow2i(s);
 }
 
-// the k index of the contraction over the EDGES of a tile runs in accumulator order: MFMA step s (16 edges), lane
-// half h, element j  <->  edge row mfma32_row(8 s + j, h) -- so that du2, which the u2 product leaves in accumulator
-// registers (lane = channel, registers = edge rows), is the A operand of the weight gradient as it stands
-__device__ __forceinline__ int edge_of(int s, int j, int h) { return mfma32_row(8 * s + j, h); }
-
+// The contraction over the EDGES of a tile (weight gradient) runs in accumulator order: MFMA step s (16 edges), lane
+// half h, element j  <->  edge row mfma32_row(8 s + j, h) = 16 s + 8 (j >> 2) + 4 h + (j & 3) -- so that du2, which the
+// u2 product leaves in accumulator registers (lane = channel, registers = edge rows), is the A operand of the weight
+// gradient as it stands, and the other operand is two 8-byte row reads of the a1' image (edges 16 s + 8 u + 4 h .. + 3).
 __global__ __launch_bounds__(512) void edge_mlp_bwd16_kernel(
     const float *__restrict__ TP, const float *__restrict__ TQ, const int32_t *__restrict__ idx, int N, int k, int P,
     const float *__restrict__ stats1, const float *__restrict__ stats2, const float *__restrict__ cc2,
@@ -83,14 +112,16 @@ __global__ __launch_bounds__(512) void edge_mlp_bwd16_kernel(
     float *__restrict__ dv1, float *__restrict__ dvsum, float *__restrict__ partial_dw2, FoldSet fs,
     BnBackwardSums fin1, int *__restrict__ guard)
 {
-    __shared__ __attribute__((aligned(16))) unsigned w2w[64][TSTR];  // {hi | lo} of sW W2 [co][ci]
-    __shared__ __attribute__((aligned(16))) float tiles[MLP_BWD_WAVES][2][32][TSTR];
+    __shared__ __attribute__((aligned(16))) unsigned char w2p[2 * W2_PLANE];
+    __shared__ __attribute__((aligned(16))) unsigned char tiles[MLP_BWD_WAVES * WAVE_TILE];
     __shared__ float s_red[MLP_BWD_WAVES];
     __shared__ float cst[4][64];  // per-channel constants of the last epilogue (rstd1, -mean1 rstd1, sc1, sh1): read there,
-                                  // not held in eight registers through the three products (the kernel spills)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, i32 = lane & 31;
-    unsigned(*tileA)[TSTR] = reinterpret_cast<unsigned(*)[TSTR]>(tiles[wave][0]);  // a1' words, then du2' words
-    float(*tileU)[TSTR] = tiles[wave][1];                                         // u1 [edge][ci]
+                                  // not held in eight registers through the three products
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), h = lane >> 5, i32 = lane & 31;
+    unsigned char *tT = tiles + wave * WAVE_TILE;                   // T planes: a1', then du2'
+    float *tU = reinterpret_cast<float *>(tT + 2 * T_PLANE);        // u1 [edge][ci]
+    const float *tUl = tU + 4 * h * 64 + i32;                       // accumulator layout: + row0 * 64 + nt * 32
+    const unsigned ldo = 4 * h * 64 + i32;                          // the same offset in a [32][64] block of dv1
 
     // ---- scales (the same in every workgroup: functions of the inputs only)
     float wmax = 0.0f;
@@ -103,7 +134,14 @@ __global__ __launch_bounds__(512) void edge_mlp_bwd16_kernel(
 #pragma unroll
     for (int w = 1; w < MLP_BWD_WAVES; ++w) wmax = fmaxf(wmax, s_red[w]);
     const float sW = scale_to(wmax, 12);
-    for (int t = threadIdx.x; t < 4096; t += 512) w2w[t >> 6][t & 63] = pack_split(w2[t] * sW);
+    for (int t = threadIdx.x; t < 4096; t += 512) {
+        const int co = t >> 6, ci = t & 63;
+        unsigned H, L;
+        split_pair(w2[t] * sW, 0.0f, H, L);
+        const int off = co * 128 + (((ci >> 3) ^ w2_swz(co)) << 4) + (ci & 7) * 2;
+        *reinterpret_cast<unsigned short *>(w2p + off) = (unsigned short)H;
+        *reinterpret_cast<unsigned short *>(w2p + W2_PLANE + off) = (unsigned short)L;
+    }
     float scmax = fabsf(stats2[ST_SC + lane]);
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) scmax = fmaxf(scmax, __shfl_xor(scmax, o));
@@ -116,6 +154,25 @@ __global__ __launch_bounds__(512) void edge_mlp_bwd16_kernel(
         cst[3][threadIdx.x] = stats1[ST_SH + threadIdx.x];
     }
     __syncthreads();
+
+    // ---- LDS byte offsets of this lane (loop-invariant)
+    // transposed reads: lane 4 q + p of a 16-lane group supplies row q, columns 4 p .. 4 p + 3 of its block (4 rows x
+    // 16 columns); the group's lanes are columns 16 gg .. 16 gg + 15 of the operand's 32 (edges, or ci)
+    const int gg = (lane >> 4) & 1, q4 = (lane & 15) >> 2, p4 = lane & 3;
+    unsigned trA[2][2];  // T image, A operand [edge][channel 16 s + 8 h + 4 t + q]: [t][s & 1]; + 2048 (s >> 1)
+    unsigned trW[2][2];  // W2 image, B operand [co 16 s + 8 h + 4 t + q][ci 32 nt + ..]: [t][nt]; + 2048 s
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const int ch = 16 * x + 8 * h + 4 * t + q4;  // (x = s & 1)
+            trA[t][x] = ch * 64 + (((4 * gg + p4) ^ t_swz(ch)) << 3);
+            const int co = 8 * h + 4 * t + q4;           // (x = nt; w2_swz does not see 16 s)
+            trW[t][x] = co * 128 + (((4 * x + 2 * gg + (p4 >> 1)) ^ w2_swz(co)) << 4) + (p4 & 1) * 8;
+        }
+    const unsigned rowW = i32 * 128 + ((h ^ w2_swz(i32)) << 4);  // W2 row co = 32 nt + i32, chunk 2 s + h: (rowW ^ (s << 5)) + 4096 nt
+    const unsigned wT = lane * 64 + (t_swz(lane) << 3);          // gather layout: row ci = lane, chunk g: wT ^ (g << 3)
+    const unsigned bT = i32 * 64 + ((t_swz(i32) ^ h) << 3);      // accumulator layout: row 32 x + i32, chunk 2 g + h: (bT ^ (g << 4)) + 2048 x
 
     // gather-phase constants (lane = channel) and accumulator-layout constants (lane (n, h) = channel nt 32 + n)
     // (LeakyReLU is positively homogeneous: a1' = 2^8 a1 = LReLU(2^8 sc1 u + 2^8 sh1))
@@ -151,12 +208,12 @@ __global__ __launch_bounds__(512) void edge_mlp_bwd16_kernel(
         const float *Pb = TP + (size_t)b * N * EC;
         const float q = TQ[(size_t)pt * EC + lane];
         const int32_t *ip = idx + (size_t)pt * k;
-        float dvs[2];
+        float dvs[2];  // the winner's term
         int hit[2];
         float dcol[2] = {0.0f, 0.0f}, dhat[2] = {0.0f, 0.0f};
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-            hit[nt] = hit2[(size_t)pt * EC + nt * 32 + i32];
+            hit[nt] = (int)hit2[(size_t)pt * EC + nt * 32 + i32] - 4 * h;  // relative to this lane half's rows
             dvs[nt] = sD * sc2[nt] * gy[(size_t)pt * EC + nt * 32 + i32] *
                       (y[(size_t)pt * EC + nt * 32 + i32] > 0.0f ? 1.0f : slope);
         }
@@ -165,20 +222,38 @@ __global__ __launch_bounds__(512) void edge_mlp_bwd16_kernel(
             {
                 float p2[32];
                 const int nv = j0 == 0 ? nvn : (lane < kk ? ip[j0 + lane] : 0);
-                gather_rows(Pb, nv, kk, lane, p2);
+                gather_rows_buf(Pb, N, nv, kk, lane, p2);
                 if (j0 == 0 && pt + it.step < it.end) nvn = lane < kk0 ? idx[(size_t)(pt + it.step) * k + lane] : 0;
+                // four edges at a time: their a1' halves are one 8-byte chunk of row `lane` of the image.  A group that
+                // lies inside the list needs no masks (the branch is wave-uniform)
+                auto stage4 = [&](auto G, auto FULL) {
+                    constexpr int g = decltype(G)::value;
+                    constexpr bool full = decltype(FULL)::value;
+                    unsigned H[2], L[2];
 #pragma unroll
-                for (int j = 0; j < 32; ++j) {
-                    const bool on = j < kk;
-                    const float u = on ? p2[j] + q : 0.0f;
-                    const float a = on ? lrelu(__builtin_fmaf(u, sc1g, sh1g), slope) : 0.0f;  // a1'
-                    amax = fmaxf(amax, fabsf(a));
-                    tileA[j][lane] = pack_split(a);
-                    tileU[j][lane] = u;
-                }
+                    for (int m = 0; m < 2; ++m) {
+                        float a[2];
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const int j = 4 * g + 2 * m + e;
+                            const float u = p2[j] + q;  // (rows past the end repeat the last row: finite, never used)
+                            const float v = lrelu(__builtin_fmaf(u, sc1g, sh1g), slope);  // a1'
+                            a[e] = full || j < kk ? v : 0.0f;
+                            amax = fmaxf(amax, fabsf(a[e]));
+                            tU[j * 64 + lane] = u;
+                        }
+                        split_pair(a[0], a[1], H[m], L[m]);
+                    }
+                    *reinterpret_cast<uint2 *>(tT + (wT ^ (g << 3))) = make_uint2(H[0], H[1]);
+                    *reinterpret_cast<uint2 *>(tT + T_PLANE + (wT ^ (g << 3))) = make_uint2(L[0], L[1]);
+                };
+                static_for<8>([&](auto G) {
+                    if (4 * decltype(G)::value + 4 <= kk) stage4(G, std::true_type{});
+                    else stage4(G, std::false_type{});
+                });
             }
 
-            // ---- u2raw = a1' . W2'^T : A = rows of the a1' tile, B[k = ci][n = co] = rows of w2w
+            // ---- u2raw = a1' . W2'^T : A = columns of the a1' image, B[k = ci][n = co] = rows of the W2 image
             f32x16 acc[2];
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
@@ -186,98 +261,114 @@ __global__ __launch_bounds__(512) void edge_mlp_bwd16_kernel(
                 for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                unsigned w[8];
-                half8 ahi, alo, bhi, blo;
-                load_row_words(tileA, i32, 16 * s + 8 * h, w);
-                words_to_operands(w, ahi, alo);
+                const unsigned char *a0 = tT + trA[0][s & 1] + 2048 * (s >> 1), *a1 = tT + trA[1][s & 1] + 2048 * (s >> 1);
+                const half8 ahi = tr_read8(a0, a1), alo = tr_read8(a0 + T_PLANE, a1 + T_PLANE);
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
-                    load_row_words(w2w, nt * 32 + i32, 16 * s + 8 * h, w);
-                    words_to_operands(w, bhi, blo);
+                    const unsigned char *bp = w2p + (rowW ^ (s << 5)) + 4096 * nt;
+                    const half8 bhi = *reinterpret_cast<const half8 *>(bp);
+                    const half8 blo = *reinterpret_cast<const half8 *>(bp + W2_PLANE);
                     acc[nt] = mfma3(ahi, alo, bhi, blo, acc[nt]);
                 }
             }
-            // a1' as the B operand of the weight gradient: B[k = edge][n = ci] in accumulator edge order (read before
-            // du2' overwrites the tile)
+            // a1' as the B operand of the weight gradient: B[k = edge][n = ci], edges in accumulator order (read before
+            // du2' overwrites the image)
             half8 xhi[2][2], xlo[2][2];  // [ci tile][step]
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    unsigned w[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) w[j] = tileA[edge_of(s, j, h)][ct * 32 + i32];
-                    words_to_operands(w, xhi[ct][s], xlo[ct][s]);
+                    const unsigned char *x0 = tT + (bT ^ ((4 * s) << 3)) + 2048 * ct, *x1 = tT + (bT ^ ((4 * s + 2) << 3)) + 2048 * ct;
+                    const uint2 h0 = *reinterpret_cast<const uint2 *>(x0), h1 = *reinterpret_cast<const uint2 *>(x1);
+                    const uint2 l0 = *reinterpret_cast<const uint2 *>(x0 + T_PLANE), l1 = *reinterpret_cast<const uint2 *>(x1 + T_PLANE);
+                    xhi[ct][s] = words_as_half8(h0.x, h0.y, h1.x, h1.y);
+                    xlo[ct][s] = words_as_half8(l0.x, l0.y, l1.x, l1.y);
                 }
 
             // ---- du2' (in place of u2raw): the whole dL/dy goes to the edge the forward selected (hit2); the rest are
-            // the dense BatchNorm mean terms, affine in u2.  Split once: packed words for the LDS transpose (A operand of
-            // da1), and the halves of registers 8 s .. 8 s + 7 as the A operand of the weight gradient.
+            // the dense BatchNorm mean terms, affine in u2.  Rows past the list end are left as they come (cA: their a1'
+            // rows are zero, so they add nothing to gW2, and their da1 rows are not used).  Split once, pairwise: registers
+            // 8 s .. 8 s + 7 are the A operand of the weight gradient, registers 4 g .. 4 g + 3 one chunk of the du2' image.
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                const int hitrow = hit[nt] - j0;
-                unsigned w[16];
+                const int hrel = hit[nt] - j0;
+                unsigned Hd[8], Ld[8];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = mfma32_row(r, h);
-                    float du = 0.0f;
-                    if (row < kk) du = __builtin_fmaf(cB[nt], acc[nt][r], cA[nt]) + (row == hitrow ? dvs[nt] : 0.0f);
-                    dmax = fmaxf(dmax, fabsf(du));
-                    w[r] = pack_split(du);
-                    tileA[row][nt * 32 + i32] = w[r];
+                for (int i = 0; i < 8; ++i) {
+                    float du[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int r = 2 * i + e;
+                        // (cA and cB u2 cancel when |mean2| >> sigma2: one fma first, the winner's term after it)
+                        du[e] = __builtin_fmaf(cB[nt], acc[nt][r], cA[nt]) + (mfma32_row(r, 0) == hrel ? dvs[nt] : 0.0f);
+                        dmax = fmaxf(dmax, fabsf(du[e]));
+                    }
+                    split_pair(du[0], du[1], Hd[i], Ld[i]);
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    *reinterpret_cast<uint2 *>(tT + (bT ^ (g << 4)) + 2048 * nt) = make_uint2(Hd[2 * g], Hd[2 * g + 1]);
+                    *reinterpret_cast<uint2 *>(tT + T_PLANE + (bT ^ (g << 4)) + 2048 * nt) = make_uint2(Ld[2 * g], Ld[2 * g + 1]);
                 }
                 // ---- gW2[co][ci] += sum_edges du2'[edge][co] a1'[edge][ci]   (this co tile)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    unsigned ws[8];
-                    half8 dhi, dlo;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) ws[j] = w[8 * s + j];
-                    words_to_operands(ws, dhi, dlo);
+                    const half8 dhi = words_as_half8(Hd[4 * s], Hd[4 * s + 1], Hd[4 * s + 2], Hd[4 * s + 3]);
+                    const half8 dlo = words_as_half8(Ld[4 * s], Ld[4 * s + 1], Ld[4 * s + 2], Ld[4 * s + 3]);
 #pragma unroll
                     for (int cit = 0; cit < 2; ++cit)
                         accW[nt][cit] = mfma3(dhi, dlo, xhi[cit][s], xlo[cit][s], accW[nt][cit]);
                 }
             }
 
-            // ---- da1raw = du2' . W2' : A = rows of the du2' tile (the LDS transpose), B[k = co][n = ci] = columns of w2w
+            // ---- da1raw = du2' . W2' : A = columns of the du2' image, B[k = co][n = ci] = columns of the W2 image
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                unsigned w[8];
-                half8 ahi, alo, bhi, blo;
-                load_row_words(tileA, i32, 16 * s + 8 * h, w);
-                words_to_operands(w, ahi, alo);
+                const unsigned char *a0 = tT + trA[0][s & 1] + 2048 * (s >> 1), *a1 = tT + trA[1][s & 1] + 2048 * (s >> 1);
+                const half8 ahi = tr_read8(a0, a1), alo = tr_read8(a0 + T_PLANE, a1 + T_PLANE);
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) w[j] = w2w[16 * s + 8 * h + j][nt * 32 + i32];
-                    words_to_operands(w, bhi, blo);
+                    const unsigned char *b0 = w2p + trW[0][nt] + 2048 * s, *b1 = w2p + trW[1][nt] + 2048 * s;
+                    const half8 bhi = tr_read8(b0, b1), blo = tr_read8(b0 + W2_PLANE, b1 + W2_PLANE);
                     acc[nt] = mfma3(ahi, alo, bhi, blo, acc[nt]);
                 }
             }
-            // ---- dv1 = da1 * LReLU'(v1), BN1 sums
+            // ---- dv1 = da1 * LReLU'(v1), BN1 sums.  Rows 8 g .. 8 g + 7 of the tile belong to registers 4 g .. 4 g + 3:
+            // a group inside the list runs without masks, one past its end is skipped (wave-uniform branches)
+            {
+                float *dvb = dv1 + ((size_t)pt * k + j0) * EC;  // (wave-uniform base; lane part: ldo)
+                float c_[2][4];
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                const float rstd1_ = cst[0][nt * 32 + i32], nmr1_ = cst[1][nt * 32 + i32];
-                const float sc1_ = cst[2][nt * 32 + i32], sh1_ = cst[3][nt * 32 + i32];
+                for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = mfma32_row(r, h);
-                    if (row < kk) {
-                        const float u = tileU[row][nt * 32 + i32];
-                        const float v = __builtin_fmaf(u, sc1_, sh1_);
-                        const float d = acc[nt][r] * (v > 0.0f ? un_da1 : un_da1s);
-                        const float uhat = __builtin_fmaf(u, rstd1_, nmr1_);
-                        // (streaming: 430 MB of dv1 must not sweep the TP table out of the XCD's L2: 395 -> 351 us)
-                        __builtin_nontemporal_store(d, &dv1[((size_t)pt * k + j0 + row) * EC + nt * 32 + i32]);
-                        dcol[nt] += d;
-                        dhat[nt] = __builtin_fmaf(d, uhat, dhat[nt]);
-                    }
-                }
+                    for (int c = 0; c < 4; ++c) c_[nt][c] = cst[c][nt * 32 + i32];
+                auto rows8 = [&](auto G, auto FULL) {
+                    constexpr int g = decltype(G)::value;
+                    constexpr bool full = decltype(FULL)::value;
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+                        static_for<4>([&](auto R) {
+                            constexpr int r = 4 * g + decltype(R)::value, row0 = mfma32_row(r, 0);
+                            const float u = tUl[row0 * 64 + nt * 32];
+                            const float v = __builtin_fmaf(u, c_[nt][2], c_[nt][3]);
+                            float d = acc[nt][r] * (v > 0.0f ? un_da1 : un_da1s);
+                            const float uhat = __builtin_fmaf(u, c_[nt][0], c_[nt][1]);
+                            const bool ok = full || row0 + 4 * h < kk;
+                            // (streaming: 430 MB of dv1 must not sweep the TP table out of the XCD's L2: 395 -> 351 us)
+                            if (ok) __builtin_nontemporal_store(d, &dvb[ldo + (unsigned)(row0 * 64 + nt * 32)]);
+                            d = ok ? d : 0.0f;
+                            dcol[nt] += d;
+                            dhat[nt] = __builtin_fmaf(d, uhat, dhat[nt]);
+                        });
+                };
+                static_for<4>([&](auto G) {
+                    if (8 * decltype(G)::value + 8 <= kk) rows8(G, std::true_type{});
+                    else if (8 * decltype(G)::value < kk) rows8(G, std::false_type{});
+                });
             }
         }
 #pragma unroll
@@ -291,7 +382,7 @@ __global__ __launch_bounds__(512) void edge_mlp_bwd16_kernel(
 
     // ---- workgroup reduction of gW2 and of the BN1 sums (tile memory is free now)
     __syncthreads();
-    float *scr = &tiles[0][0][0][0];  // 8 waves x 4096 floats fit in the tile area
+    float *scr = reinterpret_cast<float *>(tiles);  // 8 waves x 4096 floats: exactly the tile area
     const float un_w = 1.0f / (sD * MB_SA);
     bool bad = !(amax < 65000.0f) || !(dmax < 65000.0f);  // (amax is max |a1'| = 2^8 max |a1|)
 #pragma unroll
