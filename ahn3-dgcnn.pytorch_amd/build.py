@@ -24,6 +24,9 @@ FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
          # MFMA accumulators in VGPRs: the epilogues consume them with VALU instructions, and the default
          # AGPR form costs one v_accvgpr_read per accumulator register (64 per chunk in the fp16 streams)
          "-mllvm", "-amdgpu-mfma-vgpr-form"]
+# no SLP packing of independent fp32 operations into v_pk_*_f32 in these files: beside MFMAs the packed forms are slower
+# than the two scalar instructions they replace (edge_mlp_bwd16: 234 -> 225 us, edge_mlp_fwd: 129 -> 125 us)
+FILE_FLAGS = {"edge_mlp_fwd16.hip": ["-fno-slp-vectorize"], "edge_mlp_bwd16.hip": ["-fno-slp-vectorize"]}
 FLAGS += os.environ.get("DGCNN_EXTRA_HIPCC_FLAGS", "").split()  # experiments only (e.g. ablation -D switches)
 
 def sources():
@@ -53,7 +56,7 @@ def _compile(src, force, resources):
     if (not force and not resources and os.path.exists(obj) and os.path.exists(stamp)
             and open(stamp).read() == dig):
         return obj, ""
-    cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+    cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
     if resources:
         cmd.append("-Rpass-analysis=kernel-resource-usage")
     p = subprocess.run(cmd, capture_output=True, text=True)

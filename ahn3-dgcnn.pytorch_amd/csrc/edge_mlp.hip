@@ -1,19 +1,17 @@
 // edge_mlp.hip -- the per-EDGE 64 -> 64 contraction of the two-stage EdgeConv blocks
 // (conv2 / conv4 of the reference, model.py:119-121,125-127 applied at :149,:156), fused with everything around it.
-// Forward: fp16 matrix cores with both operands split in two halves, x = hi + lo 2^-11 (hi = x with the low 13
-// mantissa bits cleared, lo = fp16((x - hi) 2^11)): u2 = hi.hi + 2^-11 (hi.lo + lo.hi); the dropped lo.lo term and the
-// rounding of lo are 2^-21 relative -- inside fp32's own accumulation error over 64 terms and far inside the 1e-4
+// Forward and backward run on the fp16 matrix cores (edge_mlp_fwd16.hip, edge_mlp_bwd16.hip): both operands scaled by an
+// exact power of two and split in two fp16 halves, x' = hi + lo, u2 = hi.hi + hi.lo + lo.hi; the dropped lo.lo term and the
+// rounding of lo are 2^-22 relative -- inside fp32's own accumulation error over 64 terms and far inside the 1e-4
 // parity bound -- for 12 v_mfma_f32_32x32x16_f16 (384 cycles) per 32 x 32 x 64 tile instead of 32
 // v_mfma_f32_32x32x2_f32 (2048 cycles).  On gfx950 the fp32-input MFMA also shares the vector ALU's FMA lanes: its time
 // and the gather / epilogue VALU time ADD (measured: 114 us MFMA + 56 + 27 us VALU phases = the fp32 kernel's 206 us).
-// Backward: the same three-product split on fp16 MFMA with exact power-of-two operand scales (edge_mlp_bwd16_kernel); the
-// fp32 kernel (v_mfma_f32_32x32x2_f32) stays as its guarded fallback.
+// This file keeps the fp32 kernels (v_mfma_f32_32x32x2_f32), which are the guarded fallbacks, and the launchers.
 //
 // One wave processes one point at a time; its k edges are the M dimension of a 32-row MFMA tile
 // (k = 30 -> 30 of 32 rows used; k > 32 -> two tiles):
 //   gather  (lane = channel)  u1[j] = TP[n(i, j)] + TQ[i];  a1 = LReLU(BN1(u1)) -> wave-private LDS tile
-//   MFMA    u2[32 edges][64]  = a1 . W2^T          A from the LDS tile (8 ds_read_b128 per lane),
-//                                                   B = W2 (registers in the forward, LDS image in the backward)
+//   MFMA    u2[32 edges][64]  = a1 . W2^T          A from the wave's LDS tile, B = W2 from the workgroup's LDS image
 //   forward epilogue: accumulator layout has the output CHANNEL on the lane and the EDGES in the
 //           16 registers, so BN2 batch sums and the max/min over k are in-lane loops plus one
 //           exchange between the two lane halves; nothing per-edge is written to HBM.
@@ -53,70 +51,23 @@ __device__ __forceinline__ void load_a_operand(const float (*tile)[TSTR], int i3
     }
 }
 
-constexpr float LO_SCALE = 2048.0f, LO_UNSCALE = 1.0f / 2048.0f;
-
-// x = hi + lo / 2^11 up to 2^-21 |x|: hi = x with the low 13 mantissa bits cleared (exactly a fp16 number inside the
-// fp16 normal range), lo = the exact remainder, scaled (and rounded to fp16 by the caller).  |x| beyond the fp16 range
-// becomes an infinity in the conversion and poisons every sum it enters -- which is how the forward kernel notices
-// (no clamp, no per-element range test); below the normal range the error is at most 2^-25 absolute.
-__device__ __forceinline__ void split_f16(float x, float &hi, float &lo)
-{
-    hi = __uint_as_float(__float_as_uint(x) & 0xffffe000u);
-    lo = (x - hi) * LO_SCALE;
-}
-// A operand of the 32x32x16 fp16 MFMA from a fp32 [32][TSTR] tile: lane (i, h), step s holds columns 16 s + 8 h .. + 7
-__device__ __forceinline__ void load_a_split(const float (*tile)[TSTR], int i32, int h, half8 (&ahi)[4], half8 (&alo)[4])
-{
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const float4 v0 = *reinterpret_cast<const float4 *>(&tile[i32][16 * s + 8 * h]);
-        const float4 v1 = *reinterpret_cast<const float4 *>(&tile[i32][16 * s + 8 * h + 4]);
-        const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float a, b;
-            split_f16(x[e], a, b);
-            ahi[s][e] = (_Float16)a;
-            alo[s][e] = (_Float16)b;
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
-// F32 = false: the production kernel (fp16 matrix cores, split operands).  |a1| or |W2| beyond the fp16 range (65504)
-// overflows in the split: the kernel sees it in its sums and raises *guard, its BatchNorm finalizer then stands down, and
-// the F32 = true instance -- the same pass on v_mfma_f32_32x32x2_f32, launched behind it, returning at once while *guard
-// is zero -- redoes the work (usel2, hit2, BatchNorm-2 statistics).
-template <bool F32>
-__global__ __launch_bounds__(256) void edge_mlp_fwd_kernel(const float *__restrict__ TP, const float *__restrict__ TQ,
-                                                           const int32_t *__restrict__ idx, int N, int k, int P,
-                                                           const float *__restrict__ stats1,
-                                                           const float *__restrict__ w2,
-                                                           const float *__restrict__ gamma2, float slope,
-                                                           float *__restrict__ usel2, uint8_t *__restrict__ hit2,
-                                                           int fin_on, FoldSet fs, BnBatchStats fin, int *__restrict__ guard)
+// The fp32 form of the forward (v_mfma_f32_32x32x2_f32): the FALLBACK of edge_mlp_fwd16_kernel (edge_mlp_fwd16.hip).
+// Launched behind it, it returns at once unless that kernel has raised *guard (|a1| beyond the fp16 range, or a
+// non-finite sum), and otherwise redoes the pass: usel2, hit2, BatchNorm-2 statistics.
+__global__ __launch_bounds__(256) void edge_mlp_fwd_f32_kernel(const float *__restrict__ TP, const float *__restrict__ TQ,
+                                                               const int32_t *__restrict__ idx, int N, int k, int P,
+                                                               const float *__restrict__ stats1,
+                                                               const float *__restrict__ w2,
+                                                               const float *__restrict__ gamma2, float slope,
+                                                               float *__restrict__ usel2, uint8_t *__restrict__ hit2,
+                                                               int fin_on, FoldSet fs, BnBatchStats fin, const int *__restrict__ guard)
 {
-    if (F32 && *guard == 0) return;
+    if (*guard == 0) return;
     __shared__ __attribute__((aligned(16))) float tiles[MLP_WAVES][32][TSTR];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, i32 = lane & 31;
     float(*tileA)[TSTR] = tiles[wave];
 
-    // B operand: B[k = ci][n = co] = W2[co][ci]; lane (n, h) supplies ci = 16 s + 8 h .. + 7 at step s, split in halves
-    half8 whi[2][4], wlo[2][4];
-    if constexpr (!F32) {
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float a, b;
-                    const float w = w2[(size_t)(nt * 32 + i32) * EC + 16 * s + 8 * h + e];
-                    split_f16(w, a, b);
-                    whi[nt][s][e] = (_Float16)a;
-                    wlo[nt][s][e] = (_Float16)b;
-                }
-    }
     unsigned flip[2];  // gamma2 < 0: the activation's maximum is the pre-activation's minimum
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) flip[nt] = gamma2[nt * 32 + i32] < 0.0f ? 0x80000000u : 0u;
@@ -157,32 +108,23 @@ __global__ __launch_bounds__(256) void edge_mlp_fwd_kernel(const float *__restri
                     }
                 }
             }
-            half8 ahi[4], alo[4];
-            if constexpr (!F32) load_a_split(tileA, i32, h, ahi, alo);
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                f32x16 am, ax;  // hi.hi and (hi.lo + lo.hi) 2^11   (F32: the whole product in am)
+                f32x16 am;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) am[r] = ax[r] = 0.0f;
-                if constexpr (F32) {
+                for (int r = 0; r < 16; ++r) am[r] = 0.0f;
+                {
                     float a32[32];
                     load_a_operand(tileA, i32, h, a32);
 #pragma unroll
                     for (int s = 0; s < 32; ++s)
                         am = __builtin_amdgcn_mfma_f32_32x32x2f32(a32[s], w2[(size_t)(nt * 32 + i32) * EC + 32 * h + s], am, 0, 0, 0);
-                } else {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        am = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[s], whi[nt][s], am, 0, 0, 0);
-                        ax = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[s], wlo[nt][s], ax, 0, 0, 0);
-                        ax = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[s], whi[nt][s], ax, 0, 0, 0);
-                    }
                 }
                 // extreme of the sign-flipped value (so that it is always a maximum), then the first slot that holds it
                 float best = -__builtin_inff();
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float u = __builtin_fmaf(ax[r], LO_UNSCALE, am[r]);  // exactly 0 in the padding rows (a1 = 0)
+                    const float u = am[r];  // exactly 0 in the padding rows (a1 = 0)
                     ps[nt] += u;
                     pq[nt] = __builtin_fmaf(u, u, pq[nt]);
                     am[r] = mfma32_row(r, h) < kk ? __uint_as_float(__float_as_uint(u) ^ flip[nt]) : -__builtin_inff();
@@ -212,12 +154,6 @@ __global__ __launch_bounds__(256) void edge_mlp_fwd_kernel(const float *__restri
     }
     // BN2 batch statistics (training): lane (n, h) holds channel nt * 32 + n; fold the halves -- lane l then carries
     // channel l (nt = h) -- and let the pass finish the sums itself (fold.h)
-    if constexpr (!F32) {
-        // an operand element beyond the fp16 range turned into an infinity in the split and has poisoned the sums of
-        // squares it entered (inf, or NaN against a zero): hand the pass to the fp32 instance behind this launch
-        const bool poisoned = !(sq[0] <= 1.0e300) || !(sq[1] <= 1.0e300);
-        if (__ballot(poisoned) && lane == 0) atomicOr(guard, 1);
-    }
     if (fin_on) {
         const double t0 = sum[0] + shfl_xor_d(sum[0], 32), t1 = sum[1] + shfl_xor_d(sum[1], 32);
         const double q0 = sq[0] + shfl_xor_d(sq[0], 32), q1 = sq[1] + shfl_xor_d(sq[1], 32);
@@ -418,6 +354,10 @@ __global__ __launch_bounds__(512) void edge_mlp_bwd_f32_kernel(
 
 
 // ---------------------------------------------------------------------------------------------
+void launch_edge_mlp_fwd16(const float *TP, const float *TQ, const int32_t *idx, int N, int k, int P, const float *stats1,
+                           const float *w2, const float *gamma2, float slope, float *usel2, uint8_t *hit2, int fin_on,
+                           const FoldSet &fs, const BnBatchStats &fin, int *guard, hipStream_t st);  // edge_mlp_fwd16.hip
+
 void launch_edge_mlp_fwd(const float *TP, const float *TQ, const int32_t *idx, int N, int k, int P,
                          const float *stats1, const float *w2, const float *gamma2, float slope, float *usel2,
                          uint8_t *hit2, const FoldSet &fs, const FoldSet &fs_fallback, const BnBatchStats *fin, int *guard,
@@ -427,10 +367,10 @@ void launch_edge_mlp_fwd(const float *TP, const float *TQ, const int32_t *idx, i
     f16.guard = guard;   // the fp16 kernel's finalizer stands down when the guard is up
     f32.guard = nullptr;
     prof_begin(PROF_EDGE_MLP_FWD, st);
-    hipLaunchKernelGGL(edge_mlp_fwd_kernel<false>, dim3(mlp_grid_fwd(P)), dim3(256), 0, st, TP, TQ, idx, N, k, P, stats1, w2,
-                       gamma2, slope, usel2, hit2, fin ? 1 : 0, fs, f16, guard);
-    hipLaunchKernelGGL(edge_mlp_fwd_kernel<true>, dim3(mlp_grid_fwd(P)), dim3(256), 0, st, TP, TQ, idx, N, k, P, stats1, w2,
-                       gamma2, slope, usel2, hit2, fin ? 1 : 0, fs_fallback, f32, guard);
+    launch_edge_mlp_fwd16(TP, TQ, idx, N, k, P, stats1, w2, gamma2, slope, usel2, hit2, fin ? 1 : 0, fs, f16, guard, st);
+    // the fp32 form of the same pass: returns at once unless the fp16 kernel raised *guard
+    hipLaunchKernelGGL(edge_mlp_fwd_f32_kernel, dim3(mlp_grid_fwd(P)), dim3(256), 0, st, TP, TQ, idx, N, k, P, stats1, w2,
+                       gamma2, slope, usel2, hit2, fin ? 1 : 0, fs_fallback, f32, (const int *)guard);
     prof_end(PROF_EDGE_MLP_FWD, st);
 }
 

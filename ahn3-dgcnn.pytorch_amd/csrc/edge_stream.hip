@@ -75,7 +75,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     }
     for (; pt < it.end; pt += it.step) {
         const int b = pt / N;
-        const float *Pb = TP + (size_t)b * N * EC;
+        // the batch element's table behind a buffer descriptor: a gather is then one instruction with the row offset
+        // in a scalar register and the lane's column in ONE address register (no 64-bit address per row in flight)
+        const __amdgpu_buffer_rsrc_t Pb = __builtin_amdgcn_make_buffer_rsrc((void *)(TP + (size_t)b * N * EC), 0, N * EC * 4, 0x00020000);
         const float qs = q_next * sgn;
         int nv = nv_next;  // neighbours 0..63 of this point (lane j holds idx[pt][j])
         const int32_t *ip = idx + (size_t)pt * k;
@@ -112,7 +114,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
                         for (int t = 0; t < 8; ++t) {
                             const int tt = j + g * 8 + t < kk ? j + g * 8 + t : kk - 1;
                             const unsigned n = (unsigned)__builtin_amdgcn_readlane(nv, tt);
-                            p[g * 8 + t] = (Pb + (size_t)n * EC)[(unsigned)lane];  // scalar row base + lane offset
+                            p[g * 8 + t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(Pb, lane * 4, n * (EC * 4), 0));
                         }
                     }
                 }
@@ -614,7 +616,7 @@ __global__ __launch_bounds__(256) void edge_point_bwd_kernel(const float *__rest
 // channel); LDS float atomics of ONE wave-instruction on one address are served in a fixed lane order, and the
 // instructions run in program order, so sacc is a function of the (sorted) list alone).
 template <bool DENSE>
-__device__ __forceinline__ void rgather_segment(const float *__restrict__ TQ, int k, const float *__restrict__ dv,
+__device__ __forceinline__ void rgather_segment(const __amdgpu_buffer_rsrc_t TQb, int k, const float *__restrict__ dv,
                                                 const HitRec *__restrict__ hits, const float *__restrict__ G, int cnt,
                                                 int ev, u64 hm, float4 rec, float *sacc, int lane, float &sq, float &sd)
 {
@@ -629,7 +631,7 @@ __device__ __forceinline__ void rgather_segment(const float *__restrict__ TQ, in
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int i = __builtin_amdgcn_readlane(src, t + u);
-            q[u] = (TQ + (size_t)(unsigned)i * EC)[(unsigned)lane];  // scalar row base + lane offset
+            q[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(TQb, lane * 4, i * (EC * 4), 0));  // scalar row offset
             if (DENSE) d[u] = __builtin_nontemporal_load(&(dv + (size_t)(unsigned)__builtin_amdgcn_readlane(ev, t + u) * EC)[(unsigned)lane]);
         }
 #pragma unroll
@@ -650,7 +652,7 @@ __device__ __forceinline__ void rgather_segment(const float *__restrict__ TQ, in
         for (int u = 0; u < 8; ++u) {
             const int tt = t + u < cnt ? t + u : t;  // clamped: no branch around the loads
             const int i = __builtin_amdgcn_readlane(src, tt);
-            q[u] = (TQ + (size_t)(unsigned)i * EC)[(unsigned)lane];
+            q[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(TQb, lane * 4, i * (EC * 4), 0));
             // (dv1 rows are read once: streamed past the L2 that holds the TQ table)
             if (DENSE) d[u] = __builtin_nontemporal_load(&(dv + (size_t)(unsigned)__builtin_amdgcn_readlane(ev, tt) * EC)[(unsigned)lane]);
         }
@@ -764,6 +766,9 @@ __global__ __launch_bounds__(256) void edge_rgather_kernel(const float *__restri
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float mean = stats[ST_MEAN + lane], rstd = stats[ST_RSTD + lane], sc = stats[ST_SC + lane];
     const float c1 = cc[lane], c2 = cc[64 + lane];
+    // the TQ table behind a buffer descriptor: a row gather is one instruction with a scalar row offset (P EC 4 < 2^32
+    // is checked by the launcher)
+    const __amdgpu_buffer_rsrc_t TQb = __builtin_amdgcn_make_buffer_rsrc((void *)TQ, 0, P * EC * 4, 0x00020000);
     RgatherCtx cx;
     cx.TP = TP;
     cx.dR = dR;
@@ -796,7 +801,7 @@ __global__ __launch_bounds__(256) void edge_rgather_kernel(const float *__restri
                 rec = *reinterpret_cast<const float4 *>(h->v);
             }
             float sq, sd;
-            rgather_segment<DENSE>(TQ, k, dv, hits, G, cnt, ev, hm, rec, sacc, lane, sq, sd);
+            rgather_segment<DENSE>(TQb, k, dv, hits, G, cnt, ev, hm, rec, sacc, lane, sq, sd);
             rgather_publish(cx, pt, seg, deg, sq, sd, lane);
         }
         return;
@@ -845,7 +850,7 @@ __global__ __launch_bounds__(256) void edge_rgather_kernel(const float *__restri
             rec = *reinterpret_cast<const float4 *>(h->v);
         }
         float sq, sd;
-        rgather_segment<DENSE>(TQ, k, dv, hits, G, cnt, ev, hm, rec, sacc, lane, sq, sd);
+        rgather_segment<DENSE>(TQb, k, dv, hits, G, cnt, ev, hm, rec, sacc, lane, sq, sd);
         if (deg <= REV_SEG) {
             const float fdeg = (float)deg;
             dR[(size_t)pt * EC + lane] = fdeg * cx.a0 - cx.alpha * (sq + fdeg * TP[(size_t)pt * EC + lane]) + cx.dscale * sd;
@@ -862,6 +867,7 @@ int launch_edge_bwd(const float *TP, const float *TQ, int B, int N, int k, const
                     float *partx, float *dR, float *dD, hipStream_t st)
 {
     const int P = B * N;
+    DG_REQUIRE((size_t)P * EC * 4 < ((size_t)1 << 32), "edge backward: B * N = %d points exceed the 4 GB row-offset range of the TQ gather", P);
     const dim3 grid(stream_grid(P)), block(256);
     // (measured: the placement pass of the reverse adjacency as extra workgroups of this launch -- as the list-space
     // pass rides with bwd_point -- gains nothing: 47.9 us against 28.0 + 17.3; its N-int LDS table is then reserved by
