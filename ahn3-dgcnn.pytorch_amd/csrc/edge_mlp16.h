@@ -26,6 +26,14 @@ constexpr int W2_PLANE = 64 * 64 * 2, T_PLANE = 64 * 32 * 2, WAVE_TILE = 2 * T_P
 __device__ __forceinline__ constexpr int w2_swz(int co) { return (((co >> 1) & 1) << 2) | ((co >> 2) & 3); }
 __device__ __forceinline__ constexpr int t_swz(int c) { return ((c >> 2) & 3) | ((((c >> 1) ^ (c >> 4)) & 1) << 2); }
 
+// LeakyReLU; S01 (0 <= slope <= 1, the launcher checks): max(v, slope v) -- the same value bit for bit, one
+// instruction less than compare + select
+template <bool S01>
+__device__ __forceinline__ float lrelu_t(float v, float slope)
+{
+    return S01 ? __builtin_fmaxf(v, v * slope) : lrelu(v, slope);
+}
+
 // two scaled values -> H = {hi(x0), hi(x1)}, L = {lo(x0), lo(x1)}: hi = x rounded TOWARDS ZERO to fp16 (one
 // v_cvt_pkrtz for the pair), lo = fp16(x - hi) (x - hi is exact in fp32; v_fma_mix{lo,hi}_f16 takes hi as an fp16
 // source and rounds the difference to nearest): 1.5 instructions per element

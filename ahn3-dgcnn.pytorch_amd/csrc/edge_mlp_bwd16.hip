@@ -27,6 +27,7 @@ namespace dgcnn {
 // half h, element j  <->  edge row mfma32_row(8 s + j, h) = 16 s + 8 (j >> 2) + 4 h + (j & 3) -- so that du2, which the
 // u2 product leaves in accumulator registers (lane = channel, registers = edge rows), is the A operand of the weight
 // gradient as it stands, and the other operand is two 8-byte row reads of the a1' image (edges 16 s + 8 u + 4 h .. + 3).
+template <bool S01>
 __global__ __launch_bounds__(512) void edge_mlp_bwd16_kernel(
     const float *__restrict__ TP, const float *__restrict__ TQ, const int32_t *__restrict__ idx, int N, int k, int P,
     const float *__restrict__ stats1, const float *__restrict__ stats2, const float *__restrict__ cc2,
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(512) void edge_mlp_bwd16_kernel(
                         for (int e = 0; e < 2; ++e) {
                             const int j = 4 * g + 2 * m + e;
                             const float u = p2[j] + q;  // (rows past the end repeat the last row: finite, never used)
-                            const float v = lrelu(__builtin_fmaf(u, sc1g, sh1g), slope);  // a1'
+                            const float v = lrelu_t<S01>(__builtin_fmaf(u, sc1g, sh1g), slope);  // a1'
                             a[e] = full || j < kk ? v : 0.0f;
                             amax = fmaxf(amax, fabsf(a[e]));
                             tU[j * 64 + lane] = u;
@@ -342,8 +343,12 @@ void launch_edge_mlp_bwd16(const float *TP, const float *TQ, const int32_t *idx,
                            float *dvsum, float *partial_dw2, const FoldSet &fs, const BnBackwardSums &fin1, int *guard,
                            int grid, hipStream_t st)
 {
-    hipLaunchKernelGGL(edge_mlp_bwd16_kernel, dim3(grid), dim3(64 * MLP_BWD_WAVES), 0, st, TP, TQ, idx, N, k, P, stats1, stats2,
-                       cc2, w2, slope, training, gy, y, hit2, gmax_bits, dv1, dvsum, partial_dw2, fs, fin1, guard);
+    if (slope >= 0.0f && slope <= 1.0f)
+        hipLaunchKernelGGL(edge_mlp_bwd16_kernel<true>, dim3(grid), dim3(64 * MLP_BWD_WAVES), 0, st, TP, TQ, idx, N, k, P, stats1,
+                           stats2, cc2, w2, slope, training, gy, y, hit2, gmax_bits, dv1, dvsum, partial_dw2, fs, fin1, guard);
+    else
+        hipLaunchKernelGGL(edge_mlp_bwd16_kernel<false>, dim3(grid), dim3(64 * MLP_BWD_WAVES), 0, st, TP, TQ, idx, N, k, P, stats1,
+                           stats2, cc2, w2, slope, training, gy, y, hit2, gmax_bits, dv1, dvsum, partial_dw2, fs, fin1, guard);
 }
 
 }  // namespace dgcnn

@@ -21,6 +21,7 @@ namespace dgcnn {
 constexpr int FWD16_WAVES = 4;
 int mlp_grid_fwd16(int P) { return point_grid(P, FWD16_WAVES, 96); }
 
+template <bool S01>
 __global__ __launch_bounds__(64 * FWD16_WAVES) void edge_mlp_fwd16_kernel(
     const float *__restrict__ TP, const float *__restrict__ TQ, const int32_t *__restrict__ idx, int N, int k, int P,
     const float *__restrict__ stats1, const float *__restrict__ w2, const float *__restrict__ gamma2, float slope,
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(64 * FWD16_WAVES) void edge_mlp_fwd16_kernel(
 #pragma unroll
                         for (int e = 0; e < 2; ++e) {
                             const int j = 4 * g + 2 * m + e;
-                            const float v = lrelu(__builtin_fmaf(p[j & 7] + q, sc1g, sh1g), slope);  // a1'
+                            const float v = lrelu_t<S01>(__builtin_fmaf(p[j & 7] + q, sc1g, sh1g), slope);  // a1'
                             a[e] = full || j < kk ? v : 0.0f;
                             amax = fmaxf(amax, fabsf(a[e]));
                         }
@@ -210,8 +211,12 @@ void launch_edge_mlp_fwd16(const float *TP, const float *TQ, const int32_t *idx,
                            const float *w2, const float *gamma2, float slope, float *usel2, uint8_t *hit2, int fin_on,
                            const FoldSet &fs, const BnBatchStats &fin, int *guard, hipStream_t st)
 {
-    hipLaunchKernelGGL(edge_mlp_fwd16_kernel, dim3(mlp_grid_fwd16(P)), dim3(64 * FWD16_WAVES), 0, st, TP, TQ, idx, N, k, P, stats1, w2, gamma2,
-                       slope, usel2, hit2, fin_on, fs, fin, guard);
+    if (slope >= 0.0f && slope <= 1.0f)
+        hipLaunchKernelGGL(edge_mlp_fwd16_kernel<true>, dim3(mlp_grid_fwd16(P)), dim3(64 * FWD16_WAVES), 0, st, TP, TQ, idx, N, k, P,
+                           stats1, w2, gamma2, slope, usel2, hit2, fin_on, fs, fin, guard);
+    else
+        hipLaunchKernelGGL(edge_mlp_fwd16_kernel<false>, dim3(mlp_grid_fwd16(P)), dim3(64 * FWD16_WAVES), 0, st, TP, TQ, idx, N, k, P,
+                           stats1, w2, gamma2, slope, usel2, hit2, fin_on, fs, fin, guard);
 }
 
 }  // namespace dgcnn
