@@ -48,7 +48,8 @@ __global__ __launch_bounds__(64 * FWD16_WAVES) void edge_mlp_fwd16_kernel(
     for (int t = threadIdx.x; t < 4096; t += 64 * FWD16_WAVES) {
         const int co = t >> 6, ci = t & 63;
         unsigned H, L;
-        split_pair(w2[t] * sW, 0.0f, H, L);
+        // (output channels with gamma2 < 0 carry -W2: the extreme of the activation is then always a maximum of u2raw)
+        split_pair(w2[t] * (gamma2[co] < 0.0f ? -sW : sW), 0.0f, H, L);
         const int off = co * 128 + (((ci >> 3) ^ w2_swz(co)) << 4) + (ci & 7) * 2;
         *reinterpret_cast<unsigned short *>(w2p + off) = (unsigned short)H;
         *reinterpret_cast<unsigned short *>(w2p + W2_PLANE + off) = (unsigned short)L;
@@ -68,12 +69,14 @@ __global__ __launch_bounds__(64 * FWD16_WAVES) void edge_mlp_fwd16_kernel(
     const unsigned rowW = i32 * 128 + ((h ^ w2_swz(i32)) << 4);  // W2 row 32 nt + i32, chunk 2 s + h: (rowW ^ (s << 5)) + 4096 nt
     const unsigned wT = lane * 64 + (t_swz(lane) << 3);          // T row ci = lane, chunk g: wT ^ (g << 3)
 
-    unsigned flip[2];  // gamma2 < 0: the activation's maximum is the pre-activation's minimum
+    // u2 = uns u2raw: the power-of-two scales and the sign of the W2' row leave in one exact multiplication, applied to
+    // the sums and to the extreme only (scaling by a power of two commutes with every rounding in between)
+    const float un = 1.0f / (MB_SA * sW);
+    float uns[2];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) flip[nt] = gamma2[nt * 32 + i32] < 0.0f ? 0x80000000u : 0u;
+    for (int nt = 0; nt < 2; ++nt) uns[nt] = gamma2[nt * 32 + i32] < 0.0f ? -un : un;
     // (LeakyReLU is positively homogeneous: a1' = 2^8 a1 = LReLU(2^8 sc1 u + 2^8 sh1))
     const float sc1g = stats1[ST_SC + lane] * MB_SA, sh1g = stats1[ST_SH + lane] * MB_SA;
-    const float un = 1.0f / (MB_SA * sW);
 
     double sum[2] = {0.0, 0.0}, sq[2] = {0.0, 0.0};
     float amax = 0.0f;
@@ -83,10 +86,10 @@ __global__ __launch_bounds__(64 * FWD16_WAVES) void edge_mlp_fwd16_kernel(
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(TP + (size_t)b * N * EC), 0, N * EC * 4, 0x00020000);
         const float q = TQ[(size_t)pt * EC + lane];
         const int32_t *ip = idx + (size_t)pt * k;
-        float ext[2], ps[2] = {0.0f, 0.0f}, pq[2] = {0.0f, 0.0f};  // fp32 over the <= 32 values of a lane, fp64 across points
+        float ext[2], ps[2] = {0.0f, 0.0f}, pq[2] = {0.0f, 0.0f};  // of u2raw: fp32 over the <= 32 values of a lane, fp64 across points
         int arg[2] = {0, 0};  // edge slot of the extreme (the first one on ties): the backward routes dL/dy there
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) ext[nt] = -__builtin_inff();  // of the sign-flipped value
+        for (int nt = 0; nt < 2; ++nt) ext[nt] = -__builtin_inff();
         for (int j0 = 0; j0 < k; j0 += 32) {
             const int kk = k - j0 < 32 ? k - j0 : 32;
             {
@@ -149,30 +152,38 @@ __global__ __launch_bounds__(64 * FWD16_WAVES) void edge_mlp_fwd16_kernel(
                     const half8 blo = *reinterpret_cast<const half8 *>(bp + W2_PLANE);
                     acc = mfma3(ahi[s], alo[s], bhi, blo, acc);
                 }
-                // statistics over all rows (exactly 0 in the padding rows: a1' = 0), then the extreme of the sign-flipped
-                // value (so that it is always a maximum) over the rows that are edges, and the first slot that holds it
+                // statistics over all rows (exactly 0 in the padding rows: a1' = 0), then the maximum over the rows that
+                // are edges, and the first slot that holds it -- all on the raw accumulators, which stay as they are (the
+                // group of eight rows that holds the list end is the only one that selects; branches are wave-uniform)
                 float best = -__builtin_inff();
                 static_for<4>([&](auto G) {
                     constexpr int g = decltype(G)::value;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const int r = 4 * g + e;
-                        const float u = acc[r] * un;
-                        ps[nt] += u;
-                        pq[nt] = __builtin_fmaf(u, u, pq[nt]);
-                        acc[r] = __uint_as_float(__float_as_uint(u) ^ flip[nt]);
+                        ps[nt] += acc[4 * g + e];
+                        pq[nt] = __builtin_fmaf(acc[4 * g + e], acc[4 * g + e], pq[nt]);
                     }
-                    if (8 * g + 8 > kk) {  // (wave-uniform) the list ends inside or before this group of rows
+                    if (8 * g + 8 <= kk) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[4 * g + e] = 8 * g + e < kkh ? acc[4 * g + e] : -__builtin_inff();
+                        for (int e = 0; e < 4; ++e) best = fmaxf(best, acc[4 * g + e]);
+                    } else if (8 * g < kk) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) best = fmaxf(best, 8 * g + e < kkh ? acc[4 * g + e] : -__builtin_inff());
                     }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) best = fmaxf(best, acc[4 * g + e]);
                 });
                 if (best > ext[nt]) {
                     int slot = 0;
+                    static_for<4>([&](auto GR) {
+                        constexpr int g = 3 - decltype(GR)::value;  // descending: the first row that holds the maximum wins
+                        if (8 * g + 8 <= kk) {
 #pragma unroll
-                    for (int r = 15; r >= 0; --r) slot = acc[r] == best ? mfma32_row(r, h) : slot;
+                            for (int e = 3; e >= 0; --e) slot = acc[4 * g + e] == best ? mfma32_row(4 * g + e, h) : slot;
+                        } else if (8 * g < kk) {
+#pragma unroll
+                            for (int e = 3; e >= 0; --e)
+                                slot = (acc[4 * g + e] == best && 8 * g + e < kkh) ? mfma32_row(4 * g + e, h) : slot;
+                        }
+                    });
                     ext[nt] = best;
                     arg[nt] = j0 + slot;
                 }
@@ -186,7 +197,7 @@ __global__ __launch_bounds__(64 * FWD16_WAVES) void edge_mlp_fwd16_kernel(
             const int oa = __shfl_xor(arg[nt], 32);
             const bool take = o > ext[nt] || (o == ext[nt] && oa < arg[nt]);
             if (h == 0) {
-                usel2[(size_t)pt * EC + nt * 32 + i32] = __uint_as_float(__float_as_uint(take ? o : ext[nt]) ^ flip[nt]);
+                usel2[(size_t)pt * EC + nt * 32 + i32] = (take ? o : ext[nt]) * uns[nt];
                 hit2[(size_t)pt * EC + nt * 32 + i32] = (uint8_t)(take ? oa : arg[nt]);
             }
         }
@@ -198,8 +209,9 @@ __global__ __launch_bounds__(64 * FWD16_WAVES) void edge_mlp_fwd16_kernel(
     // BN2 batch statistics (training): lane (n, h) holds channel nt * 32 + n; fold the halves -- lane l then carries
     // channel l (nt = h) -- and let the pass finish the sums itself (fold.h)
     if (fin_on) {
-        const double t0 = sum[0] + shfl_xor_d(sum[0], 32), t1 = sum[1] + shfl_xor_d(sum[1], 32);
-        const double q0 = sq[0] + shfl_xor_d(sq[0], 32), q1 = sq[1] + shfl_xor_d(sq[1], 32);
+        const double s0 = sum[0] * (double)uns[0], s1 = sum[1] * (double)uns[1], un2 = (double)un * (double)un;
+        const double t0 = s0 + shfl_xor_d(s0, 32), t1 = s1 + shfl_xor_d(s1, 32);
+        const double q0 = (sq[0] + shfl_xor_d(sq[0], 32)) * un2, q1 = (sq[1] + shfl_xor_d(sq[1], 32)) * un2;
         const double v[2] = {h ? t1 : t0, h ? q1 : q0};
         __syncthreads();  // every wave is done with its tile: the tile memory is the fold's scratch
         double(*red)[2][64] = reinterpret_cast<double(*)[2][64]>(tiles);
