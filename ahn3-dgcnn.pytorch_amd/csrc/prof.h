@@ -11,8 +11,8 @@ enum ProfRegion {
     PROF_KNN_REFINE,      // knn_refine_kernel: exact fp32 distances of the survivors, selection
     PROF_EDGE_REDUCE,     // edge_reduce_kernel: forward gather, BatchNorm statistics, max-over-k
     PROF_EDGE_RGATHER,    // edge_rgather_kernel (both launches): backward gather over the reverse kNN graph
-    PROF_EDGE_MLP_FWD,    // edge_mlp_fwd_kernel: second 64 -> 64 convolution of a two-stage block, forward
-    PROF_EDGE_MLP_BWD,    // edge_mlp_bwd_kernel: its backward (recompute, weight and input gradients, dv1)
+    PROF_EDGE_MLP_FWD,    // edge_mlp_fwd16_kernel (+ its idle fp32 fallback): second 64 -> 64 convolution of a two-stage block, forward
+    PROF_EDGE_MLP_BWD,    // edge_mlp_bwd16_kernel (+ its idle fp32 fallback): its backward (recompute, weight and input gradients, dv1)
     PROF_NREGION
 };
 

@@ -327,9 +327,9 @@ def run_block(args, rank, world, dev):
                                 "and (one-stage) its hit record; per point list bounds, TP read, dR written"),
         "edge_mlp_fwd_kernel": ("mfma", conv2, PEAK_F16_MFMA_TFLOPS,
                                 "conv 64->64 per edge, 2 E 64 64 flops; executed as 3 split-fp16 products on fp16 MFMA"),
-        "edge_mlp_bwd_kernel": ("mfma", 2 * conv2, PEAK_F32_MFMA_TFLOPS,
+        "edge_mlp_bwd_kernel": ("mfma", 2 * conv2, PEAK_F16_MFMA_TFLOPS,
                                 "dgrad + wgrad of conv 64->64 per edge, 2 x 2 E 64 64 flops (the kernel also recomputes the "
-                                "forward product); see `mlp_bwd_math` for the MFMA type in this build"),
+                                "forward product); each executed as 3 split-fp16 products on fp16 MFMA"),
     }
     traffic = load_traffic("hbm_bytes_per_launch") if args.stages == 1 and (B, N, k, C) == (8, 7000, 30, 64) else {}
     kernels = kernel_entries(regions, work, traffic)
@@ -468,9 +468,9 @@ def run_train(args, rank, world, dev, steps, warmup, with_cpu):
     work = {
         "edge_mlp_fwd_kernel": ("mfma", conv2, PEAK_F16_MFMA_TFLOPS,
                                 "conv2 / conv4 per edge, 2 E 64 64 flops per launch; executed as 3 split-fp16 products"),
-        "edge_mlp_bwd_kernel": ("mfma", 2 * conv2, PEAK_F32_MFMA_TFLOPS,
+        "edge_mlp_bwd_kernel": ("mfma", 2 * conv2, PEAK_F16_MFMA_TFLOPS,
                                 "dgrad + wgrad of conv2 / conv4 per edge, 2 x 2 E 64 64 flops per launch (the kernel also "
-                                "recomputes the forward product)"),
+                                "recomputes the forward product); each executed as 3 split-fp16 products on fp16 MFMA"),
     }
     kernels = kernel_entries(regions, work, {})
     step_flops = 12.04e6 * Bl * N   # 12.04 MFLOP per point for the full training step
