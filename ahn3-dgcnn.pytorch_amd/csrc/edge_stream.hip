@@ -768,7 +768,7 @@ __global__ __launch_bounds__(256) void edge_rgather_kernel(const float *__restri
     const float c1 = cc[lane], c2 = cc[64 + lane];
     // the TQ table behind a buffer descriptor: a row gather is one instruction with a scalar row offset (P EC 4 < 2^32
     // is checked by the launcher)
-    const __amdgpu_buffer_rsrc_t TQb = __builtin_amdgcn_make_buffer_rsrc((void *)TQ, 0, P * EC * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t TQb = __builtin_amdgcn_make_buffer_rsrc((void *)TQ, 0, (int)((unsigned)P * (unsigned)(EC * 4)), 0x00020000);
     RgatherCtx cx;
     cx.TP = TP;
     cx.dR = dR;

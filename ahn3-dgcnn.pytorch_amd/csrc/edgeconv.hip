@@ -154,7 +154,10 @@ static int check_desc(const dgcnn_edgeconv_desc *d, const char *who)
     DG_REQUIRE(d->C <= 64, "%s: C=%d > 64 unsupported", who, d->C);
     DG_REQUIRE(d->k <= 96, "%s: k=%d > 96 unsupported", who, d->k);
     DG_REQUIRE((size_t)d->B * d->N * d->k < ((size_t)1 << 31), "%s: more than 2^31 edges", who);
-    DG_REQUIRE((size_t)d->B * d->N < ((size_t)1 << 25), "%s: more than 2^25 points", who);  // 32-bit row offsets
+    DG_REQUIRE((size_t)d->B * d->N < ((size_t)1 << 24), "%s: more than 2^24 points", who);  // 32-bit byte offsets of rows
+    // (the block takes max over k BEFORE BatchNorm's affine map and the activation, on the side the sign of gamma
+    // selects: the activation has to be non-decreasing)
+    DG_REQUIRE(d->slope >= 0.0f, "%s: LeakyReLU slope %g < 0 unsupported", who, (double)d->slope);
     DG_REQUIRE(d->n_stage == 1 || d->n_stage == 2, "%s: n_stage must be 1 or 2", who);
     DG_REQUIRE(d->w1 && d->bn1.weight && d->bn1.bias, "%s: stage-1 parameters missing", who);
     DG_REQUIRE(d->training || (d->bn1.running_mean && d->bn1.running_var), "%s: eval mode needs running statistics",

@@ -298,25 +298,34 @@ __global__ __launch_bounds__(256) void knn_prep16_kernel(const float *__restrict
     __shared__ float yys[32];
     const int tid = threadIdx.x;
     const int b = blockIdx.y, tile = blockIdx.x, q0 = tile * 32;
+    // the tile's rows are on their way while the centre is computed (C <= 128: at most 16 elements per thread)
+    float trow[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int i = tid + 256 * u;
+        trow[u] = (i < 32 * C && q0 + i / C < N) ? x[((size_t)b * N + q0) * C + i] : 0.0f;
+    }
     knn_centre(x, b, N, C, cred, ms);
     if (tid == 0) rbflag[(size_t)b * (Npad / 32) + tile] = 0;  // fallback flag of this row block (set by filter / refine)
-    for (int i = tid; i < 32 * C; i += 256) {
-        const int r = i / C, c = i - r * C;
-        xs[r][c] = q0 + r < N ? x[((size_t)b * N + q0) * C + i] : 0.0f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int i = tid + 256 * u;
+        if (i < 32 * C) xs[i / C][i % C] = trow[u];
     }
     __syncthreads();
     // norms: wave 0 lanes 0..31 the raw chain, wave 1 lanes 0..31 the centred one
     if ((tid & 63) < 32 && tid < 128) {
         const int r = tid & 31;
         const bool centred = tid >= 64;
+        // one fma chain in channel order (the oracle's); the LDS reads of sixteen channels are issued together, so
+        // that the chain pays the fma latency per channel and not an LDS round trip (channels past C add fma(0, 0, acc))
         float acc = 0.0f;
-        if (centred) {
-            for (int c = 0; c < C; ++c) {
-                const float d = xs[r][c] - ms[c];
-                acc = __builtin_fmaf(d, d, acc);
-            }
-        } else {
-            for (int c = 0; c < C; ++c) acc = __builtin_fmaf(xs[r][c], xs[r][c], acc);
+        for (int c0 = 0; c0 < C; c0 += 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = c0 + u < C ? xs[r][c0 + u] - (centred ? ms[c0 + u] : 0.0f) : 0.0f;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc = __builtin_fmaf(v[u], v[u], acc);
         }
         const bool real = q0 + r < N;
         (centred ? xxc : xx)[(size_t)b * Npad + q0 + r] = real ? acc : __builtin_inff();

@@ -35,7 +35,7 @@ def run_oracle(x, idx, stages, train, R):
     return y.detach(), xr.grad, stages
 
 
-def run_hip(x, idx, stages_cpu, train, R, device, need_gx=True):
+def run_hip(x, idx, stages_cpu, train, R, device, need_gx=True, slope=0.2):
     from ahn3_dgcnn_pytorch_amd import ops
     import copy
     stages = [copy.deepcopy(s).to(device) for s in stages_cpu]
@@ -46,7 +46,7 @@ def run_hip(x, idx, stages_cpu, train, R, device, need_gx=True):
     idx_d = torch.from_numpy(idx).to(device)
     w2 = stages[1][0].weight if len(stages) == 2 else None
     bn2 = stages[1][1] if len(stages) == 2 else None
-    y_pm = ops.edgeconv_pm(x_pm, idx_d, stages[0][0].weight, stages[0][1], w2, bn2, training=train, slope=0.2)
+    y_pm = ops.edgeconv_pm(x_pm, idx_d, stages[0][0].weight, stages[0][1], w2, bn2, training=train, slope=slope)
     y = ops.from_point_major_autograd(y_pm)
     (y * R.to(device)).sum().backward()
     torch.cuda.synchronize()
@@ -116,6 +116,35 @@ def test_single_stage_block(B, C, N, k, train, device):
 @pytest.mark.parametrize("B,C,N,k", [(2, 64, 300, 20), (2, 4, 257, 30), (1, 5, 100, 8), (1, 64, 70, 40), (1, 64, 40, 32)])
 def test_two_stage_block(B, C, N, k, train, device):
     compare(B, C, N, k, 2, train, device)
+
+
+@pytest.mark.parametrize("n_stage", [1, 2])
+def test_block_with_leaky_slope_above_one(n_stage, device):
+    """LeakyReLU(1.5): still non-decreasing, so the fused max-before-activation holds; the per-edge kernels of the
+    two-stage block then take their compare-and-select form of the activation instead of max(v, slope v)."""
+    import copy
+    B, C, N, k, slope = 2, 16, 300, 20, 1.5
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(B, C, N, generator=g)
+    idx = ke.knn_exact(x.numpy(), k)
+    base = make_stages(2 * C, n_stage)
+    for st in base:
+        st[2] = torch.nn.LeakyReLU(negative_slope=slope)
+    R = cotangent((B, 64, N), tag="edge")
+    y0, gx0, st0 = run_oracle(x, idx, copy.deepcopy(base), True, R)
+    y1, gx1, st1 = run_hip(x, idx, base, True, R, device, slope=slope)
+    np.testing.assert_allclose(y1.numpy(), y0.numpy(), rtol=0, atol=ATOL_FWD)
+    for a, b in [(gx1, gx0)] + [(s1[0].weight.grad.cpu(), s0[0].weight.grad) for s0, s1 in zip(st0, st1)]:
+        assert float((a - b).abs().max()) <= RTOL_GRAD * float(b.abs().max())
+
+
+def test_negative_leaky_slope_is_refused(device):
+    from ahn3_dgcnn_pytorch_amd import ops
+    st = make_stages(8, 1)[0].to(device)
+    x = torch.randn(1, 50, 4, device=device)
+    idx = ops.knn_pm(x, 4)
+    with pytest.raises(RuntimeError, match="slope"):
+        ops.edgeconv_pm(x, idx, st[0].weight, st[1], training=True, slope=-0.1)
 
 
 def test_single_stage_block_at_benchmark_size(device):
