@@ -286,8 +286,10 @@ __device__ __forceinline__ float batch_max(const unsigned *__restrict__ tmax, in
 //   bmax[b][which][tile] = largest centred (which = 0) / raw (1) norm of the tile, as uint bits of non-negative
 //        floats (NaN bits win the comparison, as they must); batch_max() reduces them where they are needed
 //   rbflag[b][tile] = 0: the fallback flag of the row block, set later by the filter / refine kernels
+// CC: the channel count when it is known at compile time (64: the index arithmetic is shifts; 0: C and CP at run time)
+template <int CC>
 __global__ __launch_bounds__(256) void knn_prep16_kernel(const float *__restrict__ x,
-                                                         int N, int C, int Npad, int CP, float *__restrict__ xx,
+                                                         int N, int C_, int Npad, int CP_, float *__restrict__ xx,
                                                          float *__restrict__ xxc, half8 *__restrict__ xh,
                                                          float *__restrict__ xt, unsigned *__restrict__ bmax,
                                                          int *__restrict__ rbflag)
@@ -297,6 +299,7 @@ __global__ __launch_bounds__(256) void knn_prep16_kernel(const float *__restrict
     __shared__ float cred[256];
     __shared__ float yys[32];
     const int tid = threadIdx.x;
+    const int C = CC ? CC : C_, CP = CC ? CC : CP_;
     const int b = blockIdx.y, tile = blockIdx.x, q0 = tile * 32;
     // the tile's rows are on their way while the centre is computed (C <= 128: at most 16 elements per thread)
     float trow[16];
@@ -1847,8 +1850,12 @@ extern "C" int dgcnn_knn(const float *x, int B, int N, int C, int k, int32_t *id
     const bool f16path = prepass && CP >= 16 && !f16_off;
     if (prepass && CP >= 16) {
         // one pass over x: norms, fp16 and fp32 operand tiles, norm maxima (after the centre of each batch element)
-        hipLaunchKernelGGL(knn_prep16_kernel, dim3(Npad / 32, B), dim3(256), 0, st, x, N, C, Npad, CP, xx, w.xxc, w.xh,
-                           xt, w.bmax, w.rbflag);
+        if (C == 64 && CP == 64)
+            hipLaunchKernelGGL(knn_prep16_kernel<64>, dim3(Npad / 32, B), dim3(256), 0, st, x, N, C, Npad, CP, xx, w.xxc, w.xh,
+                               xt, w.bmax, w.rbflag);
+        else
+            hipLaunchKernelGGL(knn_prep16_kernel<0>, dim3(Npad / 32, B), dim3(256), 0, st, x, N, C, Npad, CP, xx, w.xxc, w.xh,
+                               xt, w.bmax, w.rbflag);
     } else {
         hipLaunchKernelGGL(knn_norm_kernel, dim3(ceil_div(Npad, 256), B), dim3(256), 0, st, x, N, C, Npad, xx);
         const size_t nvec = (size_t)Npad * CP / (CP >= 8 ? 4 : 2);

@@ -7,7 +7,10 @@
 // ([P][64] each); the edge passes then only gather-and-add rows of TP.  The same identity turns
 // the first convolution's backward into two more per-point products (dgrad and wgrad) over the
 // scatter-reduced edge gradients.  All three run here on the exact-fp32 MFMA.
+#include <stdlib.h>
+
 #include "edge_kernels.h"
+#include "edge_mlp16.h"
 
 namespace dgcnn {
 
@@ -193,6 +196,126 @@ __global__ __launch_bounds__(256) void rowgemm_fast_kernel(const float *__restri
     }
 }
 
+// The same two products on the fp16 matrix cores: both operands scaled by an exact power of two and split in two fp16
+// halves, x' = hi + lo (edge_mlp16.h), three v_mfma_f32_32x32x16_f16 per 16 k (hi.hi + hi.lo + lo.hi, fp32 accumulate):
+// 48 matrix instructions of 32 cycles per 32-row tile instead of 128 of 64 -- the fp32 kernel above is bound by exactly
+// that (MFMA-dense code runs at 1.3-1.7 GHz on this chip).  The dropped lo.lo term and the rounding of lo are 2^-22
+// relative to the largest element of the tile.  Scales: W' = sW W with sW from max |W| (every workgroup finds it
+// itself), A' = sA A with sA from the largest magnitude of the WAVE'S OWN 32-row tile -- a local, exact scale, so that
+// gradients of any magnitude go through without a range check or a fallback; the accumulators leave with 1 / (sA sW).
+// W image: fp16 planes [n][k] (hi plane, lo plane), 16-byte chunks XOR-swizzled so that the row reads are conflict-free.
+template <int KH, int NT, bool FROM_W1>
+__global__ __launch_bounds__(256) void rowgemm_split_kernel(const float *__restrict__ A0, int K0,
+                                                            const float *__restrict__ A1, int K1,
+                                                            const float *__restrict__ W, float *__restrict__ Y0, int NO0,
+                                                            float *__restrict__ Y1, int P, float *__restrict__ wcat,
+                                                            int *__restrict__ zero_words, int nzero)
+{
+    constexpr int K = 2 * KH, NO = 32 * NT, ROWB = K * 2, PLANE = NO * ROWB;
+    static_assert(K * NO == 8192 && (K == 64 || K == 128), "the two shapes of the 64-channel blocks");
+    __shared__ __attribute__((aligned(16))) unsigned char wp[2 * PLANE];
+    __shared__ float s_red[4];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), h = lane >> 5, i32 = lane & 31;
+    const int p0 = (blockIdx.x * 4 + wave) * 32;
+    const int row = p0 + i32 < P ? p0 + i32 : P - 1;  // clamped: loads are unconditional, stores guarded
+    const float *src = (K1 == 0 || h == 0) ? A0 + (size_t)row * K0 + h * (K1 == 0 ? KH : 0) : A1 + (size_t)row * K1;
+    float4 av[KH / 4];
+#pragma unroll
+    for (int i = 0; i < KH / 4; ++i) av[i] = reinterpret_cast<const float4 *>(src)[i];
+
+    // ---- W: item e of a thread = four consecutive k of one output column n
+    if (FROM_W1) fwd_side_jobs(W, K, wcat, zero_words, nzero);
+    float4 wv[8];
+    float wmax = 0.0f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int e = threadIdx.x + 256 * u;
+        if (FROM_W1) {  // K = C = 64, NO = 128: column n of Wcat^T is row n of [Wa ; Wb - Wa]
+            const int n = e & 127, k4 = (e >> 7) * 4;
+            const float *r = W + (size_t)(n & 63) * 2 * K;
+            float4 v = *reinterpret_cast<const float4 *>(r + k4);
+            if (n >= EC) {
+                const float4 b = *reinterpret_cast<const float4 *>(r + K + k4);
+                v = float4{b.x - v.x, b.y - v.y, b.z - v.z, b.w - v.w};
+            }
+            wv[u] = v;
+        } else {  // W [K][NO] row-major
+            const int n = e & (NO - 1), k4 = (e / NO) * 4;
+            wv[u] = float4{W[(size_t)(k4 + 0) * NO + n], W[(size_t)(k4 + 1) * NO + n], W[(size_t)(k4 + 2) * NO + n],
+                           W[(size_t)(k4 + 3) * NO + n]};
+        }
+        wmax = fmaxf(fmaxf(wmax, fmaxf(fabsf(wv[u].x), fabsf(wv[u].y))), fmaxf(fabsf(wv[u].z), fabsf(wv[u].w)));
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o));
+    if (lane == 0) s_red[wave] = wmax;
+    __syncthreads();
+    const float sW = scale_to(fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3])), 12);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int e = threadIdx.x + 256 * u;
+        const int n = FROM_W1 ? (e & 127) : (e & (NO - 1)), k4 = FROM_W1 ? (e >> 7) * 4 : (e / NO) * 4;
+        const int swz = K == 64 ? w2_swz(n) : (n & 15);
+        const int off = n * ROWB + ((((k4 >> 3)) ^ swz) << 4) + (k4 & 7) * 2;
+        unsigned H0, L0, H1, L1;
+        split_pair(wv[u].x * sW, wv[u].y * sW, H0, L0);
+        split_pair(wv[u].z * sW, wv[u].w * sW, H1, L1);
+        *reinterpret_cast<uint2 *>(wp + off) = make_uint2(H0, H1);
+        *reinterpret_cast<uint2 *>(wp + PLANE + off) = make_uint2(L0, L1);
+    }
+
+    // ---- A: the tile's own scale, then the split (lane half h holds k = h KH .. h KH + KH - 1 of its row)
+    float amax = 0.0f;
+#pragma unroll
+    for (int i = 0; i < KH / 4; ++i)
+        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(av[i].x), fabsf(av[i].y))), fmaxf(fabsf(av[i].z), fabsf(av[i].w)));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+    const float sA = scale_to(amax, 10);
+    unsigned aH[KH / 2], aL[KH / 2];
+#pragma unroll
+    for (int i = 0; i < KH / 4; ++i) {
+        split_pair(av[i].x * sA, av[i].y * sA, aH[2 * i], aL[2 * i]);
+        split_pair(av[i].z * sA, av[i].w * sA, aH[2 * i + 1], aL[2 * i + 1]);
+    }
+    __syncthreads();
+    if (p0 >= P) return;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
+    // step s of lane half h covers k = h KH + 8 s .. + 7: chunk h KH / 8 + s of the image rows
+#pragma unroll
+    for (int s = 0; s < KH / 8; ++s) {
+        const half8 ahi = words_as_half8(aH[4 * s], aH[4 * s + 1], aH[4 * s + 2], aH[4 * s + 3]);
+        const half8 alo = words_as_half8(aL[4 * s], aL[4 * s + 1], aL[4 * s + 2], aL[4 * s + 3]);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = nt * 32 + i32;
+            const int swz = K == 64 ? w2_swz(n) : (n & 15);
+            const unsigned char *bp = wp + n * ROWB + (((h * (KH / 8) + s) ^ swz) << 4);
+            const half8 bhi = *reinterpret_cast<const half8 *>(bp);
+            const half8 blo = *reinterpret_cast<const half8 *>(bp + PLANE);
+            acc[nt] = mfma3(ahi, alo, bhi, blo, acc[nt]);
+        }
+    }
+    const float un = 1.0f / (sA * sW);
+    const bool full = p0 + 32 <= P;
+    const int NO1 = NO - NO0;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = nt * 32 + i32;
+        float *dst = n < NO0 ? Y0 + n : Y1 + (n - NO0);
+        const int ld = n < NO0 ? NO0 : NO1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int pr = p0 + mfma32_row(r, h);
+            if (full || pr < P) dst[(size_t)pr * ld] = acc[nt][r] * un;
+        }
+    }
+}
+
 constexpr int WGRAD_CHUNK = 64;  // points per wave (875 waves at P = 56 000)
 
 // partial[chunk][m][n] = sum_p A(p, m) X[p][n]: contraction over the points (MFMA K dimension).
@@ -347,11 +470,29 @@ __global__ __launch_bounds__(1024) void finish_dw1_kernel(const float *__restric
 }
 
 // ---------------------------------------------------------------------------------------------
+static bool rowgemm_force_f32()  // experiments / tests: the fp32-MFMA form of the backward products
+{
+    static const int v = getenv("DGCNN_ROWGEMM_F32") ? atoi(getenv("DGCNN_ROWGEMM_F32")) : 0;
+    return v != 0;
+}
+// The FORWARD product stays on the fp32 MFMA: TP and TQ decide which edge wins max-over-k, and at 2^-22 instead of 2^-24
+// the winners of near-ties (gaps of a few 1e-6 after BatchNorm and the second convolution) move away from the
+// reference's -- measured: 16.4 us against 21.1, and one gradient-parity case of the two-stage block lost.  The switch
+// keeps the experiment runnable.
+static bool rowgemm_split_fwd()
+{
+    static const int v = getenv("DGCNN_ROWGEMM_SPLIT_FWD") ? atoi(getenv("DGCNN_ROWGEMM_SPLIT_FWD")) : 0;
+    return v != 0;
+}
+
 void launch_rowgemm_fwd(const float *x, int C, const float *w1, float *TP, float *TQ, float *wcat, int *zero_words,
                         int nzero, int P, hipStream_t st)
 {
     const dim3 grid(ceil_div(ceil_div(P, 32), 4)), block(256);
-    if (C == 64)
+    if (C == 64 && rowgemm_split_fwd())
+        hipLaunchKernelGGL((rowgemm_split_kernel<32, 4, true>), grid, block, 0, st, x, C, nullptr, 0, w1, TP, EC, TQ, P, wcat,
+                           zero_words, nzero);
+    else if (C == 64)
         hipLaunchKernelGGL((rowgemm_fast_kernel<32, 4, true>), grid, block, 0, st, x, C, nullptr, 0, w1, TP, EC, TQ, P, wcat,
                            zero_words, nzero);
     else
@@ -367,6 +508,15 @@ void launch_rowgemm(const float *A0, int K0, const float *A1, int K1, const floa
     const int K = K0 + K1, NO1 = NO - NO0;
     const bool runs_ok = (K1 == 0 || K0 == K / 2) && (K0 & 3) == 0 && (K1 & 3) == 0;
     if (runs_ok && NO0 % 32 == 0 && NO1 % 32 == 0 && (NO1 == 0 || Y1)) {
+        if (!rowgemm_force_f32() && ((K == 64 && NO == 128) || (K == 128 && NO == 64))) {
+            if (K == 64)
+                hipLaunchKernelGGL((rowgemm_split_kernel<32, 4, false>), grid, block, 0, st, A0, K0, A1, K1, W, Y0, NO0, Y1, P,
+                                   nullptr, nullptr, 0);
+            else
+                hipLaunchKernelGGL((rowgemm_split_kernel<64, 2, false>), grid, block, 0, st, A0, K0, A1, K1, W, Y0, NO0, Y1, P,
+                                   nullptr, nullptr, 0);
+            return;
+        }
         if (K == 64 && NO == 128) {
             hipLaunchKernelGGL((rowgemm_fast_kernel<32, 4, false>), grid, block, 0, st, A0, K0, A1, K1, W, Y0, NO0, Y1, P,
                                nullptr, nullptr, 0);
