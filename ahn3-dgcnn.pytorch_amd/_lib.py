@@ -18,7 +18,8 @@ _c_int, _c_i64, _c_sz, _c_vp, _c_f = ctypes.c_int, ctypes.c_int64, ctypes.c_size
 
 class BnParams(ctypes.Structure):
     """mirror of `dgcnn_bn_params` (include/dgcnn_hip.h)"""
-    _fields_ = [("weight", _c_vp), ("bias", _c_vp), ("running_mean", _c_vp), ("running_var", _c_vp)]
+    _fields_ = [("weight", _c_vp), ("bias", _c_vp), ("running_mean", _c_vp), ("running_var", _c_vp),
+                ("num_batches_tracked", _c_vp)]
 
 
 class EdgeConvDesc(ctypes.Structure):

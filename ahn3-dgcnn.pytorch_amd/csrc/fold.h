@@ -161,6 +161,7 @@ struct BnBatchStats {
         double v = t[1] / count - m * m;
         if (v < 0.0) v = 0.0;
         const float mean = (float)m, var = (float)v;
+        if (c == 0 && bn.num_batches_tracked) *bn.num_batches_tracked += 1;  // (one thread of one workgroup finishes channel 0)
         if (bn.running_mean) {
             const double unbiased = count > 1.0 ? v * count / (count - 1.0) : v;
             bn.running_mean[c] = (1.0f - momentum) * bn.running_mean[c] + momentum * mean;

@@ -127,25 +127,26 @@ def graph_feature_pm(x_pm, idx):
 
 
 # ------------------------------------------------------------------------------------------------
-def _bn_struct(weight, bias, rmean, rvar):
+def _bn_struct(weight, bias, rmean, rvar, nbt=None):
     s = _lib.BnParams()
     s.weight, s.bias = weight.data_ptr(), bias.data_ptr()
     s.running_mean = rmean.data_ptr() if rmean is not None else None
     s.running_var = rvar.data_ptr() if rvar is not None else None
+    s.num_batches_tracked = nbt.data_ptr() if nbt is not None else None
     return s
 
 
-def _make_desc(B, N, C, k, training, eps, momentum, slope, w1, g1, b1, rm1, rv1, w2, g2, b2, rm2, rv2):
+def _make_desc(B, N, C, k, training, eps, momentum, slope, w1, g1, b1, rm1, rv1, w2, g2, b2, rm2, rv2, nbt1=None, nbt2=None):
     d = _lib.EdgeConvDesc()
     d.B, d.N, d.C, d.k = B, N, C, k
     d.n_stage = 2 if w2 is not None else 1
     d.training = 1 if training else 0
     d.eps, d.momentum, d.slope = eps, momentum, slope
     d.w1 = w1.data_ptr()
-    d.bn1 = _bn_struct(g1, b1, rm1, rv1)
+    d.bn1 = _bn_struct(g1, b1, rm1, rv1, nbt1)
     if w2 is not None:
         d.w2 = w2.data_ptr()
-        d.bn2 = _bn_struct(g2, b2, rm2, rv2)
+        d.bn2 = _bn_struct(g2, b2, rm2, rv2, nbt2)
     return d
 
 
@@ -153,7 +154,7 @@ class _EdgeConv(torch.autograd.Function):
     """One EdgeConv block (reference model.py:147-150 / 154-157 / 161-163) through the C ABI."""
 
     @staticmethod
-    def forward(ctx, x_pm, idx, w1, g1, b1, w2, g2, b2, rm1, rv1, rm2, rv2, training, eps, momentum, slope):
+    def forward(ctx, x_pm, idx, w1, g1, b1, w2, g2, b2, rm1, rv1, rm2, rv2, training, eps, momentum, slope, nbt1, nbt2):
         B, N, C = x_pm.shape
         k = idx.shape[2]
         lib = _lib.load()
@@ -162,7 +163,8 @@ class _EdgeConv(torch.autograd.Function):
         w2c = w2.detach().reshape(64, 64).contiguous() if w2 is not None else None
         tens = [t.detach().contiguous() if t is not None else None for t in (g1, b1, g2, b2)]
         g1c, b1c, g2c, b2c = tens
-        d = _make_desc(B, N, C, k, training, eps, momentum, slope, w1c, g1c, b1c, rm1, rv1, w2c, g2c, b2c, rm2, rv2)
+        d = _make_desc(B, N, C, k, training, eps, momentum, slope, w1c, g1c, b1c, rm1, rv1, w2c, g2c, b2c, rm2, rv2,
+                       nbt1, nbt2)  # (the counters are bumped by the launch that finishes the batch statistics)
         y = torch.empty((B, N, 64), dtype=torch.float32, device=dev)
         saved = torch.empty((lib.dgcnn_edgeconv_saved_bytes(d),), dtype=torch.uint8, device=dev)
         ws_bytes = lib.dgcnn_edgeconv_fwd_workspace_bytes(d)
@@ -202,7 +204,7 @@ class _EdgeConv(torch.autograd.Function):
                    "dgcnn_edgeconv_bwd")
         return (gx, None, gw1.reshape(w1_shape), gg1, gb1,
                 gw2.reshape(w2_shape) if gw2 is not None else None, gg2, gb2,
-                None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None, None)
 
 
 def edgeconv_pm(x_pm, idx, w1, bn1, w2=None, bn2=None, training=False, slope=0.2):
@@ -226,11 +228,17 @@ def edgeconv_pm(x_pm, idx, w1, bn1, w2=None, bn2=None, training=False, slope=0.2
     g2, b2, rm2, rv2 = unpack(bn2)
     use_batch_stats = training or rm1 is None
     momentum = bn1.momentum if bn1.momentum is not None else 0.1
+    def counter(bn):  # nn.BatchNorm bumps it in training mode; an int64 scalar on the device goes with the launch
+        t = bn.num_batches_tracked if (training and bn is not None) else None
+        return t if (t is not None and t.dtype == torch.int64 and t.device == x_pm.device) else None
+
+    nbt1, nbt2 = counter(bn1), counter(bn2)
     y = _EdgeConv.apply(x_pm, idx, w1, g1, b1, w2, g2, b2, rm1, rv1, rm2, rv2, bool(use_batch_stats),
-                        float(bn1.eps), float(momentum), float(slope))
+                        float(bn1.eps), float(momentum), float(slope), nbt1, nbt2)
     if training:
-        for bn in (bn1, bn2):
-            _count_batch(bn)
+        for bn, t in ((bn1, nbt1), (bn2, nbt2)):
+            if t is None:
+                _count_batch(bn)
     return y
 
 

@@ -93,6 +93,8 @@ typedef struct dgcnn_bn_params {
     const float *bias;    /* beta  [64] */
     float *running_mean;  /* [64]; read when training == 0, updated when training == 1 */
     float *running_var;   /* [64] */
+    int64_t *num_batches_tracked; /* optional (may be NULL): nn.BatchNorm's counter, incremented by one in the launch that
+                                     finishes the batch statistics of a training-mode forward (dgcnn_edgeconv_fwd only) */
 } dgcnn_bn_params;
 
 typedef struct dgcnn_edgeconv_desc {

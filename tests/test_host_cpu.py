@@ -23,15 +23,15 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.dgcnn_abi_version() >= 1
+    assert lib.dgcnn_abi_version() >= 4
 
 
 def test_ctypes_struct_layout_matches_c():
     from ahn3_dgcnn_pytorch_amd import _lib
     # natural alignment on x86-64: 6 int32 + 3 float = 36 -> pad to 40, then pointers
-    assert ctypes.sizeof(_lib.BnParams) == 32
+    assert ctypes.sizeof(_lib.BnParams) == 40  # four parameter pointers + num_batches_tracked (ABI version 4)
     assert _lib.EdgeConvDesc.w1.offset == 40
-    assert ctypes.sizeof(_lib.EdgeConvDesc) == 40 + 8 + 32 + 8 + 32
+    assert ctypes.sizeof(_lib.EdgeConvDesc) == 40 + 8 + 40 + 8 + 40
     assert ctypes.sizeof(_lib.EdgeConvGrads) == 56
 
 
