@@ -347,7 +347,9 @@ def run_block(args, rank, world, dev):
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32 (results); the kNN pre-filter runs on f16 MFMA and is followed by an exact f32 refine "
-                 "(indices bit-exact vs the f32 oracle)",
+                 "(indices bit-exact vs the f32 oracle); the first convolution's forward and weight gradient on f32 MFMA, "
+                 "its input gradient%s as split-f16 MFMA products (hi.hi + hi.lo + lo.hi, 2^-22 relative)" %
+                 (" and the second convolution" if args.stages == 2 else ""),
         "data": "synthetic",
         "config": {"workload": "single EdgeConv block fwd+bwd (kNN graph build + conv 128->64%s + BN(train) + "
                                "LeakyReLU + max-over-k), BASELINE.json configs[1]" %
@@ -486,7 +488,8 @@ def run_train(args, rank, world, dev, steps, warmup, with_cpu):
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
-        "dtype": "f32 (results); kNN pre-filter and the conv2/conv4 forward on f16 MFMA (split operands)",
+        "dtype": "f32 (results); kNN pre-filter on f16 MFMA (exact f32 refine); conv2/conv4 forward and backward, the "
+                 "64-channel blocks' input gradients and the head's products as split-f16 MFMA products (2^-22 relative)",
         "data": "synthetic",
         "config": {"workload": "train.py step on synthetic blocks (f64 -> f32, DGCNN fwd, softmax + cal_loss, bwd, "
                                "all-reduce of the flat gradient buffer, Adam), BASELINE.json configs[3]",
