@@ -47,8 +47,9 @@ PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md, "HBM3E peak BW" (spec; ~6.
 PEAK_L2_GATHER_GBS = 18800.0   # MI355X_MICROARCH.md, "Indexed rows": rows shared by every workgroup, served by the
                                # XCD's L2: 16.8-18.8 TB/s chip-wide
                                # (scripts/microbench/row_gather.hip reaches 20-28 TB/s for random 256-byte rows of a
-                               # 1.8 MB table per XCD; the three gather passes of the step run at 6.5-7.3 TB/s, bound by
-                               # the work and the dependencies around each row: DESIGN.md section 5)
+                               # 1.8 MB table per XCD with waves that stream thousands of rows; the three gather passes of
+                               # the step run at 60-77 G L2 requests/s (6.5-7.8 TB/s of rows) and scale with their
+                               # request count: DESIGN.md section 5, profiles/r2_60_l2_requests.txt)
 TRAFFIC_FILE = os.path.join("profiles", "hbm_traffic.json")
 
 
