@@ -43,9 +43,9 @@ __global__ __launch_bounds__(256) void k(const float *__restrict__ table, const 
 }
 
 template <int UNROLL, int V>
-void run(int slots, const float *table, const int *idx, int nrows, float *out)
+void run(int slots, const float *table, const int *idx, int nrows, float *out, int per_wave = 2048 /* rows per wave */)
 {
-    const int nblk = 8 * slots, per_wave = 2048;  // rows per wave
+    const int nblk = 8 * slots;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     float ms = 0;
     for (int rep = 0; rep < 3; ++rep) {
@@ -55,8 +55,8 @@ void run(int slots, const float *table, const int *idx, int nrows, float *out)
         hipEventElapsedTime(&ms, e0, e1);
     }
     const double bytes = (double)nblk * 4 * per_wave * 256.0;
-    printf("variant %d unroll %2d slots/XCD %4d (waves/SIMD %.1f): %.3f ms  %.2f TB/s\n", V, UNROLL, slots, slots * 4 / 128.0, ms,
-           bytes / ms / 1e9);
+    printf("variant %d unroll %2d slots/XCD %4d (waves/SIMD %.1f) rows/wave %4d: %.3f ms  %.2f TB/s\n", V, UNROLL, slots,
+           slots * 4 / 128.0, per_wave, ms, bytes / ms / 1e9);
 }
 
 int main()
@@ -75,5 +75,8 @@ int main()
     run<32, 0>(128, table, idx, nrows, out); run<32, 0>(256, table, idx, nrows, out); run<32, 0>(512, table, idx, nrows, out);
     run<4, 1>(128, table, idx, nrows, out); run<4, 1>(256, table, idx, nrows, out);
     run<8, 1>(128, table, idx, nrows, out); run<8, 1>(256, table, idx, nrows, out); run<8, 1>(512, table, idx, nrows, out);
+    // short waves, as the passes of the step have them (~200 rows per wave, 8 waves per SIMD: 1.68 M rows in all)
+    run<32, 0>(256, table, idx, nrows, out, 192); run<32, 0>(256, table, idx, nrows, out, 256);
+    run<32, 0>(256, table, idx, nrows, out, 512); run<8, 0>(256, table, idx, nrows, out, 192);
     return 0;
 }
