@@ -23,7 +23,10 @@ namespace dgcnn {
 
 constexpr int FOLD_GS = 64;        // records per group
 constexpr int FOLD_GROUPS = 64;    // at most PART_MAX / FOLD_GS groups
-constexpr int FOLD_CTR_WORDS = 80; // counters of one fold: FOLD_GROUPS group counters + the final one, padded
+constexpr int FOLD_CTR_STRIDE = 32; // ints between two counters: every counter on a 128-byte line of its own -- the
+                                    // tickets of ALL groups are drawn within a microsecond of each other, and on one line
+                                    // they would queue at one memory channel
+constexpr int FOLD_CTR_WORDS = (FOLD_GROUPS + 1) * FOLD_CTR_STRIDE;  // counters of one fold: the groups' and the final one
 static_assert(PART_MAX <= FOLD_GS * FOLD_GROUPS, "record groups");
 
 typedef __attribute__((address_space(1))) unsigned long long gu64;
@@ -115,7 +118,7 @@ __device__ __forceinline__ void fold_and_finalize(const double (&v)[NV], const F
             st_sc1(fs.rec + ((size_t)blockIdx.x * NV + i) * 64 + lane, s);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the record has left this wave before the ticket is drawn
-        if (lane == 0) s_role = ticket(fs.ctr + g) == members - 1 ? 1 : 0;
+        if (lane == 0) s_role = ticket(fs.ctr + g * FOLD_CTR_STRIDE) == members - 1 ? 1 : 0;
     }
     __syncthreads();
     if (s_role == 0) return;  // (uniform over the workgroup)
@@ -127,7 +130,7 @@ __device__ __forceinline__ void fold_and_finalize(const double (&v)[NV], const F
 #pragma unroll
             for (int i = 0; i < NV; ++i) st_sc1(fs.folded + ((size_t)g * NV + i) * 64 + lane, tot[i]);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) s_role = ticket(fs.ctr + FOLD_GROUPS) == ngroups - 1 ? 2 : 1;
+            if (lane == 0) s_role = ticket(fs.ctr + FOLD_GROUPS * FOLD_CTR_STRIDE) == ngroups - 1 ? 2 : 1;
         }
         __syncthreads();
         if (s_role != 2) return;
