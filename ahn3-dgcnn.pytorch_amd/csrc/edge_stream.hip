@@ -631,7 +631,7 @@ __device__ __forceinline__ void rgather_segment(const __amdgpu_buffer_rsrc_t TQb
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int i = __builtin_amdgcn_readlane(src, t + u);
-            q[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(TQb, lane * 4, i * (EC * 4), 0));  // scalar row offset
+            q[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(TQb, lane * 4, (int)((unsigned)i * (unsigned)(EC * 4)), 0));  // scalar row offset
             if (DENSE) d[u] = __builtin_nontemporal_load(&(dv + (size_t)(unsigned)__builtin_amdgcn_readlane(ev, t + u) * EC)[(unsigned)lane]);
         }
 #pragma unroll
@@ -652,7 +652,7 @@ __device__ __forceinline__ void rgather_segment(const __amdgpu_buffer_rsrc_t TQb
         for (int u = 0; u < 8; ++u) {
             const int tt = t + u < cnt ? t + u : t;  // clamped: no branch around the loads
             const int i = __builtin_amdgcn_readlane(src, tt);
-            q[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(TQb, lane * 4, i * (EC * 4), 0));
+            q[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(TQb, lane * 4, (int)((unsigned)i * (unsigned)(EC * 4)), 0));
             // (dv1 rows are read once: streamed past the L2 that holds the TQ table)
             if (DENSE) d[u] = __builtin_nontemporal_load(&(dv + (size_t)(unsigned)__builtin_amdgcn_readlane(ev, tt) * EC)[(unsigned)lane]);
         }
