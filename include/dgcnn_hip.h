@@ -87,7 +87,11 @@ int dgcnn_graph_feature_bwd(const float *gout, const int32_t *idx, int B, int N,
  *         batch statistics).
  * BatchNorm semantics are PyTorch's: training = biased batch variance for normalisation,
  * running_var updated with the unbiased one, running = (1 - momentum) * running + momentum *
- * batch; eval = running statistics.  num_batches_tracked is the caller's business. */
+ * batch; eval = running statistics.  num_batches_tracked: incremented by a training-mode forward when the
+ * descriptor's dgcnn_bn_params carries its address, otherwise the caller's business.
+ * Limits (checked, reported through dgcnn_last_error): C <= 64, k <= 96 (two-stage blocks: k <= 64), B * N < 2^24
+ * points, B * N * k < 2^31 edges, slope >= 0 (the block takes max over k before the activation, which therefore has
+ * to be non-decreasing). */
 typedef struct dgcnn_bn_params {
     const float *weight;  /* gamma [64] */
     const float *bias;    /* beta  [64] */
