@@ -47,6 +47,8 @@ void launch_bwd_point(const float *gy, const float *usel, const float *stats, fl
 // (alloc[1] = number of extra (point, segment) pairs), extra [2 (E / REV_SEG + 1)] ints.  The first kernel also zeroes
 // zero_words[0 .. nzero) (which must contain alloc).
 int rev_chunks(int B, int N, int k);
+constexpr int REV_MAX_N = 40000;  // points per batch element: the list kernels keep an N-int table per wave in LDS
+                                  // (160 KB per CU); every backward builds the lists, so this bounds N there
 // with_slots / with_place = false: the caller runs those passes itself -- the list-space pass inside launch_bwd_point's
 // launch (rev_slots_args), the placement with launch_rev_place.
 struct RevSlotsArgs {

@@ -330,7 +330,10 @@ __global__ __launch_bounds__(512) void edge_mlp_bwd16_kernel(
         const double g0 = sg[0] + shfl_xor_d(sg[0], 32), g1 = sg[1] + shfl_xor_d(sg[1], 32);
         const double v[2] = {h ? t1 : t0, h ? g1 : g0};
         bad = bad || !(fabs(v[0]) <= 1.0e300) || !(fabs(v[1]) <= 1.0e300);
-        if (__ballot(bad) && lane == 0) atomicOr(guard, 1);
+        if (__ballot(bad)) {  // complete before this workgroup's fold ticket is drawn (see edge_mlp_fwd16.hip)
+            if (lane == 0) atomicOr(guard, 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         double(*red)[2][64] = reinterpret_cast<double(*)[2][64]>(scr);
         fold_and_finalize<2, MLP_BWD_WAVES>(v, fs, fin1, red, reinterpret_cast<int *>(scr + MLP_BWD_WAVES * 2 * 64 * 2));
     }

@@ -205,7 +205,13 @@ __global__ __launch_bounds__(64 * FWD16_WAVES) void edge_mlp_fwd16_kernel(
     // an operand beyond the fp16 range (a1' checked here; a non-finite weight or input shows in the sums of squares):
     // hand the pass to the fp32 instance behind this launch
     const bool bad = !(amax < 65000.0f) || !(sq[0] <= 1.0e300) || !(sq[1] <= 1.0e300);
-    if (__ballot(bad) && lane == 0) atomicOr(guard, 1);
+    // (the raise has to be COMPLETE before any wave of this workgroup can draw its fold ticket: only wave 0 drains its
+    // own memory operations in fold.h, and the last arriver's finalizer reads the guard with a relaxed load -- so every
+    // raising wave waits for its atomic here, ahead of the barrier in front of the fold)
+    if (__ballot(bad)) {
+        if (lane == 0) atomicOr(guard, 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     // BN2 batch statistics (training): lane (n, h) holds channel nt * 32 + n; fold the halves -- lane l then carries
     // channel l (nt = h) -- and let the pass finish the sums itself (fold.h)
     if (fin_on) {

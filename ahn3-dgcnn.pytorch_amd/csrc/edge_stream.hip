@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256) void bwd_point_kernel(const float *__restrict_
 //   rev_place : rev[table[m]++] = edge id, rows in order (ds_add_rtn)  ->  every list ascends in edge id.
 // (Rows with REPEATED neighbours -- no kNN graph has them -- are still handled correctly; only the order of the repeated
 // pair inside the list is then left to the LDS unit.)
-constexpr int REV_MAX_N = 40000;  // N ints of LDS per wave (160 KB per CU)
+// (REV_MAX_N, edge_kernels.h: N ints of LDS per wave, 160 KB per CU)
 constexpr int REV_ROWS = 8;       // rows per step; two steps are in flight (the next step's index rows are loaded
                                   // while this step's go through the LDS: two waves per CU, nothing else hides a load)
 
@@ -499,13 +499,21 @@ int launch_rev_build(const int32_t *idx, int B, int N, int k, int *cnt, int *ind
     DG_REQUIRE(N <= REV_MAX_N, "dgcnn: N=%d > %d unsupported in the backward", N, REV_MAX_N);
     const int P = B * N, chunks = rev_chunks(B, N, k), rows_per = ceil_div(N, chunks);
     const size_t lds = (size_t)N * sizeof(int);
-    static bool attr_done = false;
-    if (!attr_done) {  // more than the default 64 KB of dynamic LDS for large N
-        (void)hipFuncSetAttribute((const void *)rev_count_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, REV_MAX_N * 4);
-        (void)hipFuncSetAttribute((const void *)rev_count_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, REV_MAX_N * 4);
-        (void)hipFuncSetAttribute((const void *)rev_place_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, REV_MAX_N * 4);
-        (void)hipFuncSetAttribute((const void *)rev_place_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, REV_MAX_N * 4);
-        attr_done = true;
+    if (lds > 64 * 1024) {
+        // more than the default 64 KB of dynamic LDS: the attribute belongs to the (kernel, device) pair, so it is set
+        // once per device of the process (the flags are only ever raised; a second thread that finds one still down sets
+        // the same attribute again, which is harmless)
+        static bool attr_done[64] = {};
+        int dev = 0;
+        DG_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64, "dgcnn: no current HIP device");
+        if (!attr_done[dev]) {
+            const void *fns[4] = {(const void *)rev_count_kernel<false>, (const void *)rev_count_kernel<true>,
+                                  (const void *)rev_place_kernel<false>, (const void *)rev_place_kernel<true>};
+            for (const void *fn : fns)
+                DG_REQUIRE(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, REV_MAX_N * 4) == hipSuccess,
+                           "dgcnn: cannot reserve %d bytes of dynamic LDS for the reverse-list kernels", REV_MAX_N * 4);
+            attr_done[dev] = true;
+        }
     }
     if (k > 64)
         hipLaunchKernelGGL((rev_count_kernel<true>), dim3(B * chunks), dim3(64), lds, st, idx, N, k, chunks, rows_per, cnt,

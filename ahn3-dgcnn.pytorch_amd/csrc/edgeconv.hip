@@ -146,7 +146,8 @@ static BwdWs bwd_ws(const dgcnn_edgeconv_desc *d, void *p)
     return w;
 }
 
-static int check_desc(const dgcnn_edgeconv_desc *d, const char *who)
+// shape limits of the block (the workspace queries check these only: they are asked before any parameter exists)
+static int check_shape(const dgcnn_edgeconv_desc *d, const char *who, bool backward)
 {
     DG_REQUIRE(d, "%s: null descriptor", who);
     DG_REQUIRE(d->B > 0 && d->N > 0 && d->C > 0 && d->k > 0, "%s: bad shape B=%d N=%d C=%d k=%d", who, d->B, d->N,
@@ -155,10 +156,19 @@ static int check_desc(const dgcnn_edgeconv_desc *d, const char *who)
     DG_REQUIRE(d->k <= 96, "%s: k=%d > 96 unsupported", who, d->k);
     DG_REQUIRE((size_t)d->B * d->N * d->k < ((size_t)1 << 31), "%s: more than 2^31 edges", who);
     DG_REQUIRE((size_t)d->B * d->N < ((size_t)1 << 24), "%s: more than 2^24 points", who);  // 32-bit byte offsets of rows
+    DG_REQUIRE(d->n_stage == 1 || d->n_stage == 2, "%s: n_stage must be 1 or 2", who);
+    DG_REQUIRE(d->n_stage == 1 || d->k <= 64, "%s: two-stage blocks support k <= 64 (k=%d)", who, d->k);
+    // every backward (training or eval) gathers over the reverse neighbour lists, whose kernels hold N ints in LDS
+    DG_REQUIRE(!backward || d->N <= REV_MAX_N, "%s: N=%d > %d unsupported in the backward", who, d->N, REV_MAX_N);
+    return 0;
+}
+
+static int check_desc(const dgcnn_edgeconv_desc *d, const char *who, bool backward = false)
+{
+    if (check_shape(d, who, backward)) return 1;
     // (the block takes max over k BEFORE BatchNorm's affine map and the activation, on the side the sign of gamma
     // selects: the activation has to be non-decreasing)
     DG_REQUIRE(d->slope >= 0.0f, "%s: LeakyReLU slope %g < 0 unsupported", who, (double)d->slope);
-    DG_REQUIRE(d->n_stage == 1 || d->n_stage == 2, "%s: n_stage must be 1 or 2", who);
     DG_REQUIRE(d->w1 && d->bn1.weight && d->bn1.bias, "%s: stage-1 parameters missing", who);
     DG_REQUIRE(d->training || (d->bn1.running_mean && d->bn1.running_var), "%s: eval mode needs running statistics",
                who);
@@ -166,7 +176,6 @@ static int check_desc(const dgcnn_edgeconv_desc *d, const char *who)
         DG_REQUIRE(d->w2 && d->bn2.weight && d->bn2.bias, "%s: stage-2 parameters missing", who);
         DG_REQUIRE(d->training || (d->bn2.running_mean && d->bn2.running_var),
                    "%s: eval mode needs running statistics", who);
-        DG_REQUIRE(d->k <= 64, "%s: two-stage blocks support k <= 64 (k=%d)", who, d->k);
     }
     return 0;
 }
@@ -183,9 +192,11 @@ extern "C" size_t dgcnn_edgeconv_fwd_workspace_bytes(const dgcnn_edgeconv_desc *
 {
     return d ? fwd_ws(d, nullptr).bytes : 0;
 }
+static int bwd_query_ok(const dgcnn_edgeconv_desc *d) { return check_shape(d, "dgcnn_edgeconv_bwd_workspace_bytes", true); }
 extern "C" size_t dgcnn_edgeconv_bwd_workspace_bytes(const dgcnn_edgeconv_desc *d)
 {
-    return d ? bwd_ws(d, nullptr).bytes : 0;
+    // 0 = unsupported shape (dgcnn_last_error says which limit): the backward itself would refuse it
+    return bwd_query_ok(d) == 0 ? bwd_ws(d, nullptr).bytes : 0;
 }
 
 extern "C" int dgcnn_edgeconv_fwd(const dgcnn_edgeconv_desc *d, const float *x, const int32_t *idx, float *y,
@@ -227,7 +238,7 @@ extern "C" int dgcnn_edgeconv_bwd(const dgcnn_edgeconv_desc *d, const float *x, 
                                   const float *gy, const void *saved, const dgcnn_edgeconv_grads *g, void *workspace,
                                   size_t workspace_bytes, void *stream)
 {
-    if (check_desc(d, "dgcnn_edgeconv_bwd")) return 1;
+    if (check_desc(d, "dgcnn_edgeconv_bwd", true)) return 1;
     DG_REQUIRE(x && idx && y && gy && saved && g && workspace, "dgcnn_edgeconv_bwd: null pointer");
     DG_REQUIRE(g->gw1 && g->gbn1_w && g->gbn1_b, "dgcnn_edgeconv_bwd: stage-1 gradient outputs missing");
     if (d->n_stage == 2) DG_REQUIRE(g->gw2 && g->gbn2_w && g->gbn2_b, "dgcnn_edgeconv_bwd: stage-2 gradient outputs missing");
@@ -308,19 +319,24 @@ static GfWs gf_ws(int B, int N, int k, void *p)
     return w;
 }
 
+static int gf_bwd_shape_ok(int B, int N, int C, int k, const char *who)
+{
+    DG_REQUIRE(B > 0 && N > 0 && C > 0 && k > 0, "%s: bad shape", who);
+    DG_REQUIRE(k <= 128, "%s: k=%d > 128 unsupported", who, k);
+    DG_REQUIRE(N <= REV_MAX_N, "%s: N=%d > %d unsupported (reverse neighbour lists)", who, N, REV_MAX_N);
+    DG_REQUIRE((size_t)B * N * k < ((size_t)1 << 31), "%s: more than 2^31 edges", who);
+    return 0;
+}
 extern "C" size_t dgcnn_graph_feature_bwd_workspace_bytes(int B, int N, int C, int k)
 {
-    (void)C;
-    return B > 0 && N > 0 && k > 0 ? gf_ws(B, N, k, nullptr).bytes : 0;
+    return gf_bwd_shape_ok(B, N, C, k, "dgcnn_graph_feature_bwd_workspace_bytes") == 0 ? gf_ws(B, N, k, nullptr).bytes : 0;
 }
 
 extern "C" int dgcnn_graph_feature_bwd(const float *gout, const int32_t *idx, int B, int N, int C, int k, float *gx,
                                        void *workspace, size_t workspace_bytes, void *stream)
 {
     DG_REQUIRE(gout && idx && gx && workspace, "dgcnn_graph_feature_bwd: null pointer");
-    DG_REQUIRE(B > 0 && N > 0 && C > 0 && k > 0, "dgcnn_graph_feature_bwd: bad shape");
-    DG_REQUIRE(k <= 128, "dgcnn_graph_feature_bwd: k=%d > 128 unsupported", k);
-    DG_REQUIRE((size_t)B * N * k < ((size_t)1 << 31), "dgcnn_graph_feature_bwd: more than 2^31 edges");
+    if (gf_bwd_shape_ok(B, N, C, k, "dgcnn_graph_feature_bwd")) return 1;
     const GfWs w = gf_ws(B, N, k, workspace);
     DG_REQUIRE(workspace_bytes >= w.bytes, "dgcnn_graph_feature_bwd: workspace too small (%zu < %zu)", workspace_bytes,
                w.bytes);

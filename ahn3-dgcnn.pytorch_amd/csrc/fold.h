@@ -14,6 +14,10 @@
 // stored with sc1 (agent-scope, write-through) stores by ONE wave, drained with s_waitcnt vmcnt(0) before that wave's
 // lane 0 adds to the counter (agent-scope atomic), and every load of a record is an sc1 load -- so no release / acquire
 // fence (an agent release writes back the whole L2 of the XCD: microseconds per workgroup) is needed.
+// Any OTHER word a finalizer reads (the fp16-range guard of the second-conv kernels, BnBatchStats::guard) obeys the same
+// rule on the writer's side: a wave that raises it waits for its atomic (s_waitcnt vmcnt(0)) ahead of the workgroup
+// barrier that precedes the ticket, so the raise is in L2 before ANY ticket of that workgroup can make another
+// workgroup the last arriver.
 // The counters must be ZERO when the kernel starts: the kernel ahead of the pass in the same C-ABI call zeroes them
 // (edgeconv.hip), i.e. they are re-initialised on every call (and on every replay of a captured graph).
 #pragma once

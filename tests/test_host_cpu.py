@@ -45,6 +45,27 @@ def test_workspace_queries_need_no_gpu():
     assert lib.dgcnn_edgeconv_bwd_workspace_bytes(d) >= 56000 * 30 * 64 * 4
 
 
+def test_backward_limit_on_points_is_reported_by_the_workspace_queries():
+    """every backward builds the reverse neighbour lists (N ints of LDS per wave): N <= 40000 is a limit of the
+    backward entry points, reported where the caller sizes its workspace -- not after the workspace has been carved"""
+    from ahn3_dgcnn_pytorch_amd import _lib
+    lib = _lib.load()
+    d = _lib.EdgeConvDesc()
+    d.B, d.N, d.C, d.k, d.n_stage, d.training = 1, 40001, 64, 30, 1, 0
+    assert lib.dgcnn_edgeconv_fwd_workspace_bytes(d) > 0          # the forward has no such limit
+    assert lib.dgcnn_edgeconv_bwd_workspace_bytes(d) == 0
+    assert b"40000" in lib.dgcnn_last_error()
+    assert lib.dgcnn_graph_feature_bwd_workspace_bytes(1, 40001, 4, 30) == 0
+    assert b"40000" in lib.dgcnn_last_error()
+    d.N = 40000
+    assert lib.dgcnn_edgeconv_bwd_workspace_bytes(d) > 0
+    assert lib.dgcnn_graph_feature_bwd_workspace_bytes(1, 40000, 4, 30) > 0
+    buf = ctypes.create_string_buffer(64)
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    assert lib.dgcnn_graph_feature_bwd(p, p, 1, 40001, 4, 30, p, p, 1 << 30, None) != 0
+    assert b"40000" in lib.dgcnn_last_error()
+
+
 def test_argument_errors_are_reported_not_crashed():
     from ahn3_dgcnn_pytorch_amd import _lib
     lib = _lib.load()
