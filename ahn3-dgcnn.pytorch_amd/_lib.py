@@ -38,6 +38,25 @@ class EdgeConvGrads(ctypes.Structure):
 
 _c_desc_p = ctypes.POINTER(EdgeConvDesc)
 
+
+class HeadTailDesc(ctypes.Structure):
+    """mirror of `dgcnn_head_tail_desc` (include/dgcnn_hip.h)"""
+    _fields_ = [("B", ctypes.c_int32), ("N", ctypes.c_int32), ("F", ctypes.c_int32), ("C7", ctypes.c_int32),
+                ("C8", ctypes.c_int32), ("NC", ctypes.c_int32), ("ldcat", ctypes.c_int32), ("ldw7", ctypes.c_int32),
+                ("training", ctypes.c_int32),
+                ("eps7", _c_f), ("eps8", _c_f), ("momentum7", _c_f), ("momentum8", _c_f), ("slope", _c_f), ("p_drop", _c_f),
+                ("seed", ctypes.c_uint64),
+                ("w7c", _c_vp), ("bn7", BnParams), ("w8", _c_vp), ("bn8", BnParams), ("w9", _c_vp)]
+
+
+class HeadTailGrads(ctypes.Structure):
+    """mirror of `dgcnn_head_tail_grads` (include/dgcnn_hip.h)"""
+    _fields_ = [("gcat", _c_vp), ("ldgcat", _c_i64), ("gadd7", _c_vp), ("gw7c", _c_vp), ("gbn7_w", _c_vp), ("gbn7_b", _c_vp),
+                ("gw8", _c_vp), ("gbn8_w", _c_vp), ("gbn8_b", _c_vp), ("gw9", _c_vp)]
+
+
+_c_ht_p = ctypes.POINTER(HeadTailDesc)
+
 # name -> (restype, argtypes); must list every symbol of include/dgcnn_hip.h
 SIGNATURES = {
     "dgcnn_last_error": (ctypes.c_char_p, []),
@@ -81,6 +100,12 @@ SIGNATURES = {
     "dgcnn_embed_max_bwd_prepare": (_c_int, [_c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_int, _c_int, _c_f, _c_vp, _c_vp, _c_vp,
                                              _c_vp, _c_vp, _c_vp]),
     "dgcnn_embed_max_bwd_scatter": (_c_int, [_c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_int, _c_int, _c_vp, _c_vp]),
+    "dgcnn_head_tail_saved_bytes": (_c_sz, [_c_ht_p]),
+    "dgcnn_head_tail_fwd_workspace_bytes": (_c_sz, [_c_ht_p]),
+    "dgcnn_head_tail_bwd_workspace_bytes": (_c_sz, [_c_ht_p]),
+    "dgcnn_head_tail_fwd": (_c_int, [_c_ht_p, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp]),
+    "dgcnn_head_tail_bwd": (_c_int, [_c_ht_p, _c_vp, _c_vp, _c_vp, _c_vp, ctypes.POINTER(HeadTailGrads), _c_vp, _c_sz, _c_vp]),
+    "dgcnn_dropout_mask": (_c_int, [ctypes.c_uint64, _c_int, _c_int, _c_f, _c_vp, _c_vp]),
     "dgcnn_seg_loss_workspace_bytes": (_c_sz, [_c_int, _c_int]),
     "dgcnn_seg_loss": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_i64, _c_i64, _c_i64, _c_vp, _c_vp, _c_f, _c_vp, _c_vp,
                                 _c_vp, _c_vp, _c_sz, _c_vp]),

@@ -1,0 +1,1332 @@
+// head_fused.hip -- the tail of the segmentation head as ONE forward call and ONE backward call:
+//
+//     u7 = cat . W7c^T + add7[b]        z7 = LReLU(BN7(u7))       (conv7 on cat(repeat(g), x1, x2, x3), model.py:179-184;
+//     u8 = z7 . W8^T                    z8 = LReLU(BN8(u8))        add7 = W7g . g_b is the pooled feature's share)
+//     logits = dropout(z8) . W9^T                                  (conv8, dp1, conv9: model.py:187-191)
+//
+// Only the PRE-activations u7 [P][512] and u8 [P][256] ever reach memory.  BatchNorm1d statistics are column sums in the
+// producing product's epilogue; BatchNorm + LeakyReLU (+ dropout) are applied where the NEXT product loads its operand;
+// the backward forms every BatchNorm input gradient du = sc (dv - c1 - c2 uhat) where a product loads it and every
+// dv = dL/dz . LReLU' where the product that makes dL/dz stores it.  Per training step and layer this replaces the
+// passes colstats, apply, (dropout,) bwd_reduce, bwd_apply over the [P][C] tensors (1.6 ms of a 13.4 ms step at B = 32)
+// and the operand-magnitude passes in front of every product.
+//
+// Products: fp32 in / fp32 out on the fp16 matrix cores with both operands split in two halves at an exact power-of-two
+// scale (hi.hi + hi.lo + lo.hi, fp32 accumulate), as head_gemm.hip -- but
+//   * weights are split ONCE per step (wprep_kernel: one wave per output row, which also finds the row's own scale: the
+//     scale of w is per output channel), in both orientations, as fp16 planes the products stage without vector work;
+//   * the scale of a GRADIENT operand is per 128-row tile (the rows of dL/dy span orders of magnitude between points), from
+//     maxima its producer leaves behind; activations take one scale per tensor (BatchNorm has normalised their columns),
+//     exact because BatchNorm + LeakyReLU is monotone per column: max |z| follows from the column extrema of u.
+#include <stdlib.h>
+
+#include "dgcnn_hip.h"
+#include "hsplit.h"
+
+namespace dgcnn {
+void launch_sum_partials(const float *partial, int nchunk, int n, float *out, hipStream_t st);  // pointgemm.hip
+
+namespace hf {
+
+constexpr int GM = 128, GN = 128, GK = 32, GSTR = GK + 8;  // workgroup tile; LDS rows of 40 halves: conflict-free 16-byte reads
+
+// ---- weights: fp16 planes + per-row scales ------------------------------------------------------------------------------
+struct WPrepJob {
+    const float *src;
+    int ld, rows, cols, transposed;  // OUTPUT shape rows x cols; out[r][c] = transposed ? src[c ld + r] : src[r ld + c]
+    _Float16 *hi, *lo;               // planes [rows][cols]
+    float *scale;                    // [rows]
+};
+constexpr int WPREP_MAX = 4;
+struct WPrepArgs {
+    WPrepJob job[WPREP_MAX];
+    int first_row[WPREP_MAX + 1];
+    int njobs;
+};
+
+__global__ __launch_bounds__(256) void wprep_kernel(WPrepArgs a)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gr = blockIdx.x * 4 + wave;
+    if (gr >= a.first_row[a.njobs]) return;
+    int j = 0;
+    while (gr >= a.first_row[j + 1]) ++j;
+    const WPrepJob J = a.job[j];
+    const int r = gr - a.first_row[j];
+    const size_t rs = J.transposed ? 1 : (size_t)J.ld, cs = J.transposed ? (size_t)J.ld : 1;
+    const float *row = J.src + (size_t)r * rs;
+    float m = 0.0f;
+    for (int c = lane; c < J.cols; c += 64) m = fmaxf(m, fabsf(row[(size_t)c * cs]));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    const float s = pow2_scale(m, H_TOP);
+    unsigned *hi = reinterpret_cast<unsigned *>(J.hi + (size_t)r * J.cols), *lo = reinterpret_cast<unsigned *>(J.lo + (size_t)r * J.cols);
+    for (int c = 2 * lane; c < J.cols; c += 128) {  // (cols is even)
+        unsigned H, L;
+        split_pair(row[(size_t)c * cs] * s, row[(size_t)(c + 1) * cs] * s, H, L);
+        hi[c >> 1] = H;
+        lo[c >> 1] = L;
+    }
+    if (lane == 0) J.scale[r] = s;
+}
+
+// ---- y = xeff . w^T with a prologue on x and an epilogue on y -----------------------------------------------------------
+enum { X_RAW = 0, X_BN = 1, X_DU = 2 };
+enum { E_PLAIN = 0, E_STATS = 1, E_DV = 2 };
+struct HGemmArgs {
+    const float *X;  // X_RAW: x;  X_BN: u of the previous layer;  X_DU: dv of this layer
+    int ldx;
+    const float *X2;  // X_DU: u of this layer
+    int ldx2;
+    int P, K, N;
+    const _Float16 *Wh, *Wl;  // planes [N][K]
+    const float *wscale;      // [N]
+    // scale of x:  X_RAW / X_BN: the bits of (an upper bound of) max |xeff| at xmax[0]
+    //              X_DU: bound of the row tile = sb[0] (ta[rb] + sb[1] + sb[2] tb[rb]),  ta / tb = bits of max |dv|, max |uhat|
+    const unsigned *xmax, *ta, *tb;
+    const unsigned *sb;  // bits of max |sc|, max |c1|, max |c2|
+    // constants per k:  X_BN: pc[0] = sc, pc[1] = sh;   X_DU: pc[0..4] = mean, rstd, sc, c1, c2
+    const float *pc[5];
+    float slope;
+    const float *add;  // E_PLAIN / E_STATS: + add[row / rows_per_batch][col] (or NULL)
+    int rows_per_batch;
+    float *Y;
+    int ldy;
+    double *psum;    // E_STATS: [nrb][2][N] sum, sum of squares (or NULL: extrema only)
+    float *pext;     // E_STATS: [nrb][2][N] min, max
+    unsigned *zero;  // E_STATS: one word zeroed by workgroup 0 (the finalize kernel behind this launch takes a maximum into it)
+    // E_DV: Y = (acc) . LReLU'(ec_sc U + ec_sh): the gradient wrt the pre-BatchNorm... of the PREVIOUS layer's activation
+    const float *U;
+    int ldu;
+    const float *ec[4];  // per column n: mean, rstd, sc, sh
+    double *pdv;         // [nrb][2][3][N]: per batch-element slot of the tile: sum dv, sum dv uhat, sum uhat
+    unsigned *oa, *ob;   // [nrb + 1]: bits of max |dv|, max |uhat| of the row tile (zero at launch); [nrb] = over all tiles
+    int ncb, nrb;
+};
+
+struct XRegs {
+    float4 v[4];  // v[i]: row (t + 256 i) / 8 of the tile, columns 4 (t % 8) .. + 3 of the chunk
+};
+__device__ __forceinline__ void load_x(const float *__restrict__ src, int ld, int row0, int nrows, int k0, XRegs &r)
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = threadIdx.x + 256 * i, row = f >> 3, c = (f & 7) * 4;
+        const int rr = row0 + row < nrows ? row0 + row : nrows - 1;  // clamped: rows past the end are never stored
+        r.v[i] = *reinterpret_cast<const float4 *>(src + (size_t)rr * ld + k0 + c);
+    }
+}
+struct WRegs {
+    u32x4 h[2], l[2];  // piece q = t + 256 j: row q / 4 of the tile, halves 8 (q % 4) .. + 7 of the chunk
+};
+__device__ __forceinline__ void load_w(const _Float16 *__restrict__ Wh, const _Float16 *__restrict__ Wl, int K, int col0, int N,
+                                       int k0, WRegs &r)
+{
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int q = threadIdx.x + 256 * j, row = q >> 2, pc = (q & 3) * 8;
+        const int rr = col0 + row < N ? col0 + row : N - 1;
+        r.h[j] = *reinterpret_cast<const u32x4 *>(Wh + (size_t)rr * K + k0 + pc);
+        r.l[j] = *reinterpret_cast<const u32x4 *>(Wl + (size_t)rr * K + k0 + pc);
+    }
+}
+__device__ __forceinline__ void store_w(const WRegs &r, _Float16 (*wh)[GSTR], _Float16 (*wl)[GSTR])
+{
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int q = threadIdx.x + 256 * j, row = q >> 2, pc = (q & 3) * 8;
+        *reinterpret_cast<u32x4 *>(&wh[row][pc]) = r.h[j];
+        *reinterpret_cast<u32x4 *>(&wl[row][pc]) = r.l[j];
+    }
+}
+struct KConst {
+    float4 c[5];
+};
+template <int XMODE>
+__device__ __forceinline__ void load_kconst(const HGemmArgs &a, int k0, KConst &kc)
+{
+    const int c = (threadIdx.x & 7) * 4;
+    constexpr int n = XMODE == X_BN ? 2 : (XMODE == X_DU ? 5 : 0);
+#pragma unroll
+    for (int i = 0; i < n; ++i) kc.c[i] = *reinterpret_cast<const float4 *>(a.pc[i] + k0 + c);
+}
+__device__ __forceinline__ float f4(const float4 &v, int e) { return e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w)); }
+
+// BatchNorm input gradient at one element:  du = sc (dv - c1 - c2 uhat),  uhat = (u - mean) rstd
+__device__ __forceinline__ float du_of(float dv, float u, float mean, float rstd, float sc, float c1, float c2)
+{
+    const float uh = (u - mean) * rstd;
+    return sc * __builtin_fmaf(-c2, uh, dv - c1);
+}
+
+template <int XMODE>
+__device__ __forceinline__ void store_x(const XRegs &r, const XRegs &r2, const KConst &kc, float sx, float slope,
+                                        _Float16 (*xh)[GSTR], _Float16 (*xl)[GSTR])
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = threadIdx.x + 256 * i, row = f >> 3, c = (f & 7) * 4;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float x = f4(r.v[i], e);
+            float y;
+            if (XMODE == X_RAW) y = x;
+            else if (XMODE == X_BN) y = lrelu_f(__builtin_fmaf(x, f4(kc.c[0], e), f4(kc.c[1], e)), slope);
+            else y = du_of(x, f4(r2.v[i], e), f4(kc.c[0], e), f4(kc.c[1], e), f4(kc.c[2], e), f4(kc.c[3], e), f4(kc.c[4], e));
+            v[e] = y * sx;
+        }
+        u32x2 h, l;
+        split4(v, h, l);
+        *reinterpret_cast<u32x2 *>(&xh[row][c]) = h;
+        *reinterpret_cast<u32x2 *>(&xl[row][c]) = l;
+    }
+}
+
+template <int XMODE, int EMODE>
+__global__ __launch_bounds__(256) void hgemm_kernel(const HGemmArgs a)
+{
+    __shared__ __attribute__((aligned(16))) _Float16 lds[4][GM][GSTR];  // one block: the epilogues reuse it as scratch
+    static_assert(GM == GN && sizeof(lds) >= 4 * 2 * 3 * GN * sizeof(double), "epilogue scratch fits the staging area");
+    _Float16(*xh)[GSTR] = lds[0], (*xl)[GSTR] = lds[1], (*wh)[GSTR] = lds[2], (*wl)[GSTR] = lds[3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, i32 = lane & 31;
+    const int cb = (int)blockIdx.x % a.ncb, rb = (int)blockIdx.x / a.ncb;  // column blocks of a row block are neighbours
+    const int row0 = rb * GM, col0 = cb * GN;
+    const int P = a.P, K = a.K, N = a.N;
+    float xbound;
+    if (XMODE == X_DU)
+        xbound = __uint_as_float(a.sb[0]) * (__uint_as_float(a.ta[rb]) + __uint_as_float(a.sb[1]) + __uint_as_float(a.sb[2]) * __uint_as_float(a.tb[rb]));
+    else
+        xbound = __uint_as_float(*a.xmax);
+    const float sx = pow2_scale(xbound, H_TOP);
+    if (EMODE == E_STATS && blockIdx.x == 0 && threadIdx.x == 0 && a.zero) *a.zero = 0u;
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
+
+    XRegs rx, rx2;
+    WRegs rw;
+    KConst kc;
+    load_x(a.X, a.ldx, row0, P, 0, rx);
+    if (XMODE == X_DU) load_x(a.X2, a.ldx2, row0, P, 0, rx2);
+    load_kconst<XMODE>(a, 0, kc);
+    load_w(a.Wh, a.Wl, K, col0, N, 0, rw);
+    for (int k0 = 0; k0 < K; k0 += GK) {
+        __syncthreads();  // the previous chunk's LDS reads are done
+        store_x<XMODE>(rx, rx2, kc, sx, a.slope, xh, xl);
+        store_w(rw, wh, wl);
+        __syncthreads();
+        if (k0 + GK < K) {  // next chunk in flight during the MFMAs
+            load_x(a.X, a.ldx, row0, P, k0 + GK, rx);
+            if (XMODE == X_DU) load_x(a.X2, a.ldx2, row0, P, k0 + GK, rx2);
+            load_kconst<XMODE>(a, k0 + GK, kc);
+            load_w(a.Wh, a.Wl, K, col0, N, k0 + GK, rw);
+        }
+#pragma unroll
+        for (int s = 0; s < GK / 16; ++s) {
+            const half8 ahi = *reinterpret_cast<const half8 *>(&xh[wave * 32 + i32][16 * s + 8 * h]);
+            const half8 alo = *reinterpret_cast<const half8 *>(&xl[wave * 32 + i32][16 * s + 8 * h]);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const half8 bhi = *reinterpret_cast<const half8 *>(&wh[nt * 32 + i32][16 * s + 8 * h]);
+                const half8 blo = *reinterpret_cast<const half8 *>(&wl[nt * 32 + i32][16 * s + 8 * h]);
+                acc[nt] = mfma3(ahi, alo, bhi, blo, acc[nt]);
+            }
+        }
+    }
+
+    // ---- epilogue: lane (n, h) holds column nt 32 + n, rows mfma32_row(r, h) (ascending in r) of this wave's 32 rows
+    const float isx = 1.0f / sx;
+    if (EMODE == E_PLAIN) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int col = col0 + nt * 32 + i32;
+            if (col < N) {
+                const float un = isx / a.wscale[col];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row0 + wave * 32 + mfma32_row(r, h);
+                    if (row < P) {
+                        float v = acc[nt][r] * un;
+                        if (a.add) v += a.add[(size_t)(row / a.rows_per_batch) * N + col];
+                        a.Y[(size_t)row * a.ldy + col] = v;
+                    }
+                }
+            }
+        }
+    } else if (EMODE == E_STATS) {
+        __syncthreads();  // the staging area becomes the scratch of the column reductions
+        double(*csum)[2][GN] = reinterpret_cast<double(*)[2][GN]>(&lds[0][0][0]);                         // [4][2][GN]
+        float(*cext)[2][GN] = reinterpret_cast<float(*)[2][GN]>(reinterpret_cast<char *>(&lds[0][0][0]) + 4 * 2 * GN * 8);  // [4][2][GN] behind it
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int cl = nt * 32 + i32, col = col0 + cl;
+            const bool cv = col < N;
+            const float un = cv ? isx / a.wscale[col] : 0.0f;
+            // (fp64 from the first addition on: the variance is sum v^2 / P - mean^2, and with |mean| >> sigma an fp32 partial
+            // sum of squares over even 16 rows costs the difference its digits)
+            double s1 = 0.0, s2 = 0.0;
+            float mn = __builtin_inff(), mx = -__builtin_inff();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + wave * 32 + mfma32_row(r, h);
+                if (row < P && cv) {
+                    float v = acc[nt][r] * un;
+                    if (a.add) v += a.add[(size_t)(row / a.rows_per_batch) * N + col];
+                    a.Y[(size_t)row * a.ldy + col] = v;
+                    s1 += (double)v;
+                    s2 = __builtin_fma((double)v, (double)v, s2);
+                    mn = fminf(mn, v);
+                    mx = fmaxf(mx, v);
+                }
+            }
+            const double d1 = s1 + __shfl_xor(s1, 32), d2 = s2 + __shfl_xor(s2, 32);
+            mn = fminf(mn, __shfl_xor(mn, 32));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            if (h == 0) {
+                csum[wave][0][cl] = d1;
+                csum[wave][1][cl] = d2;
+                cext[wave][0][cl] = mn;
+                cext[wave][1][cl] = mx;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < GN && col0 + (int)threadIdx.x < N) {
+            const int cl = threadIdx.x;
+            if (a.psum) {
+                a.psum[((size_t)rb * 2 + 0) * N + col0 + cl] = (csum[0][0][cl] + csum[1][0][cl]) + (csum[2][0][cl] + csum[3][0][cl]);
+                a.psum[((size_t)rb * 2 + 1) * N + col0 + cl] = (csum[0][1][cl] + csum[1][1][cl]) + (csum[2][1][cl] + csum[3][1][cl]);
+            }
+            a.pext[((size_t)rb * 2 + 0) * N + col0 + cl] = fminf(fminf(cext[0][0][cl], cext[1][0][cl]), fminf(cext[2][0][cl], cext[3][0][cl]));
+            a.pext[((size_t)rb * 2 + 1) * N + col0 + cl] = fmaxf(fmaxf(cext[0][1][cl], cext[1][1][cl]), fmaxf(cext[2][1][cl], cext[3][1][cl]));
+        }
+    } else {  // E_DV
+        __syncthreads();
+        double(*cdv)[2][3][GN] = reinterpret_cast<double(*)[2][3][GN]>(&lds[0][0][0]);  // [4][2][3][GN]
+        __shared__ float smax[4][2];
+        // rows of the tile's second batch-element slot start at rsplit (the tile spans at most two: rows_per_batch >= GM)
+        const int rsplit = (row0 / a.rows_per_batch + 1) * a.rows_per_batch;
+        float amax_dv = 0.0f, amax_uh = 0.0f;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int cl = nt * 32 + i32, col = col0 + cl;
+            const bool cv = col < N;
+            const float un = cv ? isx / a.wscale[col] : 0.0f;
+            const float mean = cv ? a.ec[0][col] : 0.0f, rstd = cv ? a.ec[1][col] : 0.0f, sc = cv ? a.ec[2][col] : 0.0f,
+                        sh = cv ? a.ec[3][col] : 0.0f;
+            float s[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + wave * 32 + mfma32_row(r, h);
+                if (row < P && cv) {
+                    const float u = a.U[(size_t)row * a.ldu + col];
+                    const float g = acc[nt][r] * un;
+                    const float dv = __builtin_fmaf(u, sc, sh) > 0.0f ? g : g * a.slope;
+                    const float uh = (u - mean) * rstd;
+                    a.Y[(size_t)row * a.ldy + col] = dv;
+                    const int sl = row >= rsplit ? 1 : 0;
+                    s[sl][0] += dv;
+                    s[sl][1] = __builtin_fmaf(dv, uh, s[sl][1]);
+                    s[sl][2] += uh;
+                    amax_dv = fmaxf(amax_dv, fabsf(dv));
+                    amax_uh = fmaxf(amax_uh, fabsf(uh));
+                }
+            }
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const double d = (double)s[sl][q] + (double)__shfl_xor(s[sl][q], 32);
+                    if (h == 0) cdv[wave][sl][q][cl] = d;
+                }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            amax_dv = fmaxf(amax_dv, __shfl_xor(amax_dv, o));
+            amax_uh = fmaxf(amax_uh, __shfl_xor(amax_uh, o));
+        }
+        if (lane == 0) {
+            smax[wave][0] = amax_dv;
+            smax[wave][1] = amax_uh;
+        }
+        __syncthreads();
+        if (threadIdx.x < GN && col0 + (int)threadIdx.x < N) {
+            const int cl = threadIdx.x;
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    a.pdv[(((size_t)rb * 2 + sl) * 3 + q) * N + col0 + cl] =
+                        (cdv[0][sl][q][cl] + cdv[1][sl][q][cl]) + (cdv[2][sl][q][cl] + cdv[3][sl][q][cl]);
+        }
+        if (threadIdx.x == 0) {
+            const unsigned ba = __float_as_uint(fmaxf(fmaxf(smax[0][0], smax[1][0]), fmaxf(smax[2][0], smax[3][0])));
+            const unsigned bb = __float_as_uint(fmaxf(fmaxf(smax[0][1], smax[1][1]), fmaxf(smax[2][1], smax[3][1])));
+            atomicMax(a.oa + rb, ba);  // (non-negative floats order like their bits; a maximum: order-independent)
+            atomicMax(a.ob + rb, bb);
+            atomicMax(a.oa + a.nrb, ba);
+            atomicMax(a.ob + a.nrb, bb);
+        }
+    }
+}
+
+// ---- weight gradient dW[M][Nn] = sum_p aeff[p][m] beff[p][n] with prologues on both operands ---------------------------
+// (the structure of rows_wgrad16_kernel, head_gemm.hip: stages of 32 points, loaded in 16-byte row pieces, transformed,
+// split and written to LDS TRANSPOSED as fp16 planes [column][point]; one 128 x 128 tile of dW over one chunk of the
+// points per workgroup, wave = a 64 x 64 quadrant; partial tiles are added in chunk order by sum_partials_kernel)
+enum { A_RAW = 0, A_DU = 2, B_RAW = 0, B_BN = 1 };
+constexpr int WK = 32, WSTR = WK + 8;
+struct HWgradArgs {
+    const float *A;  // A_DU: dv
+    int lda;
+    const float *A2;  // A_DU: u
+    int lda2, M;
+    const float *Bm;  // B_BN: u of the previous layer;  B_RAW: the layer's input
+    int ldb, Nn, P, chunk, ntiles_n;
+    const float *ac[5];  // A_DU, per column m: mean, rstd, sc, c1, c2
+    const float *bc[2];  // B_BN, per column n: sc, sh
+    float slope;
+    const unsigned *ta, *tb, *sb;  // A_DU: scale bound = sb[0] (ta[gi] + sb[1] + sb[2] tb[gi])
+    int gi;
+    const unsigned *amax_b;  // bits of max |beff|
+    float *partial;
+};
+struct WStage {
+    float4 v[4];  // v[i] = row p0 + 4 pq + i, columns c0 + 4 cq .. + 3
+};
+__device__ __forceinline__ void wstage_load(const float *__restrict__ src, int ld, int ncols, int c0, int p0, int pend, WStage &r)
+{
+    const int cq = threadIdx.x & 31, pq = threadIdx.x >> 5;
+    const int col = c0 + 4 * cq < ncols ? c0 + 4 * cq : 0;  // columns past the matrix: any valid address (never stored)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int p = p0 + 4 * pq + i;
+        r.v[i] = *reinterpret_cast<const float4 *>(src + (size_t)(p < pend ? p : pend - 1) * ld + col);
+    }
+}
+// the four columns of this thread, transformed, for the stage's four points -> transposed, split, stored
+__device__ __forceinline__ void wstage_store(const float (&t)[4][4] /* [column][point] */, _Float16 (*hi)[WSTR], _Float16 (*lo)[WSTR])
+{
+    const int cq = threadIdx.x & 31, pq = threadIdx.x >> 5;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        u32x2 h, l;
+        split4(t[c], h, l);
+        *reinterpret_cast<u32x2 *>(&hi[4 * cq + c][4 * pq]) = h;
+        *reinterpret_cast<u32x2 *>(&lo[4 * cq + c][4 * pq]) = l;
+    }
+}
+
+template <int AMODE, int BMODE>
+__global__ __launch_bounds__(256) void hwgrad_kernel(const HWgradArgs a)
+{
+    __shared__ __attribute__((aligned(16))) _Float16 ah[128][WSTR], al[128][WSTR], bh[128][WSTR], bl[128][WSTR];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, i32 = lane & 31;
+    const int M = a.M, Nn = a.Nn, P = a.P;
+    const int tiles = a.ntiles_n * ((M + 127) / 128);
+    const int v = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);  // gridDim.x is a multiple of 8: a chunk's tiles on ONE XCD
+    const int cidx = v / tiles, tile = v - cidx * tiles;
+    if (cidx * a.chunk >= P) return;  // padding workgroups
+    const int tm = tile / a.ntiles_n, tn = tile - tm * a.ntiles_n;
+    const int m0 = tm * 128, n0 = tn * 128;
+    const int pbeg = cidx * a.chunk, pend = pbeg + a.chunk < P ? pbeg + a.chunk : P;
+    float abound;
+    if (AMODE == A_DU)
+        abound = __uint_as_float(a.sb[0]) * (__uint_as_float(a.ta[a.gi]) + __uint_as_float(a.sb[1]) + __uint_as_float(a.sb[2]) * __uint_as_float(a.tb[a.gi]));
+    else
+        abound = __uint_as_float(*a.ta);  // (A_RAW: ta points at the bits of max |a|)
+    const float sa = pow2_scale(abound, H_TOP), sb = pow2_scale(__uint_as_float(*a.amax_b), H_TOP);
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int cq = threadIdx.x & 31, pq = threadIdx.x >> 5;
+
+    // per-thread column constants (the thread's four columns are the same in every stage)
+    float4 ca[5], cbv[2];
+    {
+        const int cm = m0 + 4 * cq < M ? m0 + 4 * cq : 0, cn = n0 + 4 * cq < Nn ? n0 + 4 * cq : 0;
+        if (AMODE == A_DU)
+#pragma unroll
+            for (int i = 0; i < 5; ++i) ca[i] = *reinterpret_cast<const float4 *>(a.ac[i] + cm);
+        if (BMODE == B_BN)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) cbv[i] = *reinterpret_cast<const float4 *>(a.bc[i] + cn);
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a_ = 0; a_ < 2; ++a_)
+#pragma unroll
+        for (int b_ = 0; b_ < 2; ++b_)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a_][b_][r] = 0.0f;
+
+    WStage ra, ra2, rb;
+    wstage_load(a.A, a.lda, M, m0, pbeg, pend, ra);
+    if (AMODE == A_DU) wstage_load(a.A2, a.lda2, M, m0, pbeg, pend, ra2);
+    wstage_load(a.Bm, a.ldb, Nn, n0, pbeg, pend, rb);
+    for (int p0 = pbeg; p0 < pend; p0 += WK) {
+        __syncthreads();
+        {
+            float ta_[4][4], tb_[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool on = p0 + 4 * pq + i < pend;  // points past the chunk add nothing
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float x = f4(ra.v[i], c);
+                    if (AMODE == A_DU) x = du_of(x, f4(ra2.v[i], c), f4(ca[0], c), f4(ca[1], c), f4(ca[2], c), f4(ca[3], c), f4(ca[4], c));
+                    ta_[c][i] = on ? x * sa : 0.0f;
+                    float y = f4(rb.v[i], c);
+                    if (BMODE == B_BN) y = lrelu_f(__builtin_fmaf(y, f4(cbv[0], c), f4(cbv[1], c)), a.slope);
+                    tb_[c][i] = on ? y * sb : 0.0f;
+                }
+            }
+            wstage_store(ta_, ah, al);
+            wstage_store(tb_, bh, bl);
+        }
+        __syncthreads();
+        if (p0 + WK < pend) {
+            wstage_load(a.A, a.lda, M, m0, p0 + WK, pend, ra);
+            if (AMODE == A_DU) wstage_load(a.A2, a.lda2, M, m0, p0 + WK, pend, ra2);
+            wstage_load(a.Bm, a.ldb, Nn, n0, p0 + WK, pend, rb);
+        }
+#pragma unroll
+        for (int s = 0; s < WK / 16; ++s) {
+            half8 xhi[2], xlo[2], yhi[2], ylo[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                xhi[t] = *reinterpret_cast<const half8 *>(&ah[wm + t * 32 + i32][16 * s + 8 * h]);
+                xlo[t] = *reinterpret_cast<const half8 *>(&al[wm + t * 32 + i32][16 * s + 8 * h]);
+                yhi[t] = *reinterpret_cast<const half8 *>(&bh[wn + t * 32 + i32][16 * s + 8 * h]);
+                ylo[t] = *reinterpret_cast<const half8 *>(&bl[wn + t * 32 + i32][16 * s + 8 * h]);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma3(xhi[mt], xlo[mt], yhi[nt], ylo[nt], acc[mt][nt]);
+        }
+    }
+    const float un = 1.0f / (sa * sb);
+    float *out = a.partial + (size_t)cidx * M * Nn;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int n = n0 + wn + nt * 32 + i32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm + mt * 32 + mfma32_row(r, h);
+                if (m < M && n < Nn) out[(size_t)m * Nn + n] = acc[mt][nt][r] * un;
+            }
+        }
+}
+
+
+// ---- the classifier on u8 (conv9 after bn8 + LeakyReLU + dropout, model.py:187-191) ------------------------------------
+// Five output columns are no matrix tile: streaming passes, as dgcnn_cls_fwd / dgcnn_cls_bwd (head_gemm.hip) -- but the
+// input is the PRE-activation u8: BatchNorm, LeakyReLU and the dropout mask are applied to the loaded row in registers.
+struct ClsArgs {
+    const float *u;
+    int P, K, nrb, nblk;
+    const float *mean, *rstd, *sc, *sh;  // stats of bn8
+    const float *w;                      // [NC][K]
+    float slope, inv_keep;
+    unsigned keep16;
+    unsigned long long seed;
+    float *y;         // forward: logits [P][NC]
+    const float *gy;  // backward: dL/dlogits [P][NC]
+    float *dv;        // backward: [P][K] = dL/dz8 . LReLU'
+    float *pdw;       // backward: [nblk][NC][K]
+    double *pbn;      // backward: [nblk][2][K]: sum dv, sum dv uhat
+    unsigned *oa, *ob;  // backward: [nrb + 1] bits of max |dv|, max |uhat| per 128-row tile (zero at launch), [nrb] = over all
+};
+constexpr int CLS_ROWS = 8, CLS_MAX = 8;
+
+template <int NC, bool DROP>
+__global__ __launch_bounds__(256) void cls_fwd_fused_kernel(const ClsArgs a)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nk = a.K / 4, P = a.P;
+    for (int p0 = (blockIdx.x * 4 + wave) * CLS_ROWS; p0 < P; p0 += gridDim.x * 4 * CLS_ROWS) {
+        float acc[CLS_ROWS][NC];
+#pragma unroll
+        for (int r = 0; r < CLS_ROWS; ++r)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc[r][c] = 0.0f;
+        for (int q = lane; q < nk; q += 64) {
+            float4 wv[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) wv[c] = reinterpret_cast<const float4 *>(a.w + (size_t)c * a.K)[q];
+            const float4 sc = reinterpret_cast<const float4 *>(a.sc)[q], sh = reinterpret_cast<const float4 *>(a.sh)[q];
+            float4 uv[CLS_ROWS];
+#pragma unroll
+            for (int r = 0; r < CLS_ROWS; ++r) {
+                const int p = p0 + r < P ? p0 + r : P - 1;
+                uv[r] = reinterpret_cast<const float4 *>(a.u + (size_t)p * a.K)[q];
+            }
+#pragma unroll
+            for (int r = 0; r < CLS_ROWS; ++r) {
+                const int p = p0 + r < P ? p0 + r : P - 1;
+                const unsigned long long mix = DROP ? drop_mix(a.seed, (unsigned long long)p * nk + q) : 0ull;
+                float d[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float z = lrelu_f(__builtin_fmaf(f4(uv[r], e), f4(sc, e), f4(sh, e)), a.slope);
+                    d[e] = DROP ? (drop_keep(mix, e, a.keep16) ? z * a.inv_keep : 0.0f) : z;
+                }
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    acc[r][c] = __builtin_fmaf(d[0], wv[c].x, acc[r][c]);
+                    acc[r][c] = __builtin_fmaf(d[1], wv[c].y, acc[r][c]);
+                    acc[r][c] = __builtin_fmaf(d[2], wv[c].z, acc[r][c]);
+                    acc[r][c] = __builtin_fmaf(d[3], wv[c].w, acc[r][c]);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < CLS_ROWS; ++r)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                float v = acc[r][c];
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+                acc[r][c] = v;
+            }
+        if (lane < CLS_ROWS * NC) {
+            const int r = lane / NC, c = lane - r * NC;
+            float v = 0.0f;
+#pragma unroll
+            for (int rr = 0; rr < CLS_ROWS; ++rr)
+#pragma unroll
+                for (int cc = 0; cc < NC; ++cc) v = (rr == r && cc == c) ? acc[rr][cc] : v;
+            if (p0 + r < P) a.y[(size_t)(p0 + r) * NC + c] = v;
+        }
+    }
+}
+
+// backward of the classifier in ONE pass over u8 and dL/dlogits:
+//   dL/dd = gy . W9,  dL/dz8 = dL/dd . mask / (1 - p),  dv = dL/dz8 . LReLU'(v8)          -> dv [P][K]
+//   dW9 += gy^T d  (d = dropout(z8), recomputed)                                           -> one record per workgroup
+//   BatchNorm-8 backward sums: sum dv, sum dv uhat8 (fp32 per 128-row tile, fp64 across)   -> one record per workgroup
+//   max |dv|, max |uhat8| per 128-row tile (the products behind take dv's scale bound from them)
+// A workgroup walks 128-row tiles blk, blk + nblk, ...; a wave takes 4 consecutive rows of every 16, in row order.
+template <int NC, bool DROP>
+__global__ __launch_bounds__(256) void cls_bwd_fused_kernel(const ClsArgs a)
+{
+    __shared__ float red[4][CLS_MAX * 4][64];
+    __shared__ double redd[4][8][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nk = a.K / 4, P = a.P;
+    for (int q0 = 0; q0 < nk; q0 += 64) {
+        const int q = q0 + lane;
+        const bool qv = q < nk;
+        const int qq = qv ? q : 0;
+        float4 wv[NC], dw[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            wv[c] = qv ? reinterpret_cast<const float4 *>(a.w + (size_t)c * a.K)[qq] : float4{0.0f, 0.0f, 0.0f, 0.0f};
+            dw[c] = float4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+        const float4 mean = reinterpret_cast<const float4 *>(a.mean)[qq], rstd = reinterpret_cast<const float4 *>(a.rstd)[qq];
+        const float4 sc = reinterpret_cast<const float4 *>(a.sc)[qq], sh = reinterpret_cast<const float4 *>(a.sh)[qq];
+        double sdv[4] = {0.0, 0.0, 0.0, 0.0}, sdu[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int tile = blockIdx.x; tile < a.nrb; tile += a.nblk) {
+            const int pb = tile * 128, pe = pb + 128 < P ? pb + 128 : P;
+            float tdv[4] = {0.0f, 0.0f, 0.0f, 0.0f}, tdu[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            float amax_dv = 0.0f, amax_uh = 0.0f;
+            for (int p0 = pb + wave * 4; p0 < pe; p0 += 16) {
+                float g[4][NC];
+                float4 uv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int p = p0 + r < pe ? p0 + r : pe - 1;
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) g[r][c] = p0 + r < pe ? a.gy[(size_t)p * NC + c] : 0.0f;
+                    uv[r] = reinterpret_cast<const float4 *>(a.u + (size_t)p * a.K)[qq];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool on = qv && p0 + r < pe;
+                    const int p = p0 + r < pe ? p0 + r : pe - 1;
+                    const unsigned long long mix = DROP ? drop_mix(a.seed, (unsigned long long)p * nk + qq) : 0ull;
+                    float o[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        o[0] = __builtin_fmaf(g[r][c], wv[c].x, o[0]);
+                        o[1] = __builtin_fmaf(g[r][c], wv[c].y, o[1]);
+                        o[2] = __builtin_fmaf(g[r][c], wv[c].z, o[2]);
+                        o[3] = __builtin_fmaf(g[r][c], wv[c].w, o[3]);
+                    }
+                    float d[4], dvv[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float u = f4(uv[r], e);
+                        const float v = __builtin_fmaf(u, f4(sc, e), f4(sh, e));
+                        const float z = lrelu_f(v, a.slope);
+                        const bool keep = DROP ? drop_keep(mix, e, a.keep16) : true;
+                        d[e] = keep ? (DROP ? z * a.inv_keep : z) : 0.0f;
+                        const float gz = keep ? (DROP ? o[e] * a.inv_keep : o[e]) : 0.0f;
+                        dvv[e] = on ? (v > 0.0f ? gz : gz * a.slope) : 0.0f;
+                        const float uh = (u - f4(mean, e)) * f4(rstd, e);
+                        tdv[e] += dvv[e];
+                        tdu[e] = __builtin_fmaf(dvv[e], uh, tdu[e]);
+                        amax_dv = fmaxf(amax_dv, fabsf(dvv[e]));
+                        amax_uh = on ? fmaxf(amax_uh, fabsf(uh)) : amax_uh;
+                    }
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {  // (g = 0 in rows past the tile)
+                        dw[c].x = __builtin_fmaf(g[r][c], d[0], dw[c].x);
+                        dw[c].y = __builtin_fmaf(g[r][c], d[1], dw[c].y);
+                        dw[c].z = __builtin_fmaf(g[r][c], d[2], dw[c].z);
+                        dw[c].w = __builtin_fmaf(g[r][c], d[3], dw[c].w);
+                    }
+                    if (on) reinterpret_cast<float4 *>(a.dv + (size_t)(p0 + r) * a.K)[q] = float4{dvv[0], dvv[1], dvv[2], dvv[3]};
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                sdv[e] += (double)tdv[e];
+                sdu[e] += (double)tdu[e];
+            }
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                amax_dv = fmaxf(amax_dv, __shfl_xor(amax_dv, o));
+                amax_uh = fmaxf(amax_uh, __shfl_xor(amax_uh, o));
+            }
+            if (lane == 0) {
+                atomicMax(a.oa + tile, __float_as_uint(amax_dv));
+                atomicMax(a.ob + tile, __float_as_uint(amax_uh));
+                atomicMax(a.oa + a.nrb, __float_as_uint(amax_dv));
+                atomicMax(a.ob + a.nrb, __float_as_uint(amax_uh));
+            }
+        }
+        // fold the four waves in wave order: one record per workgroup
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            red[wave][c * 4 + 0][lane] = dw[c].x;
+            red[wave][c * 4 + 1][lane] = dw[c].y;
+            red[wave][c * 4 + 2][lane] = dw[c].z;
+            red[wave][c * 4 + 3][lane] = dw[c].w;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            redd[wave][e][lane] = sdv[e];
+            redd[wave][4 + e][lane] = sdu[e];
+        }
+        __syncthreads();
+        if (wave == 0 && qv) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                float4 t;
+                t.x = (red[0][c * 4 + 0][lane] + red[1][c * 4 + 0][lane]) + (red[2][c * 4 + 0][lane] + red[3][c * 4 + 0][lane]);
+                t.y = (red[0][c * 4 + 1][lane] + red[1][c * 4 + 1][lane]) + (red[2][c * 4 + 1][lane] + red[3][c * 4 + 1][lane]);
+                t.z = (red[0][c * 4 + 2][lane] + red[1][c * 4 + 2][lane]) + (red[2][c * 4 + 2][lane] + red[3][c * 4 + 2][lane]);
+                t.w = (red[0][c * 4 + 3][lane] + red[1][c * 4 + 3][lane]) + (red[2][c * 4 + 3][lane] + red[3][c * 4 + 3][lane]);
+                reinterpret_cast<float4 *>(a.pdw + ((size_t)blockIdx.x * NC + c) * a.K)[q] = t;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a.pbn[((size_t)blockIdx.x * 2 + 0) * a.K + 4 * q + e] = (redd[0][e][lane] + redd[1][e][lane]) + (redd[2][e][lane] + redd[3][e][lane]);
+                a.pbn[((size_t)blockIdx.x * 2 + 1) * a.K + 4 * q + e] =
+                    (redd[0][4 + e][lane] + redd[1][4 + e][lane]) + (redd[2][4 + e][lane] + redd[3][4 + e][lane]);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---- finalizers: fold per-workgroup records in record order (16 waves take every 16th record, 8 in flight; the wave sums
+// are added in wave order: the association depends on the record count only) ---------------------------------------------
+constexpr int FW = 16;
+
+// forward: BatchNorm1d batch statistics (or the running ones) -> stats [4][C] = mean, rstd, sc, sh; running statistics
+// updated when training; zmax <- bits of max |LReLU(BN(u))| over the whole tensor, exact: per column the activation is
+// monotone in u, so its extremes are the images of the column's extremes.
+__global__ __launch_bounds__(64 * FW) void stats_finalize_kernel(const double *__restrict__ psum, const float *__restrict__ pext,
+                                                                 int nrec, int P, int C, int training,
+                                                                 const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                                 float *__restrict__ rmean, float *__restrict__ rvar, float eps,
+                                                                 float momentum, float slope, float *__restrict__ stats,
+                                                                 unsigned *__restrict__ zmax)
+{
+    __shared__ double red[FW][2][64];
+    __shared__ float rex[FW][2][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const bool live = c < C;
+    double a0 = 0.0, a1 = 0.0;
+    float mn = __builtin_inff(), mx = -__builtin_inff();
+    if (live) {
+        int g = wave;
+        for (; g + 7 * FW < nrec; g += 8 * FW) {
+            double va[8], vb[8];
+            float ea[8], eb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const size_t o = (size_t)(g + u * FW) * 2 * C + c;
+                va[u] = training ? psum[o] : 0.0;
+                vb[u] = training ? psum[o + C] : 0.0;
+                ea[u] = pext[o];
+                eb[u] = pext[o + C];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                a0 += va[u];
+                a1 += vb[u];
+                mn = fminf(mn, ea[u]);
+                mx = fmaxf(mx, eb[u]);
+            }
+        }
+        for (; g < nrec; g += FW) {
+            const size_t o = (size_t)g * 2 * C + c;
+            if (training) {
+                a0 += psum[o];
+                a1 += psum[o + C];
+            }
+            mn = fminf(mn, pext[o]);
+            mx = fmaxf(mx, pext[o + C]);
+        }
+    }
+    red[wave][0][lane] = a0;
+    red[wave][1][lane] = a1;
+    rex[wave][0][lane] = mn;
+    rex[wave][1][lane] = mx;
+    __syncthreads();
+    if (wave != 0) return;
+    double s = 0.0, ss = 0.0;
+#pragma unroll
+    for (int w = 0; w < FW; ++w) {
+        s += red[w][0][lane];
+        ss += red[w][1][lane];
+        mn = fminf(mn, rex[w][0][lane]);
+        mx = fmaxf(mx, rex[w][1][lane]);
+    }
+    float zm = 0.0f;
+    if (live) {
+        float mean, var;
+        if (training) {
+            const double m = s / P;
+            double v = ss / P - m * m;
+            if (v < 0.0) v = 0.0;
+            mean = (float)m;
+            var = (float)v;
+            if (rmean) {
+                const double unbiased = P > 1 ? v * P / (P - 1.0) : v;
+                rmean[c] = (1.0f - momentum) * rmean[c] + momentum * mean;
+                rvar[c] = (1.0f - momentum) * rvar[c] + momentum * (float)unbiased;
+            }
+        } else {
+            mean = rmean[c];
+            var = rvar[c];
+        }
+        const float rstd = (float)(1.0 / sqrt((double)var + (double)eps));
+        const float sc = gamma[c] * rstd, sh = beta[c] - mean * sc;
+        stats[0 * (size_t)C + c] = mean;
+        stats[1 * (size_t)C + c] = rstd;
+        stats[2 * (size_t)C + c] = sc;
+        stats[3 * (size_t)C + c] = sh;
+        zm = fmaxf(fabsf(lrelu_f(__builtin_fmaf(mn, sc, sh), slope)), fabsf(lrelu_f(__builtin_fmaf(mx, sc, sh), slope)));
+        if (!(zm <= 3.0e38f)) zm = 0.0f;  // (a non-finite activation: any scale is as good)
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) zm = fmaxf(zm, __shfl_xor(zm, o));
+    if (lane == 0 && zmax) atomicMax(zmax, __float_as_uint(zm));
+}
+
+// BatchNorm backward constants of one column from the two sums; sb <- bits of max |sc|, max |c1|, max |c2| (zero at launch)
+__device__ __forceinline__ void bn_bwd_consts(double sdv, double sdu, int P, int training, int c, bool live, float sc,
+                                              float *__restrict__ gw, float *__restrict__ gb, float *__restrict__ cc, int C,
+                                              unsigned *__restrict__ sb, float &c1, float &c2)
+{
+    c1 = live && training ? (float)(sdv / P) : 0.0f;
+    c2 = live && training ? (float)(sdu / P) : 0.0f;
+    if (live) {
+        gb[c] = (float)sdv;
+        gw[c] = (float)sdu;
+        cc[c] = c1;
+        cc[C + c] = c2;
+    }
+    float m0 = live ? fabsf(sc) : 0.0f, m1 = fabsf(c1), m2 = fabsf(c2);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        m0 = fmaxf(m0, __shfl_xor(m0, o));
+        m1 = fmaxf(m1, __shfl_xor(m1, o));
+        m2 = fmaxf(m2, __shfl_xor(m2, o));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(sb + 0, __float_as_uint(m0));
+        atomicMax(sb + 1, __float_as_uint(m1));
+        atomicMax(sb + 2, __float_as_uint(m2));
+    }
+}
+
+// backward, from the classifier pass: records pbn [nrec][2][C] -> gw = sum dv uhat, gb = sum dv, cc = [c1 | c2]
+__global__ __launch_bounds__(64 * FW) void bwd_finalize_kernel(const double *__restrict__ pbn, int nrec, int P, int C,
+                                                               int training, const float *__restrict__ stats,
+                                                               float *__restrict__ gw, float *__restrict__ gb,
+                                                               float *__restrict__ cc, unsigned *__restrict__ sb)
+{
+    __shared__ double red[FW][2][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const bool live = c < C;
+    double a0 = 0.0, a1 = 0.0;
+    if (live) {
+        int g = wave;
+        for (; g + 7 * FW < nrec; g += 8 * FW) {
+            double va[8], vb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                va[u] = pbn[(size_t)(g + u * FW) * 2 * C + c];
+                vb[u] = pbn[(size_t)(g + u * FW) * 2 * C + C + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                a0 += va[u];
+                a1 += vb[u];
+            }
+        }
+        for (; g < nrec; g += FW) {
+            a0 += pbn[(size_t)g * 2 * C + c];
+            a1 += pbn[(size_t)g * 2 * C + C + c];
+        }
+    }
+    red[wave][0][lane] = a0;
+    red[wave][1][lane] = a1;
+    __syncthreads();
+    if (wave != 0) return;
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int w = 0; w < FW; ++w) {
+        s0 += red[w][0][lane];
+        s1 += red[w][1][lane];
+    }
+    float c1, c2;
+    bn_bwd_consts(s0, s1, P, training, c, live, live ? stats[2 * (size_t)C + c] : 0.0f, gw, gb, cc, C, sb, c1, c2);
+}
+
+// backward, from a product's E_DV epilogue: records pdv [nrb][2 slots][3][C] (sum dv, sum dv uhat, sum uhat per
+// batch-element slot of a 128-row tile).  Wave w adds up batch elements w, w + 16, ... (tiles in order), the totals are the
+// wave sums in wave order; then gw, gb, cc as above and the gradient of the per-batch-element row that was added to u:
+//   gadd[b][c] = sum over the rows of b of du = sc (sum_b dv - N c1 - c2 sum_b uhat).
+constexpr int SLOT_B = 4;  // batch elements per wave: B <= 64
+__global__ __launch_bounds__(64 * FW) void bwd_finalize_slots_kernel(const double *__restrict__ pdv, int nrb, int B, int N, int C,
+                                                                     int training, const float *__restrict__ stats,
+                                                                     float *__restrict__ gw, float *__restrict__ gb,
+                                                                     float *__restrict__ cc, unsigned *__restrict__ sb,
+                                                                     float *__restrict__ gadd)
+{
+    __shared__ double red[FW][2][64];
+    __shared__ float scc[2][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const bool live = c < C;
+    double bdv[SLOT_B], bdu[SLOT_B], buh[SLOT_B];
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int i = 0; i < SLOT_B; ++i) {
+        const int b = wave + i * FW;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+        if (live && b < B) {
+            const int t0 = (int)(((long long)b * N) / 128), t1 = (int)((((long long)(b + 1)) * N - 1) / 128);
+            for (int t = t0; t <= t1 && t < nrb; ++t) {
+                const int sl = b - (int)(((long long)t * 128) / N);  // 0: b is the tile's first batch element, 1: its second
+                const double *r = pdv + (((size_t)t * 2 + sl) * 3) * C + c;
+                s0 += r[0];
+                s1 += r[C];
+                s2 += r[2 * (size_t)C];
+            }
+        }
+        bdv[i] = s0;
+        bdu[i] = s1;
+        buh[i] = s2;
+        a0 += s0;
+        a1 += s1;
+    }
+    red[wave][0][lane] = a0;
+    red[wave][1][lane] = a1;
+    __syncthreads();
+    if (wave == 0) {
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int w = 0; w < FW; ++w) {
+            s0 += red[w][0][lane];
+            s1 += red[w][1][lane];
+        }
+        float c1, c2;
+        bn_bwd_consts(s0, s1, B * N, training, c, live, live ? stats[2 * (size_t)C + c] : 0.0f, gw, gb, cc, C, sb, c1, c2);
+        scc[0][lane] = c1;
+        scc[1][lane] = c2;
+    }
+    __syncthreads();
+    if (!live || !gadd) return;
+    const float c1 = scc[0][lane], c2 = scc[1][lane], sc = stats[2 * (size_t)C + c];
+#pragma unroll
+    for (int i = 0; i < SLOT_B; ++i) {
+        const int b = wave + i * FW;
+        if (b < B) gadd[(size_t)b * C + c] = sc * (float)(bdv[i] - (double)N * (double)c1 - (double)c2 * buh[i]);
+    }
+}
+
+__global__ void dropout_mask_kernel(unsigned long long seed, int P, int K, unsigned keep16, unsigned char *mask)
+{
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nq = (size_t)P * (K / 4);
+    if (q >= nq) return;
+    const unsigned long long mix = drop_mix(seed, q);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) mask[4 * q + e] = drop_keep(mix, e, keep16) ? 1 : 0;
+}
+
+// ---- host side: layouts and launch sequences ----------------------------------------------------------------------------
+struct Carver {
+    char *base;
+    size_t off;
+    explicit Carver(void *p) : base((char *)p), off(0) {}
+    template <typename T>
+    T *take(size_t n)
+    {
+        T *r = (T *)(base + off);
+        off += align_up(n * sizeof(T), 256);
+        return r;
+    }
+};
+struct Planes {
+    _Float16 *hi, *lo;
+    float *scale;
+};
+template <typename C>
+static Planes take_planes(C &c, int rows, int cols)
+{
+    Planes p;
+    p.hi = c.template take<_Float16>((size_t)rows * cols);
+    p.lo = c.template take<_Float16>((size_t)rows * cols);
+    p.scale = c.template take<float>(rows);
+    return p;
+}
+struct Saved {
+    float *u7, *u8, *stats7, *stats8;
+    unsigned *zmax;  // [0] max |z7|, [1] max |z8| (unused)
+    Planes w7c, w8, w8t, w7ct;
+    size_t bytes;
+};
+static Saved saved_layout(const dgcnn_head_tail_desc *d, void *p)
+{
+    Carver c(p);
+    Saved s;
+    const size_t P = (size_t)d->B * d->N;
+    s.u7 = c.take<float>(P * d->C7);
+    s.u8 = c.take<float>(P * d->C8);
+    s.stats7 = c.take<float>(4 * (size_t)d->C7);
+    s.stats8 = c.take<float>(4 * (size_t)d->C8);
+    s.zmax = c.take<unsigned>(4);
+    s.w7c = take_planes(c, d->C7, d->F);
+    s.w8 = take_planes(c, d->C8, d->C7);
+    s.w8t = take_planes(c, d->C7, d->C8);
+    s.w7ct = take_planes(c, d->F, d->C7);
+    s.bytes = c.off;
+    return s;
+}
+static int row_blocks(const dgcnn_head_tail_desc *d) { return ceil_div(d->B * d->N, GM); }
+struct FwdWs {
+    double *psum7, *psum8;
+    float *pext7, *pext8;
+    size_t bytes;
+};
+static FwdWs fwd_ws(const dgcnn_head_tail_desc *d, void *p)
+{
+    Carver c(p);
+    FwdWs w;
+    const size_t nrb = row_blocks(d);
+    w.psum7 = c.take<double>(nrb * 2 * d->C7);
+    w.pext7 = c.take<float>(nrb * 2 * d->C7);
+    w.psum8 = c.take<double>(nrb * 2 * d->C8);
+    w.pext8 = c.take<float>(nrb * 2 * d->C8);
+    w.bytes = c.off;
+    return w;
+}
+static int wgrad_chunks(int M, int Nn, int P)
+{
+    const int tiles = ceil_div(M, 128) * ceil_div(Nn, 128);
+    int chunks = 768 / tiles;  // about three workgroups per CU
+    if (chunks < 8) chunks = 8;
+    const int most = ceil_div(P, 128);
+    if (chunks > most) chunks = most;
+    return chunks < 1 ? 1 : chunks;
+}
+static int cls_blocks(int nrb) { return nrb < 512 ? nrb : 512; }
+struct BwdWs {
+    unsigned *zero;  // one block, zeroed by a memset node: oa8, ob8, oa7, ob7 [nrb + 1] each, sb8 [4], sb7 [4]
+    size_t zero_words;
+    unsigned *oa8, *ob8, *oa7, *ob7, *sb8, *sb7;
+    float *dv8, *dv7, *pdw9, *cc8, *cc7, *wpart;
+    double *pbn8, *pdv7;
+    size_t bytes;
+};
+static BwdWs bwd_ws(const dgcnn_head_tail_desc *d, void *p)
+{
+    Carver c(p);
+    BwdWs w;
+    const size_t P = (size_t)d->B * d->N, nrb = row_blocks(d);
+    w.zero_words = 4 * (nrb + 1) + 8;
+    w.zero = c.take<unsigned>(w.zero_words);
+    w.oa8 = w.zero;
+    w.ob8 = w.oa8 + nrb + 1;
+    w.oa7 = w.ob8 + nrb + 1;
+    w.ob7 = w.oa7 + nrb + 1;
+    w.sb8 = w.ob7 + nrb + 1;
+    w.sb7 = w.sb8 + 4;
+    w.dv8 = c.take<float>(P * d->C8);
+    w.dv7 = c.take<float>(P * d->C7);
+    w.pdw9 = c.take<float>((size_t)cls_blocks((int)nrb) * d->NC * d->C8);
+    w.pbn8 = c.take<double>((size_t)cls_blocks((int)nrb) * 2 * d->C8);
+    w.cc8 = c.take<float>(2 * (size_t)d->C8);
+    w.pdv7 = c.take<double>(nrb * 2 * 3 * d->C7);
+    w.cc7 = c.take<float>(2 * (size_t)d->C7);
+    const size_t wp8 = (size_t)wgrad_chunks(d->C8, d->C7, (int)P) * d->C8 * d->C7, wp7 = (size_t)wgrad_chunks(d->C7, d->F, (int)P) * d->C7 * d->F;
+    w.wpart = c.take<float>(wp8 > wp7 ? wp8 : wp7);
+    w.bytes = c.off;
+    return w;
+}
+
+static int check_desc(const dgcnn_head_tail_desc *d, const char *who, bool params)
+{
+    DG_REQUIRE(d, "%s: null descriptor", who);
+    DG_REQUIRE(d->B > 0 && d->N >= GM && d->B <= FW * SLOT_B, "%s: needs 1 <= B <= %d and N >= %d (B=%d N=%d)", who, FW * SLOT_B, GM,
+               d->B, d->N);
+    DG_REQUIRE((size_t)d->B * d->N < ((size_t)1 << 23), "%s: more than 2^23 points", who);
+    DG_REQUIRE(d->F > 0 && d->F % 32 == 0 && d->C7 > 0 && d->C7 % 32 == 0 && d->C8 > 0 && d->C8 % 32 == 0 && d->C8 <= 1024,
+               "%s: F, C7, C8 must be multiples of 32 (C8 <= 1024): F=%d C7=%d C8=%d", who, d->F, d->C7, d->C8);
+    DG_REQUIRE(d->NC >= 1 && d->NC <= CLS_MAX, "%s: 1 <= classes <= %d (NC=%d)", who, CLS_MAX, d->NC);
+    DG_REQUIRE(d->ldcat >= d->F && d->ldcat % 4 == 0 && d->ldw7 >= d->F && d->ldw7 % 4 == 0, "%s: ldcat / ldw7 must be multiples of 4 and >= F", who);
+    DG_REQUIRE(d->p_drop >= 0.0f && d->p_drop < 1.0f, "%s: dropout probability %g outside [0, 1)", who, (double)d->p_drop);
+    if (!params) return 0;
+    DG_REQUIRE(d->w7c && d->w8 && d->w9 && d->bn7.weight && d->bn7.bias && d->bn8.weight && d->bn8.bias, "%s: parameters missing", who);
+    DG_REQUIRE(((uintptr_t)d->w7c & 15) == 0 && ((uintptr_t)d->w8 & 15) == 0 && ((uintptr_t)d->w9 & 15) == 0, "%s: weights must be 16-byte aligned", who);
+    DG_REQUIRE(d->training || (d->bn7.running_mean && d->bn7.running_var && d->bn8.running_mean && d->bn8.running_var),
+               "%s: eval mode needs running statistics", who);
+    return 0;
+}
+
+#define HF_CLS_DISPATCH(NC_, CALL)                      \
+    switch (NC_) {                                      \
+        case 1: { constexpr int NCV = 1; CALL; } break; \
+        case 2: { constexpr int NCV = 2; CALL; } break; \
+        case 3: { constexpr int NCV = 3; CALL; } break; \
+        case 4: { constexpr int NCV = 4; CALL; } break; \
+        case 5: { constexpr int NCV = 5; CALL; } break; \
+        case 6: { constexpr int NCV = 6; CALL; } break; \
+        case 7: { constexpr int NCV = 7; CALL; } break; \
+        default: { constexpr int NCV = 8; CALL; } break; \
+    }
+
+static unsigned keep16_of(float p) { return (unsigned)((1.0 - (double)p) * 65536.0 + 0.5); }
+// the survivors' scale: the reciprocal of the keep probability the mask REALISES (a multiple of 2^-16), so that the
+// expectation of dropout(z) is z exactly
+static float inv_keep_of(float p) { return (float)(65536.0 / (double)keep16_of(p)); }
+
+}  // namespace hf
+}  // namespace dgcnn
+
+using namespace dgcnn;
+using namespace dgcnn::hf;
+
+extern "C" size_t dgcnn_head_tail_saved_bytes(const dgcnn_head_tail_desc *d)
+{
+    return check_desc(d, "dgcnn_head_tail_saved_bytes", false) == 0 ? saved_layout(d, nullptr).bytes : 0;
+}
+extern "C" size_t dgcnn_head_tail_fwd_workspace_bytes(const dgcnn_head_tail_desc *d)
+{
+    return check_desc(d, "dgcnn_head_tail_fwd_workspace_bytes", false) == 0 ? fwd_ws(d, nullptr).bytes : 0;
+}
+extern "C" size_t dgcnn_head_tail_bwd_workspace_bytes(const dgcnn_head_tail_desc *d)
+{
+    return check_desc(d, "dgcnn_head_tail_bwd_workspace_bytes", false) == 0 ? bwd_ws(d, nullptr).bytes : 0;
+}
+
+extern "C" int dgcnn_head_tail_fwd(const dgcnn_head_tail_desc *d, const float *cat, const uint32_t *amax_cat, const float *add7,
+                                   float *logits, void *saved, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (check_desc(d, "dgcnn_head_tail_fwd", true)) return 1;
+    DG_REQUIRE(cat && amax_cat && logits && saved && workspace, "dgcnn_head_tail_fwd: null pointer");
+    DG_REQUIRE(((uintptr_t)cat & 15) == 0, "dgcnn_head_tail_fwd: cat must be 16-byte aligned");
+    const FwdWs w = fwd_ws(d, workspace);
+    DG_REQUIRE(workspace_bytes >= w.bytes, "dgcnn_head_tail_fwd: workspace too small (%zu < %zu)", workspace_bytes, w.bytes);
+    const Saved s = saved_layout(d, saved);
+    hipStream_t st = (hipStream_t)stream;
+    const int P = d->B * d->N, nrb = row_blocks(d), F = d->F, C7 = d->C7, C8 = d->C8;
+
+    {   // the weights of this step as fp16 planes, both orientations (the backward reads the transposed ones)
+        WPrepArgs a{};
+        a.job[0] = WPrepJob{d->w7c, d->ldw7, C7, F, 0, s.w7c.hi, s.w7c.lo, s.w7c.scale};
+        a.job[1] = WPrepJob{d->w8, C7, C8, C7, 0, s.w8.hi, s.w8.lo, s.w8.scale};
+        a.job[2] = WPrepJob{d->w8, C7, C7, C8, 1, s.w8t.hi, s.w8t.lo, s.w8t.scale};
+        a.job[3] = WPrepJob{d->w7c, d->ldw7, F, C7, 1, s.w7ct.hi, s.w7ct.lo, s.w7ct.scale};
+        a.njobs = 4;
+        a.first_row[0] = 0;
+        for (int j = 0; j < 4; ++j) a.first_row[j + 1] = a.first_row[j] + a.job[j].rows;
+        hipLaunchKernelGGL(wprep_kernel, dim3(ceil_div(a.first_row[4], 4)), dim3(256), 0, st, a);
+    }
+    {   // u7 = cat . W7c^T + add7[b]; column sums and extrema in the epilogue
+        HGemmArgs a{};
+        a.X = cat, a.ldx = d->ldcat, a.P = P, a.K = F, a.N = C7;
+        a.Wh = s.w7c.hi, a.Wl = s.w7c.lo, a.wscale = s.w7c.scale;
+        a.xmax = amax_cat;
+        a.slope = d->slope;
+        a.add = add7, a.rows_per_batch = d->N;
+        a.Y = s.u7, a.ldy = C7;
+        a.psum = d->training ? w.psum7 : nullptr, a.pext = w.pext7, a.zero = s.zmax;
+        a.ncb = ceil_div(C7, GN), a.nrb = nrb;
+        hipLaunchKernelGGL((hgemm_kernel<X_RAW, E_STATS>), dim3(a.ncb * nrb), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(stats_finalize_kernel, dim3(ceil_div(C7, 64)), dim3(64 * FW), 0, st, w.psum7, w.pext7, nrb, P, C7,
+                           d->training, d->bn7.weight, d->bn7.bias, d->bn7.running_mean, d->bn7.running_var, d->eps7,
+                           d->momentum7, d->slope, s.stats7, s.zmax);
+    }
+    {   // u8 = LReLU(BN7(u7)) . W8^T: the activation is formed where the product loads its operand
+        HGemmArgs a{};
+        a.X = s.u7, a.ldx = C7, a.P = P, a.K = C7, a.N = C8;
+        a.Wh = s.w8.hi, a.Wl = s.w8.lo, a.wscale = s.w8.scale;
+        a.xmax = s.zmax;
+        a.pc[0] = s.stats7 + 2 * (size_t)C7, a.pc[1] = s.stats7 + 3 * (size_t)C7;
+        a.slope = d->slope;
+        a.Y = s.u8, a.ldy = C8;
+        a.psum = d->training ? w.psum8 : nullptr, a.pext = w.pext8, a.zero = s.zmax + 1;
+        a.ncb = ceil_div(C8, GN), a.nrb = nrb;
+        hipLaunchKernelGGL((hgemm_kernel<X_BN, E_STATS>), dim3(a.ncb * nrb), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(stats_finalize_kernel, dim3(ceil_div(C8, 64)), dim3(64 * FW), 0, st, w.psum8, w.pext8, nrb, P, C8,
+                           d->training, d->bn8.weight, d->bn8.bias, d->bn8.running_mean, d->bn8.running_var, d->eps8,
+                           d->momentum8, d->slope, s.stats8, s.zmax + 1);
+    }
+    {   // logits = dropout(LReLU(BN8(u8))) . W9^T
+        ClsArgs a{};
+        a.u = s.u8, a.P = P, a.K = C8, a.nrb = nrb;
+        a.mean = s.stats8, a.rstd = s.stats8 + C8, a.sc = s.stats8 + 2 * (size_t)C8, a.sh = s.stats8 + 3 * (size_t)C8;
+        a.w = d->w9, a.slope = d->slope;
+        const bool drop = d->training && d->p_drop > 0.0f;
+        a.keep16 = keep16_of(d->p_drop), a.inv_keep = inv_keep_of(d->p_drop), a.seed = d->seed;
+        a.y = logits;
+        int grid = ceil_div(P, 4 * CLS_ROWS);
+        grid = grid > 4096 ? 4096 : grid;
+        if (drop) {
+            HF_CLS_DISPATCH(d->NC, hipLaunchKernelGGL((cls_fwd_fused_kernel<NCV, true>), dim3(grid), dim3(256), 0, st, a));
+        } else {
+            HF_CLS_DISPATCH(d->NC, hipLaunchKernelGGL((cls_fwd_fused_kernel<NCV, false>), dim3(grid), dim3(256), 0, st, a));
+        }
+    }
+    DG_CHECK_LAUNCH("dgcnn_head_tail_fwd");
+    return 0;
+}
+
+extern "C" int dgcnn_head_tail_bwd(const dgcnn_head_tail_desc *d, const float *cat, const uint32_t *amax_cat,
+                                   const float *glogits, const void *saved, const dgcnn_head_tail_grads *g, void *workspace,
+                                   size_t workspace_bytes, void *stream)
+{
+    if (check_desc(d, "dgcnn_head_tail_bwd", true)) return 1;
+    DG_REQUIRE(cat && amax_cat && glogits && saved && g && workspace, "dgcnn_head_tail_bwd: null pointer");
+    DG_REQUIRE(g->gcat && g->gadd7 && g->gw7c && g->gbn7_w && g->gbn7_b && g->gw8 && g->gbn8_w && g->gbn8_b && g->gw9,
+               "dgcnn_head_tail_bwd: gradient outputs missing");
+    DG_REQUIRE(g->ldgcat >= d->F, "dgcnn_head_tail_bwd: ldgcat < F");
+    const BwdWs w = bwd_ws(d, workspace);
+    DG_REQUIRE(workspace_bytes >= w.bytes, "dgcnn_head_tail_bwd: workspace too small (%zu < %zu)", workspace_bytes, w.bytes);
+    const Saved s = saved_layout(d, const_cast<void *>(saved));
+    hipStream_t st = (hipStream_t)stream;
+    const int P = d->B * d->N, nrb = row_blocks(d), F = d->F, C7 = d->C7, C8 = d->C8, NC = d->NC;
+    const float *mean7 = s.stats7, *rstd7 = s.stats7 + C7, *sc7 = s.stats7 + 2 * (size_t)C7, *sh7 = s.stats7 + 3 * (size_t)C7;
+    const float *mean8 = s.stats8, *rstd8 = s.stats8 + C8, *sc8 = s.stats8 + 2 * (size_t)C8, *sh8 = s.stats8 + 3 * (size_t)C8;
+
+    if (hipMemsetAsync(w.zero, 0, w.zero_words * sizeof(unsigned), st) != hipSuccess) DG_FAIL("dgcnn_head_tail_bwd: hipMemsetAsync failed");
+    {   // classifier backward: dv8, dW9 records, BatchNorm-8 sums, tile maxima
+        ClsArgs a{};
+        a.u = s.u8, a.P = P, a.K = C8, a.nrb = nrb, a.nblk = cls_blocks(nrb);
+        a.mean = mean8, a.rstd = rstd8, a.sc = sc8, a.sh = sh8;
+        a.w = d->w9, a.slope = d->slope;
+        const bool drop = d->training && d->p_drop > 0.0f;
+        a.keep16 = keep16_of(d->p_drop), a.inv_keep = inv_keep_of(d->p_drop), a.seed = d->seed;
+        a.gy = glogits, a.dv = w.dv8, a.pdw = w.pdw9, a.pbn = w.pbn8, a.oa = w.oa8, a.ob = w.ob8;
+        if (drop) {
+            HF_CLS_DISPATCH(NC, hipLaunchKernelGGL((cls_bwd_fused_kernel<NCV, true>), dim3(a.nblk), dim3(256), 0, st, a));
+        } else {
+            HF_CLS_DISPATCH(NC, hipLaunchKernelGGL((cls_bwd_fused_kernel<NCV, false>), dim3(a.nblk), dim3(256), 0, st, a));
+        }
+        launch_sum_partials(w.pdw9, a.nblk, NC * C8, g->gw9, st);
+        hipLaunchKernelGGL(bwd_finalize_kernel, dim3(ceil_div(C8, 64)), dim3(64 * FW), 0, st, w.pbn8, a.nblk, P, C8, d->training,
+                           s.stats8, g->gbn8_w, g->gbn8_b, w.cc8, w.sb8);
+    }
+    {   // dL/dz7 = du8 . W8 with du8 formed from (dv8, u8) at the operand load; dv7 = dL/dz7 . LReLU'(v7) and the
+        // BatchNorm-7 sums in the epilogue
+        HGemmArgs a{};
+        a.X = w.dv8, a.ldx = C8, a.X2 = s.u8, a.ldx2 = C8, a.P = P, a.K = C8, a.N = C7;
+        a.Wh = s.w8t.hi, a.Wl = s.w8t.lo, a.wscale = s.w8t.scale;
+        a.ta = w.oa8, a.tb = w.ob8, a.sb = w.sb8;
+        a.pc[0] = mean8, a.pc[1] = rstd8, a.pc[2] = sc8, a.pc[3] = w.cc8, a.pc[4] = w.cc8 + C8;
+        a.slope = d->slope;
+        a.rows_per_batch = d->N;
+        a.Y = w.dv7, a.ldy = C7;
+        a.U = s.u7, a.ldu = C7;
+        a.ec[0] = mean7, a.ec[1] = rstd7, a.ec[2] = sc7, a.ec[3] = sh7;
+        a.pdv = w.pdv7, a.oa = w.oa7, a.ob = w.ob7;
+        a.ncb = ceil_div(C7, GN), a.nrb = nrb;
+        hipLaunchKernelGGL((hgemm_kernel<X_DU, E_DV>), dim3(a.ncb * nrb), dim3(256), 0, st, a);
+    }
+    {   // dW8 = du8^T z7: both operands formed at the load
+        HWgradArgs a{};
+        a.A = w.dv8, a.lda = C8, a.A2 = s.u8, a.lda2 = C8, a.M = C8;
+        a.Bm = s.u7, a.ldb = C7, a.Nn = C7, a.P = P;
+        const int chunks = wgrad_chunks(C8, C7, P);
+        a.chunk = (ceil_div(P, chunks) + 31) & ~31;
+        a.ntiles_n = ceil_div(C7, 128);
+        a.ac[0] = mean8, a.ac[1] = rstd8, a.ac[2] = sc8, a.ac[3] = w.cc8, a.ac[4] = w.cc8 + C8;
+        a.bc[0] = sc7, a.bc[1] = sh7;
+        a.slope = d->slope;
+        a.ta = w.oa8, a.tb = w.ob8, a.sb = w.sb8, a.gi = nrb;
+        a.amax_b = s.zmax;
+        a.partial = w.wpart;
+        const int nch = ceil_div(P, a.chunk);
+        const dim3 grid((unsigned)align_up((size_t)ceil_div(C8, 128) * a.ntiles_n * nch, 8));
+        hipLaunchKernelGGL((hwgrad_kernel<A_DU, B_BN>), grid, dim3(256), 0, st, a);
+        launch_sum_partials(w.wpart, nch, C8 * C7, g->gw8, st);
+    }
+    hipLaunchKernelGGL(bwd_finalize_slots_kernel, dim3(ceil_div(C7, 64)), dim3(64 * FW), 0, st, w.pdv7, nrb, d->B, d->N, C7,
+                       d->training, s.stats7, g->gbn7_w, g->gbn7_b, w.cc7, w.sb7, g->gadd7);
+    {   // dL/dcat = du7 . W7c
+        HGemmArgs a{};
+        a.X = w.dv7, a.ldx = C7, a.X2 = s.u7, a.ldx2 = C7, a.P = P, a.K = C7, a.N = F;
+        a.Wh = s.w7ct.hi, a.Wl = s.w7ct.lo, a.wscale = s.w7ct.scale;
+        a.ta = w.oa7, a.tb = w.ob7, a.sb = w.sb7;
+        a.pc[0] = mean7, a.pc[1] = rstd7, a.pc[2] = sc7, a.pc[3] = w.cc7, a.pc[4] = w.cc7 + C7;
+        a.slope = d->slope;
+        a.Y = g->gcat, a.ldy = g->ldgcat;
+        a.ncb = ceil_div(F, GN), a.nrb = nrb;
+        hipLaunchKernelGGL((hgemm_kernel<X_DU, E_PLAIN>), dim3(a.ncb * nrb), dim3(256), 0, st, a);
+    }
+    {   // dW7c = du7^T cat
+        HWgradArgs a{};
+        a.A = w.dv7, a.lda = C7, a.A2 = s.u7, a.lda2 = C7, a.M = C7;
+        a.Bm = cat, a.ldb = d->ldcat, a.Nn = F, a.P = P;
+        const int chunks = wgrad_chunks(C7, F, P);
+        a.chunk = (ceil_div(P, chunks) + 31) & ~31;
+        a.ntiles_n = ceil_div(F, 128);
+        a.ac[0] = mean7, a.ac[1] = rstd7, a.ac[2] = sc7, a.ac[3] = w.cc7, a.ac[4] = w.cc7 + C7;
+        a.slope = d->slope;
+        a.ta = w.oa7, a.tb = w.ob7, a.sb = w.sb7, a.gi = nrb;
+        a.amax_b = amax_cat;
+        a.partial = w.wpart;
+        const int nch = ceil_div(P, a.chunk);
+        const dim3 grid((unsigned)align_up((size_t)ceil_div(C7, 128) * a.ntiles_n * nch, 8));
+        hipLaunchKernelGGL((hwgrad_kernel<A_DU, B_RAW>), grid, dim3(256), 0, st, a);
+        launch_sum_partials(w.wpart, nch, C7 * F, g->gw7c, st);
+    }
+    DG_CHECK_LAUNCH("dgcnn_head_tail_bwd");
+    return 0;
+}
+
+extern "C" int dgcnn_dropout_mask(uint64_t seed, int P, int K, float p_drop, uint8_t *mask, void *stream)
+{
+    DG_REQUIRE(mask && P > 0 && K > 0 && (K & 3) == 0 && p_drop >= 0.0f && p_drop < 1.0f, "dgcnn_dropout_mask: bad arguments");
+    const size_t nq = (size_t)P * (K / 4);
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (unsigned long long)seed, P, K, keep16_of(p_drop), mask);
+    DG_CHECK_LAUNCH("dgcnn_dropout_mask");
+    return 0;
+}

@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void rows_gemm16_colred_kernel(const float *__
         const int cl = nt * 32 + i32, col = col0 + cl;
         const bool cv = col < N;
         const unsigned flip = cv && gamma[col] < 0.0f ? 0x80000000u : 0u;  // gamma < 0: the activation's maximum is u's minimum
-        float s1 = 0.0f, s2 = 0.0f;
+        double s1 = 0.0, s2 = 0.0;  // (fp64 from the first addition on: |mean| >> sigma costs an fp32 sum of squares its digits)
         hkey64 best = 0;
         int bcur = -1;
 #pragma unroll
@@ -257,8 +257,8 @@ __global__ __launch_bounds__(256) void rows_gemm16_colred_kernel(const float *__
             const int row = row0 + wave * 32 + mfma32_row(r, h);
             if (row < P && cv) {
                 const float u = acc[nt][r] * un;
-                s1 += u;
-                s2 = __builtin_fmaf(u, u, s2);
+                s1 += (double)u;
+                s2 = __builtin_fma((double)u, (double)u, s2);
                 const int b = row / rows_per_batch, rl = row - b * rows_per_batch;
                 if (b != bcur) {  // the rows of a lane ascend: a batch element's rows are consecutive
                     if (bcur >= 0) {
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void rows_gemm16_colred_kernel(const float *__
             else atomicMax(keys + (size_t)bcur * N + col, best);
         }
         if (want_sums) {
-            const double d1 = (double)s1 + (double)__shfl_xor(s1, 32), d2 = (double)s2 + (double)__shfl_xor(s2, 32);
+            const double d1 = s1 + __shfl_xor(s1, 32), d2 = s2 + __shfl_xor(s2, 32);
             if (h == 0) {
                 csum[wave][0][cl] = d1;
                 csum[wave][1][cl] = d2;

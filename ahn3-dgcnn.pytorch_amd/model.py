@@ -147,8 +147,10 @@ class DGCNN(nn.Module):
                     # conv6 -> bn6 -> LeakyReLU -> max over the points (model.py:172-175): the activated [P, emb]
                     # tensor is never written (BN + LeakyReLU is monotone per column, see dgcnn_bn_lrelu_max_fwd)
                     # and its backward runs on 192-wide products only (ops._EmbedMax)
-                    g = ops.embed_max_rows(cat.reshape(P, 192), self.conv6[0].weight.squeeze(-1), self.bn6, B, N,
-                                           self.training, NEG_SLOPE).view(B, 1, emb)
+                    cat2 = cat.reshape(P, 192)
+                    amax_cat = ops.rows_absmax(cat2.detach())     # max |cat|, measured once for every product that reads cat
+                    g = ops.embed_max_rows(cat2, self.conv6[0].weight.squeeze(-1), self.bn6, B, N,
+                                           self.training, NEG_SLOPE, amax_cat).view(B, 1, emb)
                     if depth == 6:
                         out = g.transpose(1, 2).contiguous()
                     else:
@@ -161,6 +163,16 @@ class DGCNN(nn.Module):
                             # (one [B, emb] x [emb, 512] product per batch element + a 192-wide per-point GEMM:
                             # 84 % fewer FLOPs than the 1216-wide one)
                             w7 = self.conv7[0].weight.squeeze(-1)
+                            w8, w9 = self.conv8[0].weight.squeeze(-1), self.conv9.weight.squeeze(-1)
+                            if depth == 10 and ops.head_tail_supported(B, N, 192, w7.shape[0], w8.shape[0], w9.shape[0]):
+                                # conv7 .. conv9 as one forward and one backward call: only the pre-activations of
+                                # conv7 and conv8 are written (ops._HeadTail, head_fused.hip)
+                                z = ops.head_tail_rows(cat2, F.linear(g.view(B, emb), w7[:, :emb]), w7[:, emb:], self.bn7, w8,
+                                                       self.bn8, w9, B, N, self.training, NEG_SLOPE, self.dp1.p, amax_cat)
+                                out = ops.from_point_major_autograd(z.view(B, N, -1))
+                                if out.device != in_dev:
+                                    out = out.to(in_dev)
+                                return (out, used) if return_idx else out
                             u7 = ops.linear_rows(cat.reshape(P, 192), w7[:, emb:], F.linear(g.view(B, emb), w7[:, :emb]), N)
                             z = ops.bn_lrelu_rows(u7, self.bn7, self.training, NEG_SLOPE)
                             if depth == 8:

@@ -534,7 +534,7 @@ class _EmbedMax(torch.autograd.Function):
     matrix kernel's accumulators -- column sums and the running extreme are its epilogue."""
 
     @staticmethod
-    def forward(ctx, cat, w, weight, bias, rmean, rvar, B, N, training, eps, momentum, slope):
+    def forward(ctx, cat, w, weight, bias, rmean, rvar, B, N, training, eps, momentum, slope, amax_cat=None):
         P, F_ = cat.shape
         C = w.shape[0]
         lib = _lib.load()
@@ -546,7 +546,8 @@ class _EmbedMax(torch.autograd.Function):
         g = torch.empty((B, C), dtype=torch.float32, device=dev)
         arg = torch.empty((B, C), dtype=torch.int32, device=dev)
         stats = torch.empty((4, C), dtype=torch.float32, device=dev)
-        ac = rows_absmax(catd)     # max |cat|: this product and the two 192-wide ones of the backward
+        # max |cat|: this product and the two 192-wide ones of the backward (the caller's word when it has measured cat)
+        ac = amax_cat if amax_cat is not None else rows_absmax(catd)
         fused = _gemm_ok(F_) and C % 4 == 0 and catd.stride(0) % 4 == 0 and catd.data_ptr() % 16 == 0
         if fused:
             # ONE pass: the [P, emb] product never leaves the matrix kernel's accumulators (dgcnn_embed_max_fwd)
@@ -609,10 +610,10 @@ class _EmbedMax(torch.autograd.Function):
             dcat = torch.zeros_like(catd)
         _lib.check(lib.dgcnn_embed_max_bwd_scatter(_lib.ptr(arg), _lib.ptr(s), _lib.ptr(wd), B, N, C, F_, _lib.ptr(dcat), st),
                    "dgcnn_embed_max_bwd_scatter")
-        return dcat, dw.view_as(w), gw_bn, gb_bn, None, None, None, None, None, None, None, None
+        return dcat, dw.view_as(w), gw_bn, gb_bn, None, None, None, None, None, None, None, None, None
 
 
-def embed_max_rows(cat, w, bn, B, N, training, slope=0.2):
+def embed_max_rows(cat, w, bn, B, N, training, slope=0.2, amax_cat=None):
     """g[b] = max over the N points of batch element b of LeakyReLU(BatchNorm1d(cat W^T)): cat point-major rows
     [B*N, F], w [emb, F] (conv6's weight) -> [B, emb]; `bn` is the nn.BatchNorm1d module (running statistics updated
     in place when training)."""
@@ -622,10 +623,123 @@ def embed_max_rows(cat, w, bn, B, N, training, slope=0.2):
     use_batch_stats = training or bn.running_mean is None
     momentum = bn.momentum if bn.momentum is not None else 0.1
     g = _EmbedMax.apply(cat, w, bn.weight, bn.bias, bn.running_mean, bn.running_var, int(B), int(N),
-                        bool(use_batch_stats), float(bn.eps), float(momentum), float(slope))
+                        bool(use_batch_stats), float(bn.eps), float(momentum), float(slope), amax_cat)
     if training:
         _count_batch(bn)
     return g
+
+
+# ------------------------------------------------------------------------------------------------
+class _HeadTail(torch.autograd.Function):
+    """conv7 -> bn7 -> LeakyReLU -> conv8 -> bn8 -> LeakyReLU -> dropout -> conv9 (model.py:179-191) on point-major rows as
+    ONE forward and ONE backward call (dgcnn_head_tail_fwd / _bwd, head_fused.hip): only the pre-activations u7 and u8 are
+    written; BatchNorm statistics, BatchNorm + LeakyReLU (+ dropout) and every BatchNorm input gradient are prologues /
+    epilogues of the products."""
+
+    @staticmethod
+    def forward(ctx, cat, add7, w7c, g7, b7, w8, g8, b8, w9, rm7, rv7, rm8, rv8, amax_cat, B, N, training, eps7, eps8, mom7,
+                mom8, slope, p_drop, seed):
+        P, F_ = cat.shape
+        C7, C8, NC = w7c.shape[0], w8.shape[0], w9.shape[0]
+        lib = _lib.load()
+        dev = cat.device
+        tens = [t.detach().contiguous() for t in (g7, b7, g8, b8)]
+        w8c, w9c = w8.detach().contiguous(), w9.detach().contiguous()
+        w7d = w7c.detach()
+        if w7d.stride(1) != 1 or w7d.stride(0) % 4 or w7d.data_ptr() % 16:
+            w7d = w7d.contiguous()
+        catd = cat.detach()
+        d = _lib.HeadTailDesc()
+        d.B, d.N, d.F, d.C7, d.C8, d.NC = B, N, F_, C7, C8, NC
+        d.ldcat, d.ldw7 = catd.stride(0), w7d.stride(0)
+        d.training = 1 if training else 0
+        d.eps7, d.eps8, d.momentum7, d.momentum8, d.slope, d.p_drop = eps7, eps8, mom7, mom8, slope, p_drop
+        d.seed = seed
+        d.w7c, d.w8, d.w9 = w7d.data_ptr(), w8c.data_ptr(), w9c.data_ptr()
+        d.bn7 = _bn_struct(tens[0], tens[1], rm7, rv7)
+        d.bn8 = _bn_struct(tens[2], tens[3], rm8, rv8)
+        logits = torch.empty((P, NC), dtype=torch.float32, device=dev)
+        saved = torch.empty((lib.dgcnn_head_tail_saved_bytes(d),), dtype=torch.uint8, device=dev)
+        ws_bytes = lib.dgcnn_head_tail_fwd_workspace_bytes(d)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        addd = add7.detach().contiguous()
+        _lib.check(lib.dgcnn_head_tail_fwd(d, _lib.ptr(catd), _lib.ptr(amax_cat), _lib.ptr(addd), _lib.ptr(logits), _lib.ptr(saved),
+                                           _lib.ptr(ws), ws_bytes, _lib.stream_ptr(dev)), "dgcnn_head_tail_fwd")
+        ctx.save_for_backward(cat, amax_cat, saved, w7d, w8c, w9c, *tens, rm7, rv7, rm8, rv8)
+        ctx.cfg = (B, N, training, eps7, eps8, mom7, mom8, slope, p_drop, seed, tuple(w7c.shape), tuple(w8.shape), tuple(w9.shape))
+        return logits
+
+    @staticmethod
+    def backward(ctx, gl):
+        cat, amax_cat, saved, w7d, w8c, w9c, g7c, b7c, g8c, b8c, rm7, rv7, rm8, rv8 = ctx.saved_tensors
+        B, N, training, eps7, eps8, mom7, mom8, slope, p_drop, seed, w7_shape, w8_shape, w9_shape = ctx.cfg
+        P, F_ = cat.shape
+        C7, C8, NC = w7d.shape[0], w8c.shape[0], w9c.shape[0]
+        lib = _lib.load()
+        dev = cat.device
+        catd = cat.detach()
+        d = _lib.HeadTailDesc()
+        d.B, d.N, d.F, d.C7, d.C8, d.NC = B, N, F_, C7, C8, NC
+        d.ldcat, d.ldw7 = catd.stride(0), w7d.stride(0)
+        d.training = 1 if training else 0
+        d.eps7, d.eps8, d.momentum7, d.momentum8, d.slope, d.p_drop = eps7, eps8, mom7, mom8, slope, p_drop
+        d.seed = seed
+        d.w7c, d.w8, d.w9 = w7d.data_ptr(), w8c.data_ptr(), w9c.data_ptr()
+        d.bn7 = _bn_struct(g7c, b7c, rm7, rv7)
+        d.bn8 = _bn_struct(g8c, b8c, rm8, rv8)
+        gl = gl.contiguous()
+        g = _lib.HeadTailGrads()
+        gcat = torch.empty((P, F_), dtype=torch.float32, device=dev)
+        gadd = torch.empty((B, C7), dtype=torch.float32, device=dev)
+        gw7 = torch.empty((C7, F_), dtype=torch.float32, device=dev)
+        gw8, gw9 = torch.empty_like(w8c), torch.empty_like(w9c)
+        gg7, gb7, gg8, gb8 = torch.empty_like(g7c), torch.empty_like(b7c), torch.empty_like(g8c), torch.empty_like(b8c)
+        g.gcat, g.ldgcat, g.gadd7, g.gw7c = gcat.data_ptr(), F_, gadd.data_ptr(), gw7.data_ptr()
+        g.gbn7_w, g.gbn7_b, g.gw8, g.gbn8_w, g.gbn8_b, g.gw9 = (gg7.data_ptr(), gb7.data_ptr(), gw8.data_ptr(), gg8.data_ptr(),
+                                                               gb8.data_ptr(), gw9.data_ptr())
+        ws_bytes = lib.dgcnn_head_tail_bwd_workspace_bytes(d)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        _lib.check(lib.dgcnn_head_tail_bwd(d, _lib.ptr(catd), _lib.ptr(amax_cat), _lib.ptr(gl), _lib.ptr(saved), ctypes.byref(g),
+                                           _lib.ptr(ws), ws_bytes, _lib.stream_ptr(dev)), "dgcnn_head_tail_bwd")
+        return (gcat, gadd, gw7.view(w7_shape), gg7, gb7, gw8.view(w8_shape), gg8, gb8, gw9.view(w9_shape),
+                None, None, None, None, None, None, None, None, None, None, None, None, None, None, None)
+
+
+def head_tail_supported(B, N, F_, C7, C8, NC):
+    """shapes dgcnn_head_tail_* takes (include/dgcnn_hip.h); others go through the per-layer operators"""
+    return (N >= 128 and 1 <= B <= 64 and B * N < (1 << 23) and F_ % 32 == 0 and C7 % 32 == 0 and C8 % 32 == 0
+            and C8 <= 1024 and 1 <= NC <= 8)
+
+
+def head_tail_rows(cat, add7, w7c, bn7, w8, bn8, w9, B, N, training, slope=0.2, p_drop=0.0, amax_cat=None):
+    """logits [B*N, classes] of the head's tail on point-major rows: cat [B*N, F], add7 [B, C7] (conv7's share of the pooled
+    feature), w7c [C7, F] (a view of conv7's weight), w8 [C8, C7], w9 [classes, C8]; bn7 / bn8 the nn.BatchNorm1d modules
+    (running statistics updated in place when training).  Dropout (training only) draws its 64-bit seed from torch's CPU
+    generator, so torch.manual_seed makes a step reproducible; the mask itself is dgcnn_dropout_mask's."""
+    cat = _f32c(cat, "cat")
+    if cat.shape[0] != B * N:
+        raise ValueError("cat must have B*N rows")
+    if amax_cat is None:
+        amax_cat = rows_absmax(cat.detach())
+    use_batch_stats = training or bn7.running_mean is None
+    mom = [bn.momentum if bn.momentum is not None else 0.1 for bn in (bn7, bn8)]
+    drop = float(p_drop) if training else 0.0
+    seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64)) if drop > 0.0 else 0
+    y = _HeadTail.apply(cat, add7, w7c, bn7.weight, bn7.bias, w8, bn8.weight, bn8.bias, w9, bn7.running_mean, bn7.running_var,
+                        bn8.running_mean, bn8.running_var, amax_cat, int(B), int(N), bool(use_batch_stats), float(bn7.eps),
+                        float(bn8.eps), float(mom[0]), float(mom[1]), float(slope), drop, seed)
+    if training:
+        _count_batch(bn7)
+        _count_batch(bn8)
+    return y
+
+
+def dropout_mask(seed, P, K, p_drop, device):
+    """the keep mask (uint8 [P, K]) dgcnn_head_tail_* uses for (seed, p_drop)"""
+    mask = torch.empty((P, K), dtype=torch.uint8, device=device)
+    lib = _lib.load()
+    _lib.check(lib.dgcnn_dropout_mask(int(seed), P, K, float(p_drop), _lib.ptr(mask), _lib.stream_ptr(device)), "dgcnn_dropout_mask")
+    return mask
 
 
 # ------------------------------------------------------------------------------------------------

@@ -66,7 +66,9 @@ int dgcnn_knn(const float *x, int B, int N, int C, int k, int32_t *idx,
  * The backward OVERWRITES gx: centre term by a local sum over k, neighbour term (autograd's
  * IndexBackward0 of model.py:74, a scatter-add with atomics there) as a gather over the reverse
  * neighbour lists, which the call builds in `workspace` sorted by edge id: the additions happen in
- * a fixed order and the result is bit-stable from run to run.  k <= 128. */
+ * a fixed order and the result is bit-stable from run to run.  k <= 128, N <= 40000 (the list kernels keep N ints
+ * per wave in LDS), B * N * k < 2^31; the workspace query returns 0 for a shape the backward would refuse
+ * (dgcnn_last_error names the limit). */
 int dgcnn_graph_feature_fwd(const float *x, const int32_t *idx, int B, int N, int C, int k,
                             float *out, void *stream);
 size_t dgcnn_graph_feature_bwd_workspace_bytes(int B, int N, int C, int k);
@@ -91,7 +93,10 @@ int dgcnn_graph_feature_bwd(const float *gout, const int32_t *idx, int B, int N,
  * descriptor's dgcnn_bn_params carries its address, otherwise the caller's business.
  * Limits (checked, reported through dgcnn_last_error): C <= 64, k <= 96 (two-stage blocks: k <= 64), B * N < 2^24
  * points, B * N * k < 2^31 edges, slope >= 0 (the block takes max over k before the activation, which therefore has
- * to be non-decreasing). */
+ * to be non-decreasing).  The backward -- training AND eval mode -- additionally needs N <= 40000 (reverse neighbour
+ * lists: N ints per wave in LDS); dgcnn_edgeconv_bwd_workspace_bytes returns 0 for a shape the backward would
+ * refuse, with the limit in dgcnn_last_error.
+ * One process drives one GPU: per-kernel attributes are set for the process's current device. */
 typedef struct dgcnn_bn_params {
     const float *weight;  /* gamma [64] */
     const float *bias;    /* beta  [64] */
@@ -133,7 +138,10 @@ int dgcnn_edgeconv_fwd(const dgcnn_edgeconv_desc *d, const float *x, const int32
  * deterministic: the scatter-add of autograd's IndexBackward0 (model.py:74) runs as a gather over reverse
  * neighbour lists sorted by edge id, every reduction has a fixed association, no floating-point atomics:
  * two calls on the same inputs return the same bits (provided no row of idx repeats a neighbour -- a kNN
- * graph never does).  N <= 40000. */
+ * graph never does).  One qualification: in the one-stage block the few max-over-k winners of a destination's
+ * in-edges meet in LDS through float adds of ONE wave instruction on one address; the library relies on the LDS unit
+ * of gfx950 resolving those in a fixed lane order (a property of this hardware, not an ISA guarantee; held by
+ * tests/test_edgeconv_gpu.py::test_backward_is_bit_stable on every run).  N <= 40000. */
 int dgcnn_edgeconv_bwd(const dgcnn_edgeconv_desc *d, const float *x, const int32_t *idx,
                        const float *y, const float *gy, const void *saved,
                        const dgcnn_edgeconv_grads *g, void *workspace, size_t workspace_bytes,
@@ -219,6 +227,63 @@ int dgcnn_embed_max_bwd_prepare(const float *uwin, const float *gg, const float 
                                 void *stream);
 int dgcnn_embed_max_bwd_scatter(const int32_t *arg, const float *s, const float *w, int B, int N, int C, int F,
                                 float *dcat, void *stream);
+
+/* ---- the tail of the head in one call (conv7 .. conv9) --------------------------------------------
+ * Replaces model.py:179-191 on point-major rows, for cat = [x1 | x2 | x3] rows [P = B N][F] (leading dimension ldcat) and
+ * add7 [B][C7] = W7[:, :emb] . g_b, conv7's share of the pooled feature (the repeat / cat of :179-180 never exists):
+ *     u7 = cat . W7c^T + add7[b];  z7 = LReLU(BN7(u7));  u8 = z7 . W8^T;  z8 = LReLU(BN8(u8));
+ *     logits [P][NC] = dropout(z8, p_drop) . W9^T                                    (dropout only when training)
+ * Only u7 and u8 are written: BatchNorm statistics are the products' epilogues, BatchNorm + LeakyReLU (+ dropout) are
+ * applied where the next product loads its operand, and the backward forms every BatchNorm input gradient the same way
+ * (head_fused.hip).  Products on the fp16 matrix cores with split operands, fp32 accumulate: weights scaled per output
+ * channel, gradient operands per 128-row tile, activations per tensor (exact maximum from the column extrema) -- an
+ * operand element is represented to 2^-22 relative (2^-40 of its tile's / row's largest entry where the low half
+ * leaves fp16's normal range).
+ * w7c: conv7.weight[:, emb:] as a [C7][F] view with row stride ldw7; w8 [C8][C7]; w9 [NC][C8].  BatchNorm semantics as
+ * dgcnn_edgeconv_* (num_batches_tracked is the caller's business here).  amax_cat: the dgcnn_rows_absmax word of cat.
+ * Dropout: element (p, k) is kept when dgcnn_dropout_mask says so for (seed, p_drop) -- a counter-based generator, the
+ * backward regenerates the mask from the seed; survivors are scaled by the reciprocal of the realised keep probability
+ * (a multiple of 2^-16).
+ * Limits: F, C7, C8 multiples of 32, C8 <= 1024, NC <= 8, N >= 128, B <= 64, B N < 2^23; 16-byte aligned rows.
+ * saved: opaque, forward -> backward (u7, u8, the statistics, this step's weight planes).  Every gradient is
+ * OVERWRITTEN; all reductions have a fixed association (bit-stable). */
+typedef struct dgcnn_head_tail_desc {
+    int32_t B, N;           /* P = B N rows; add7 row b belongs to rows b N .. b N + N - 1 */
+    int32_t F, C7, C8, NC;  /* 192, 512, 256, classes in the reference */
+    int32_t ldcat, ldw7;
+    int32_t training;       /* 1: batch statistics (+ running update) and dropout; 0: running statistics, no dropout */
+    float eps7, eps8, momentum7, momentum8, slope, p_drop;
+    uint64_t seed;          /* of the dropout mask of this step */
+    const float *w7c;
+    dgcnn_bn_params bn7;    /* [C7] */
+    const float *w8;
+    dgcnn_bn_params bn8;    /* [C8] */
+    const float *w9;
+} dgcnn_head_tail_desc;
+
+typedef struct dgcnn_head_tail_grads {
+    float *gcat;   /* [P][F] rows with leading dimension ldgcat */
+    int64_t ldgcat;
+    float *gadd7;  /* [B][C7] */
+    float *gw7c;   /* [C7][F] dense */
+    float *gbn7_w, *gbn7_b;
+    float *gw8;    /* [C8][C7] */
+    float *gbn8_w, *gbn8_b;
+    float *gw9;    /* [NC][C8] */
+} dgcnn_head_tail_grads;
+
+size_t dgcnn_head_tail_saved_bytes(const dgcnn_head_tail_desc *d);
+size_t dgcnn_head_tail_fwd_workspace_bytes(const dgcnn_head_tail_desc *d);
+size_t dgcnn_head_tail_bwd_workspace_bytes(const dgcnn_head_tail_desc *d);
+int dgcnn_head_tail_fwd(const dgcnn_head_tail_desc *d, const float *cat, const uint32_t *amax_cat, const float *add7,
+                        float *logits, void *saved, void *workspace, size_t workspace_bytes, void *stream);
+/* glogits: dL/dlogits [P][NC] */
+int dgcnn_head_tail_bwd(const dgcnn_head_tail_desc *d, const float *cat, const uint32_t *amax_cat, const float *glogits,
+                        const void *saved, const dgcnn_head_tail_grads *g, void *workspace, size_t workspace_bytes,
+                        void *stream);
+/* mask [P][K] (K a multiple of 4) <- 1 where dropout keeps the element, 0 where it drops it: the generator of
+ * dgcnn_head_tail_* (tests; a caller that wants the mask of a step). */
+int dgcnn_dropout_mask(uint64_t seed, int P, int K, float p_drop, uint8_t *mask, void *stream);
 
 /* ---- the steps either side of DGCNN.forward in the reference's loops ("next") -------
  * Logits are addressed by element strides, (b, c, n) at b*stride_b + c*stride_c + n*stride_n, so both the

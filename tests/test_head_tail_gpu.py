@@ -1,0 +1,205 @@
+"""The tail of the head as one forward and one backward call (dgcnn_head_tail_*, head_fused.hip; reference
+model.py:179-191: conv7 -> bn7 -> LeakyReLU -> conv8 -> bn8 -> LeakyReLU -> dropout -> conv9) against the same operator
+sequence in float64 on the CPU: logits within 1e-4 (north_star's tolerance), gradients within 1e-4 of each tensor's
+largest entry, running statistics updated as nn.BatchNorm1d does, bit-stable from run to run."""
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+SLOPE = 0.2
+
+
+def make_layers(seed, F_=192, C7=512, C8=256, NC=5, emb=1024):
+    g = torch.Generator().manual_seed(seed)
+    w7 = torch.randn(C7, emb + F_, generator=g) / (emb + F_) ** 0.5
+    w8 = torch.randn(C8, C7, generator=g) / C7 ** 0.5
+    w9 = torch.randn(NC, C8, generator=g) / C8 ** 0.5
+    bn7, bn8 = nn.BatchNorm1d(C7), nn.BatchNorm1d(C8)
+    for bn in (bn7, bn8):
+        with torch.no_grad():
+            gam = torch.rand(bn.num_features, generator=g) * 0.9 + 0.2             # |gamma| in [0.2, 1.1], a quarter negative
+            bn.weight.copy_(torch.where(torch.rand(bn.num_features, generator=g) < 0.25, -gam, gam))
+            bn.bias.copy_(torch.randn(bn.num_features, generator=g) * 0.3)
+            bn.running_mean.copy_(torch.randn(bn.num_features, generator=g) * 0.2)
+            bn.running_var.copy_(torch.rand(bn.num_features, generator=g) + 0.5)
+    return w7, w8, w9, bn7, bn8
+
+
+NEAR = 2e-6   # |pre-activation| below which fp32 and fp64 may take different sides of LeakyReLU (fp32's own error is ~1e-6)
+
+
+def reference(cat, add7, w7c, w8, w9, bn7, bn8, B, N, training, mask, inv_keep):
+    """float64, the reference's operator sequence on rows; returns logits, the biased batch statistics and the
+    pre-activations (u7 with its gradient retained, v7, v8)"""
+    def bn(u, m):
+        if training:
+            mean, var = u.mean(0), u.var(0, unbiased=False)
+        else:
+            mean, var = m.running_mean.double(), m.running_var.double()
+        return (u - mean) / torch.sqrt(var + m.eps) * m.weight.double() + m.bias.double(), mean, var
+    u7 = cat @ w7c.t() + add7.repeat_interleave(N, 0)
+    if u7.requires_grad:
+        u7.retain_grad()
+    v7, m7, s7 = bn(u7, bn7)
+    z7 = F.leaky_relu(v7, SLOPE)
+    u8 = z7 @ w8.t()
+    v8, m8, s8 = bn(u8, bn8)
+    z8 = F.leaky_relu(v8, SLOPE)
+    d = z8 * mask * inv_keep if mask is not None else z8
+    return d @ w9.t(), (m7, s7, m8, s8), (u7, v7, v8)
+
+
+def run_case(B, N, training, p_drop, seed=0, NC=5, cat_scale=1.0, cat_shift=0.0, tol=1e-4, strict=True):
+    """strict: a seed is used only if no pre-activation of the float64 evaluation lies within NEAR of zero -- the
+    derivative of LeakyReLU is discontinuous there and fp32 (either implementation) may take the other side, which moves
+    that point's gradients by O(1); the seed is advanced until the case is free of such near-ties (small cases only).
+    not strict (large cases, where near-ties cannot be avoided): gradients in relative L2, which one flipped derivative
+    among P x C moves by about 1 / sqrt(P)."""
+    from ahn3_dgcnn_pytorch_amd import ops
+    import copy
+    dev = torch.device("cuda:0")
+    P = B * N
+    for attempt in range(200):
+        w7, w8, w9, bn7, bn8 = make_layers(seed, NC=NC)
+        g = torch.Generator().manual_seed(100 + seed)
+        cat = torch.randn(P, 192, generator=g) * cat_scale + cat_shift
+        add7 = torch.randn(B, 512, generator=g)
+        cot = torch.randn(P, NC, generator=g)
+        bn7.train(training), bn8.train(training)
+        mask, inv_keep = None, 1.0
+        if training and p_drop > 0:   # the mask head_tail_rows will use: its seed is the next draw of torch's CPU generator
+            torch.manual_seed(1234 + seed)
+            sd = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64))
+            mask = ops.dropout_mask(sd, P, 256, p_drop, dev).cpu().double()
+            keep16 = int((1.0 - p_drop) * 65536.0 + 0.5)
+            inv_keep = 65536.0 / keep16
+            assert abs(mask.mean().item() - (1.0 - p_drop)) < 0.01
+        # float64 reference
+        rl = [t.double().requires_grad_(True) for t in (cat, add7, w7, w8, w9)]
+        rcat, radd, rw7, rw8, rw9 = rl
+        rb7, rb8 = copy.deepcopy(bn7).double(), copy.deepcopy(bn8).double()
+        for m in (rb7, rb8):
+            m.weight.requires_grad_(True), m.bias.requires_grad_(True)
+        want, (m7, s7, m8, s8), (u7, v7, v8) = reference(rcat, radd, rw7[:, 1024:], rw8, rw9, rb7, rb8, B, N, training, mask, inv_keep)
+        near = int((v7.detach().abs() < NEAR).sum() + (v8.detach().abs() < NEAR).sum())
+        if near == 0 or not strict:
+            break
+        seed += 1000
+    else:
+        raise AssertionError("no seed without near-ties found")
+    (want * cot.double()).sum().backward()
+
+    # HIP path
+    dbn7, dbn8 = copy.deepcopy(bn7).to(dev), copy.deepcopy(bn8).to(dev)
+    leaves = [t.to(dev).requires_grad_(True) for t in (cat, add7, w7, w8, w9)]
+    dcat, dadd, dw7, dw8, dw9 = leaves
+    torch.manual_seed(1234 + seed)
+    y = ops.head_tail_rows(dcat, dadd, dw7[:, 1024:], dbn7, dw8, dbn8, dw9, B, N, training, SLOPE, p_drop)
+    (y * cot.to(dev)).sum().backward()
+    torch.cuda.synchronize()
+
+    err = (y.detach().cpu().double() - want.detach()).abs().max().item()
+    assert err < tol, "logits differ by %g" % err
+
+    def close(got, ref, name, floor=0.0):
+        ref = ref.detach()
+        diff = got.detach().cpu().double() - ref
+        if strict:
+            e = diff.abs().max().item() / max(ref.abs().max().item(), floor, 1e-30)
+            assert e < tol, "%s: relative error %g" % (name, e)
+        else:
+            e = diff.norm().item() / max(ref.norm().item(), floor, 1e-30)
+            assert e < tol + 2.0 * (1 + near) / P ** 0.5, "%s: relative L2 error %g (%d near-ties)" % (name, e, near)
+    close(dcat.grad, rcat.grad, "dcat")
+    # (B = 1 in training mode: the true gradient of the added row is zero -- the BatchNorm input gradients of a column sum
+    # to zero -- so the error is measured against the magnitude of what is summed)
+    close(dadd.grad, radd.grad, "dadd7", floor=1e-3 * u7.grad.abs().sum(0).max().item())
+    close(dw7.grad[:, 1024:], rw7.grad[:, 1024:], "dW7c")
+    assert float(dw7.grad[:, :1024].abs().max()) == 0.0
+    close(dw8.grad, rw8.grad, "dW8")
+    close(dw9.grad, rw9.grad, "dW9")
+    close(dbn7.weight.grad, rb7.weight.grad, "dgamma7")
+    close(dbn7.bias.grad, rb7.bias.grad, "dbeta7")
+    close(dbn8.weight.grad, rb8.weight.grad, "dgamma8")
+    close(dbn8.bias.grad, rb8.bias.grad, "dbeta8")
+    if training:   # running statistics: momentum 0.1, unbiased variance (nn.BatchNorm1d's rule)
+        for dm, m, mean, var in ((dbn7, bn7, m7, s7), (dbn8, bn8, m8, s8)):
+            want_rm = 0.9 * m.running_mean.double() + 0.1 * mean.detach()
+            want_rv = 0.9 * m.running_var.double() + 0.1 * var.detach() * P / (P - 1)
+            assert (dm.running_mean.cpu().double() - want_rm).abs().max().item() < 1e-5 * max(1.0, want_rm.abs().max().item())
+            assert (dm.running_var.cpu().double() - want_rv).abs().max().item() < 1e-5 * max(1.0, want_rv.abs().max().item())
+            assert int(dm.num_batches_tracked) == 1
+    return y, [t.grad for t in leaves]
+
+
+@pytest.mark.parametrize("B,N", [(2, 256), (3, 160), (1, 700), (5, 129)])
+def test_head_tail_train_matches_float64(B, N):
+    run_case(B, N, True, 0.0, seed=B)
+
+
+@pytest.mark.parametrize("B,N", [(2, 300), (1, 128)])
+def test_head_tail_eval_matches_float64(B, N):
+    run_case(B, N, False, 0.5, seed=7)   # eval: no dropout whatever p says
+
+
+def test_head_tail_dropout_mask_is_the_documented_generator():
+    run_case(3, 257, True, 0.5, seed=11)
+    run_case(2, 200, True, 0.25, seed=12)
+
+
+def test_head_tail_other_class_counts():
+    run_case(2, 150, True, 0.0, seed=3, NC=2)
+    run_case(2, 150, True, 0.5, seed=4, NC=8)
+
+
+def test_head_tail_offset_and_small_inputs():
+    # features far from zero (|mean| >> sigma) and tiny features: the statistics are fp64 sums, the scales exact powers of two
+    run_case(2, 300, True, 0.0, seed=5, cat_shift=40.0)
+    run_case(2, 300, True, 0.0, seed=6, cat_scale=1e-3)
+
+
+def test_head_tail_gradient_rows_of_very_different_size():
+    # dL/dlogits rows spanning sixteen orders of magnitude between points (well- against mis-classified points): every
+    # 128-row tile of a gradient operand has its own scale, so the small rows keep their relative accuracy -- checked row
+    # by row on dL/dcat
+    from ahn3_dgcnn_pytorch_amd import ops
+    import copy
+    dev = torch.device("cuda:0")
+    B, N = 2, 1024
+    P = B * N
+    w7, w8, w9, bn7, bn8 = make_layers(21)
+    g = torch.Generator().manual_seed(22)
+    cat, add7, cot = torch.randn(P, 192, generator=g), torch.randn(B, 512, generator=g), torch.randn(P, 5, generator=g)
+    rows = torch.ones(P)
+    rows[256:384] = 1e-8
+    rows[1024:1152] = 1e8
+    cot = cot * rows.unsqueeze(1)
+    bn7.eval(), bn8.eval()   # eval: no batch coupling, so a row's gradient depends on its own cotangent only
+    dcat = cat.to(dev).requires_grad_(True)
+    y = ops.head_tail_rows(dcat, add7.to(dev), w7.to(dev)[:, 1024:], copy.deepcopy(bn7).to(dev), w8.to(dev),
+                           copy.deepcopy(bn8).to(dev), w9.to(dev), B, N, False, SLOPE, 0.0)
+    (y * cot.to(dev)).sum().backward()
+    rcat = cat.double().requires_grad_(True)
+    want, _, (_, v7, v8) = reference(rcat, add7.double(), w7.double()[:, 1024:], w8.double(), w9.double(), bn7.double(),
+                                     bn8.double(), B, N, False, None, 1.0)
+    (want * cot.double()).sum().backward()
+    got, ref = dcat.grad.cpu().double(), rcat.grad
+    rel = (got - ref).abs().amax(1) / ref.abs().amax(1)
+    clean = ((v7.detach().abs() < NEAR).sum(1) + (v8.detach().abs() < NEAR).sum(1)) == 0   # rows without a LeakyReLU near-tie
+    assert clean.sum().item() > P - 40
+    assert rel[clean].max().item() < 1e-4, rel[clean].max().item()
+
+
+def test_head_tail_is_bit_stable():
+    a, ga = run_case(2, 500, True, 0.5, seed=9, strict=False)
+    b, gb = run_case(2, 500, True, 0.5, seed=9, strict=False)
+    assert torch.equal(a, b)
+    for x, y in zip(ga, gb):
+        assert torch.equal(x, y)
+
+
+def test_head_tail_at_the_benchmark_size():
+    run_case(8, 7000, True, 0.5, seed=13, strict=False)
