@@ -106,6 +106,14 @@ SIGNATURES = {
     "dgcnn_head_tail_fwd": (_c_int, [_c_ht_p, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp]),
     "dgcnn_head_tail_bwd": (_c_int, [_c_ht_p, _c_vp, _c_vp, _c_vp, _c_vp, ctypes.POINTER(HeadTailGrads), _c_vp, _c_sz, _c_vp]),
     "dgcnn_dropout_mask": (_c_int, [ctypes.c_uint64, _c_int, _c_int, _c_f, _c_vp, _c_vp]),
+    "dgcnn_comm_rccl_version": (_c_int, []),
+    "dgcnn_comm_unique_id": (_c_int, [_c_vp]),
+    "dgcnn_comm_init": (_c_int, [ctypes.POINTER(_c_vp), _c_vp, _c_int, _c_int]),
+    "dgcnn_comm_destroy": (_c_int, [_c_vp]),
+    "dgcnn_comm_world": (_c_int, [_c_vp]),
+    "dgcnn_comm_rank": (_c_int, [_c_vp]),
+    "dgcnn_comm_allreduce_f32": (_c_int, [_c_vp, _c_vp, _c_sz, _c_int, _c_vp]),
+    "dgcnn_comm_broadcast_f32": (_c_int, [_c_vp, _c_vp, _c_sz, _c_int, _c_vp]),
     "dgcnn_seg_loss_workspace_bytes": (_c_sz, [_c_int, _c_int]),
     "dgcnn_seg_loss": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_i64, _c_i64, _c_i64, _c_vp, _c_vp, _c_f, _c_vp, _c_vp,
                                 _c_vp, _c_vp, _c_sz, _c_vp]),

@@ -139,42 +139,52 @@ __device__ __forceinline__ void store_w(const WRegs &r, _Float16 (*wh)[GSTR], _F
         *reinterpret_cast<u32x4 *>(&wl[row][pc]) = r.l[j];
     }
 }
-struct KConst {
-    float4 c[5];
-};
-template <int XMODE>
-__device__ __forceinline__ void load_kconst(const HGemmArgs &a, int k0, KConst &kc)
-{
-    const int c = (threadIdx.x & 7) * 4;
-    constexpr int n = XMODE == X_BN ? 2 : (XMODE == X_DU ? 5 : 0);
-#pragma unroll
-    for (int i = 0; i < n; ++i) kc.c[i] = *reinterpret_cast<const float4 *>(a.pc[i] + k0 + c);
-}
 __device__ __forceinline__ float f4(const float4 &v, int e) { return e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w)); }
 
-// BatchNorm input gradient at one element:  du = sc (dv - c1 - c2 uhat),  uhat = (u - mean) rstd
-__device__ __forceinline__ float du_of(float dv, float u, float mean, float rstd, float sc, float c1, float c2)
+// Prologue constants per k, folded with the operand's power-of-two scale sx (exact) and kept in LDS for the whole kernel:
+//   X_BN:  xeff sx = LReLU(x (sc sx) + sh sx)                                      kt[0] = sc sx, kt[1] = sh sx
+//   X_DU:  du sx = sc sx (dv - c1 - c2 rstd (u - mean)) = A dv + (Bc u + Cc)      kt[0] = A = sc sx, kt[1] = Bc = -A c2 rstd,
+//                                                                                 kt[2] = Cc = A (c2 rstd mean - c1)
+//          (two fused multiply-adds per element; Bc u + Cc cancels where |mean| >> sigma, at an error of 6e-8 |mean| / sigma
+//          relative to the c2 term -- the correction of the gradient by its projection on uhat -- which itself is O(1) of dv)
+constexpr int KT_MAX = 1024;
+template <int XMODE>
+__device__ __forceinline__ void fill_ktable(const HGemmArgs &a, float sx, float (*kt)[KT_MAX])
 {
-    const float uh = (u - mean) * rstd;
-    return sc * __builtin_fmaf(-c2, uh, dv - c1);
+    for (int k = threadIdx.x; k < a.K; k += 256) {
+        if (XMODE == X_BN) {
+            kt[0][k] = a.pc[0][k] * sx;
+            kt[1][k] = a.pc[1][k] * sx;
+        } else if (XMODE == X_DU) {
+            const float mean = a.pc[0][k], rstd = a.pc[1][k], A = a.pc[2][k] * sx, c1 = a.pc[3][k], c2 = a.pc[4][k];
+            kt[0][k] = A;
+            kt[1][k] = -A * c2 * rstd;
+            kt[2][k] = A * __builtin_fmaf(c2 * rstd, mean, -c1);
+        }
+    }
 }
 
 template <int XMODE>
-__device__ __forceinline__ void store_x(const XRegs &r, const XRegs &r2, const KConst &kc, float sx, float slope,
+__device__ __forceinline__ void store_x(const XRegs &r, const XRegs &r2, const float (*kt)[KT_MAX], int k0, float sx, float slope,
                                         _Float16 (*xh)[GSTR], _Float16 (*xl)[GSTR])
 {
+    const int c = (threadIdx.x & 7) * 4;  // the thread's four k of the chunk: the same in every one of its rows
+    float4 q0, q1, q2;
+    if (XMODE != X_RAW) {
+        q0 = *reinterpret_cast<const float4 *>(&kt[0][k0 + c]);
+        q1 = *reinterpret_cast<const float4 *>(&kt[1][k0 + c]);
+        if (XMODE == X_DU) q2 = *reinterpret_cast<const float4 *>(&kt[2][k0 + c]);
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int f = threadIdx.x + 256 * i, row = f >> 3, c = (f & 7) * 4;
+        const int f = threadIdx.x + 256 * i, row = f >> 3;
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float x = f4(r.v[i], e);
-            float y;
-            if (XMODE == X_RAW) y = x;
-            else if (XMODE == X_BN) y = lrelu_f(__builtin_fmaf(x, f4(kc.c[0], e), f4(kc.c[1], e)), slope);
-            else y = du_of(x, f4(r2.v[i], e), f4(kc.c[0], e), f4(kc.c[1], e), f4(kc.c[2], e), f4(kc.c[3], e), f4(kc.c[4], e));
-            v[e] = y * sx;
+            if (XMODE == X_RAW) v[e] = x * sx;
+            else if (XMODE == X_BN) v[e] = lrelu_f(__builtin_fmaf(x, f4(q0, e), f4(q1, e)), slope);
+            else v[e] = __builtin_fmaf(f4(q0, e), x, __builtin_fmaf(f4(q1, e), f4(r2.v[i], e), f4(q2, e)));
         }
         u32x2 h, l;
         split4(v, h, l);
@@ -183,11 +193,15 @@ __device__ __forceinline__ void store_x(const XRegs &r, const XRegs &r2, const K
     }
 }
 
-template <int XMODE, int EMODE>
-__global__ __launch_bounds__(256) void hgemm_kernel(const HGemmArgs a)
+constexpr int EST = 68;  // floats per row of the epilogue's LDS image of 64 accumulator columns (272 bytes: 16-byte aligned rows)
+
+template <int XMODE, int EMODE, int OCC>
+__global__ __launch_bounds__(256, OCC) void hgemm_kernel(const HGemmArgs a)
 {
-    __shared__ __attribute__((aligned(16))) _Float16 lds[4][GM][GSTR];  // one block: the epilogues reuse it as scratch
-    static_assert(GM == GN && sizeof(lds) >= 4 * 2 * 3 * GN * sizeof(double), "epilogue scratch fits the staging area");
+    __shared__ __attribute__((aligned(16))) _Float16 lds[4][GM][GSTR];  // one block: the epilogue reuses it
+    __shared__ __attribute__((aligned(16))) float kt[XMODE == X_RAW ? 1 : (XMODE == X_BN ? 2 : 3)][XMODE == X_RAW ? 4 : KT_MAX];
+    static_assert(GM == GN && sizeof(lds) >= 4 * 32 * EST * sizeof(float) && sizeof(lds) >= 4 * 2 * 3 * GN * sizeof(double),
+                  "epilogue images fit the staging area");
     _Float16(*xh)[GSTR] = lds[0], (*xl)[GSTR] = lds[1], (*wh)[GSTR] = lds[2], (*wl)[GSTR] = lds[3];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, i32 = lane & 31;
     const int cb = (int)blockIdx.x % a.ncb, rb = (int)blockIdx.x / a.ncb;  // column blocks of a row block are neighbours
@@ -200,6 +214,7 @@ __global__ __launch_bounds__(256) void hgemm_kernel(const HGemmArgs a)
         xbound = __uint_as_float(*a.xmax);
     const float sx = pow2_scale(xbound, H_TOP);
     if (EMODE == E_STATS && blockIdx.x == 0 && threadIdx.x == 0 && a.zero) *a.zero = 0u;
+    if (XMODE != X_RAW) fill_ktable<XMODE>(a, sx, reinterpret_cast<float(*)[KT_MAX]>(kt));  // (visible behind the loop's first barrier)
 
     f32x16 acc[4];
 #pragma unroll
@@ -209,20 +224,17 @@ __global__ __launch_bounds__(256) void hgemm_kernel(const HGemmArgs a)
 
     XRegs rx, rx2;
     WRegs rw;
-    KConst kc;
     load_x(a.X, a.ldx, row0, P, 0, rx);
     if (XMODE == X_DU) load_x(a.X2, a.ldx2, row0, P, 0, rx2);
-    load_kconst<XMODE>(a, 0, kc);
     load_w(a.Wh, a.Wl, K, col0, N, 0, rw);
     for (int k0 = 0; k0 < K; k0 += GK) {
         __syncthreads();  // the previous chunk's LDS reads are done
-        store_x<XMODE>(rx, rx2, kc, sx, a.slope, xh, xl);
+        store_x<XMODE>(rx, rx2, reinterpret_cast<const float(*)[KT_MAX]>(kt), k0, sx, a.slope, xh, xl);
         store_w(rw, wh, wl);
         __syncthreads();
         if (k0 + GK < K) {  // next chunk in flight during the MFMAs
             load_x(a.X, a.ldx, row0, P, k0 + GK, rx);
             if (XMODE == X_DU) load_x(a.X2, a.ldx2, row0, P, k0 + GK, rx2);
-            load_kconst<XMODE>(a, k0 + GK, kc);
             load_w(a.Wh, a.Wl, K, col0, N, k0 + GK, rw);
         }
 #pragma unroll
@@ -238,60 +250,152 @@ __global__ __launch_bounds__(256) void hgemm_kernel(const HGemmArgs a)
         }
     }
 
-    // ---- epilogue: lane (n, h) holds column nt 32 + n, rows mfma32_row(r, h) (ascending in r) of this wave's 32 rows
+    // ---- epilogue through LDS: the wave's 32 x 128 accumulator tile goes, 64 columns at a time, from the MFMA layout (lane =
+    // column) to rows -- lane (lr, lc) holds columns lc .. lc + 3 of rows lr, lr + 4, .., lr + 28 -- so that Y, U and add move
+    // in 16-byte pieces of whole 256-byte row segments
+    __syncthreads();  // every wave is done with the staging area
+    float *wbuf = reinterpret_cast<float *>(&lds[0][0][0]) + wave * (32 * EST);
+    const int lr = lane >> 4, lc = (lane & 15) * 4;
     const float isx = 1.0f / sx;
-    if (EMODE == E_PLAIN) {
+    const int wrow0 = row0 + wave * 32;
+    const int nvalid = P - wrow0 < 0 ? 0 : (P - wrow0 > 32 ? 32 : P - wrow0);  // rows of this wave inside the matrix
+    // the tile spans at most two batch elements (rows_per_batch >= GM): rows >= rsplit belong to the second
+    const int b0 = (EMODE == E_DV || a.add) ? row0 / a.rows_per_batch : 0;
+    const int rsplit = (EMODE == E_DV || a.add) ? (b0 + 1) * a.rows_per_batch : 0x7fffffff;
+    // per-lane results of the two 64-column halves, kept until the staging area is free for the cross-wave step
+    double st_sum[2][4], st_sq[2][4];  // E_STATS
+    float st_mn[2][4], st_mx[2][4];
+    float dvs[2][4][6];                // E_DV: [half][column][slot 0: dv, dv uhat, uhat; slot 1: the same]
+    float amax_dv = 0.0f, amax_uh = 0.0f;
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const int col = col0 + nt * 32 + i32;
-            if (col < N) {
-                const float un = isx / a.wscale[col];
+    for (int half = 0; half < 2; ++half) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = row0 + wave * 32 + mfma32_row(r, h);
-                    if (row < P) {
-                        float v = acc[nt][r] * un;
-                        if (a.add) v += a.add[(size_t)(row / a.rows_per_batch) * N + col];
-                        a.Y[(size_t)row * a.ldy + col] = v;
+        for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) wbuf[mfma32_row(r, h) * EST + n2 * 32 + i32] = acc[2 * half + n2][r];
+        __builtin_amdgcn_wave_barrier();
+        const int cbase = col0 + half * 64 + lc;
+        const bool cv = cbase < N;  // (N is a multiple of 4: the lane's four columns are inside or outside together)
+        const int cc = cv ? cbase : 0;
+        const float4 ws4 = *reinterpret_cast<const float4 *>(a.wscale + cc);
+        const float un[4] = {isx / ws4.x, isx / ws4.y, isx / ws4.z, isx / ws4.w};
+        float4 ad0 = float4{0.0f, 0.0f, 0.0f, 0.0f}, ad1 = ad0;
+        if (EMODE != E_DV && a.add) {
+            ad0 = *reinterpret_cast<const float4 *>(a.add + (size_t)b0 * N + cc);
+            // (the second batch element's row only where the tile really reaches into it: past the last batch element
+            // there is no such row to read)
+            ad1 = *reinterpret_cast<const float4 *>(a.add + (size_t)(wrow0 + 31 >= rsplit && rsplit < P ? b0 + 1 : b0) * N + cc);
+        }
+        float4 e_mean, e_rstd, e_sc, e_sh;
+        if (EMODE == E_DV) {
+            e_mean = *reinterpret_cast<const float4 *>(a.ec[0] + cc);
+            e_rstd = *reinterpret_cast<const float4 *>(a.ec[1] + cc);
+            e_sc = *reinterpret_cast<const float4 *>(a.ec[2] + cc);
+            e_sh = *reinterpret_cast<const float4 *>(a.ec[3] + cc);
+        }
+        float4 uv[4];  // (the rows of U, four at a time: eight in flight cost the kernel a workgroup per CU in registers)
+        float S1[4] = {0.0f, 0.0f, 0.0f, 0.0f}, S2[4] = {0.0f, 0.0f, 0.0f, 0.0f}, cshift[4];
+        float mn[4], mx[4];
+        float ds[4][6];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            mn[e] = __builtin_inff();
+            mx[e] = -__builtin_inff();
+#pragma unroll
+            for (int q = 0; q < 6; ++q) ds[e][q] = 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (EMODE == E_DV && (i & 3) == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int rj = wrow0 + lr + 4 * (i + j);
+                    uv[j] = *reinterpret_cast<const float4 *>(a.U + (size_t)(rj < P ? rj : P - 1) * a.ldu + cc);
+                }
+            }
+            const int row = wrow0 + lr + 4 * i;
+            const bool on = cv && row < P;
+            const float4 t4 = *reinterpret_cast<const float4 *>(&wbuf[(lr + 4 * i) * EST + lc]);
+            float o[4];
+            const bool second = row >= rsplit;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float g = f4(t4, e) * un[e];
+                if (EMODE == E_DV) {
+                    const float u = f4(uv[i & 3], e);
+                    const float dv = __builtin_fmaf(u, f4(e_sc, e), f4(e_sh, e)) > 0.0f ? g : g * a.slope;
+                    const float uh = (u - f4(e_mean, e)) * f4(e_rstd, e);
+                    o[e] = dv;
+                    const float dvm = on ? dv : 0.0f, uhm = on ? uh : 0.0f;
+                    ds[e][0] += second ? 0.0f : dvm;
+                    ds[e][1] = __builtin_fmaf(second ? 0.0f : dvm, uhm, ds[e][1]);
+                    ds[e][2] += second ? 0.0f : uhm;
+                    ds[e][3] += second ? dvm : 0.0f;
+                    ds[e][4] = __builtin_fmaf(second ? dvm : 0.0f, uhm, ds[e][4]);
+                    ds[e][5] += second ? uhm : 0.0f;
+                    amax_dv = fmaxf(amax_dv, fabsf(dvm));
+                    amax_uh = fmaxf(amax_uh, fabsf(uhm));
+                } else {
+                    const float v = g + (second ? f4(ad1, e) : f4(ad0, e));
+                    o[e] = v;
+                    if (EMODE == E_STATS) {
+                        // sums shifted by the value of the wave's first row (fp32 is enough for sum (v - c), sum (v - c)^2
+                        // over 32 rows whatever the column's mean is; the shift is undone in fp64 below)
+                        if (i == 0) cshift[e] = __shfl(v, lane & 15);
+                        const float d = on ? v - cshift[e] : 0.0f;
+                        S1[e] += d;
+                        S2[e] = __builtin_fmaf(d, d, S2[e]);
+                        mn[e] = on ? fminf(mn[e], v) : mn[e];
+                        mx[e] = on ? fmaxf(mx[e], v) : mx[e];
                     }
                 }
             }
+            if (on) *reinterpret_cast<float4 *>(a.Y + (size_t)row * a.ldy + cbase) = float4{o[0], o[1], o[2], o[3]};
         }
-    } else if (EMODE == E_STATS) {
-        __syncthreads();  // the staging area becomes the scratch of the column reductions
-        double(*csum)[2][GN] = reinterpret_cast<double(*)[2][GN]>(&lds[0][0][0]);                         // [4][2][GN]
-        float(*cext)[2][GN] = reinterpret_cast<float(*)[2][GN]>(reinterpret_cast<char *>(&lds[0][0][0]) + 4 * 2 * GN * 8);  // [4][2][GN] behind it
+        // fold the four row groups of the wave (lanes lr = 0 .. 3 of a column group): lanes with lr == 0 end up with the sums
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const int cl = nt * 32 + i32, col = col0 + cl;
-            const bool cv = col < N;
-            const float un = cv ? isx / a.wscale[col] : 0.0f;
-            // (fp64 from the first addition on: the variance is sum v^2 / P - mean^2, and with |mean| >> sigma an fp32 partial
-            // sum of squares over even 16 rows costs the difference its digits)
-            double s1 = 0.0, s2 = 0.0;
-            float mn = __builtin_inff(), mx = -__builtin_inff();
+        for (int e = 0; e < 4; ++e) {
+            if (EMODE == E_STATS) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = row0 + wave * 32 + mfma32_row(r, h);
-                if (row < P && cv) {
-                    float v = acc[nt][r] * un;
-                    if (a.add) v += a.add[(size_t)(row / a.rows_per_batch) * N + col];
-                    a.Y[(size_t)row * a.ldy + col] = v;
-                    s1 += (double)v;
-                    s2 = __builtin_fma((double)v, (double)v, s2);
-                    mn = fminf(mn, v);
-                    mx = fmaxf(mx, v);
+                for (int o_ = 16; o_ <= 32; o_ <<= 1) {
+                    S1[e] += __shfl_xor(S1[e], o_);
+                    S2[e] += __shfl_xor(S2[e], o_);
+                    mn[e] = fminf(mn[e], __shfl_xor(mn[e], o_));
+                    mx[e] = fmaxf(mx[e], __shfl_xor(mx[e], o_));
+                }
+                const double c = (double)cshift[e], n = (double)nvalid;
+                st_sum[half][e] = nvalid ? (double)S1[e] + n * c : 0.0;
+                st_sq[half][e] = nvalid ? (double)S2[e] + 2.0 * c * (double)S1[e] + n * c * c : 0.0;
+                st_mn[half][e] = mn[e];
+                st_mx[half][e] = mx[e];
+            } else if (EMODE == E_DV) {
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    float v = ds[e][q];
+                    v += __shfl_xor(v, 16);
+                    v += __shfl_xor(v, 32);
+                    dvs[half][e][q] = v;
                 }
             }
-            const double d1 = s1 + __shfl_xor(s1, 32), d2 = s2 + __shfl_xor(s2, 32);
-            mn = fminf(mn, __shfl_xor(mn, 32));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            if (h == 0) {
-                csum[wave][0][cl] = d1;
-                csum[wave][1][cl] = d2;
-                cext[wave][0][cl] = mn;
-                cext[wave][1][cl] = mx;
-            }
+        }
+        __builtin_amdgcn_wave_barrier();  // the image is read: the next half may overwrite it
+    }
+    if (EMODE == E_PLAIN) return;
+    __syncthreads();  // all images are consumed: the staging area becomes the scratch of the cross-wave step
+    if (EMODE == E_STATS) {
+        double(*csum)[2][GN] = reinterpret_cast<double(*)[2][GN]>(&lds[0][0][0]);                                            // [4][2][GN]
+        float(*cext)[2][GN] = reinterpret_cast<float(*)[2][GN]>(reinterpret_cast<char *>(&lds[0][0][0]) + 4 * 2 * GN * 8);  // [4][2][GN]
+        if (lr == 0) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int cl = half * 64 + lc + e;
+                    csum[wave][0][cl] = st_sum[half][e];
+                    csum[wave][1][cl] = st_sq[half][e];
+                    cext[wave][0][cl] = st_mn[half][e];
+                    cext[wave][1][cl] = st_mx[half][e];
+                }
         }
         __syncthreads();
         if (threadIdx.x < GN && col0 + (int)threadIdx.x < N) {
@@ -304,43 +408,18 @@ __global__ __launch_bounds__(256) void hgemm_kernel(const HGemmArgs a)
             a.pext[((size_t)rb * 2 + 1) * N + col0 + cl] = fmaxf(fmaxf(cext[0][1][cl], cext[1][1][cl]), fmaxf(cext[2][1][cl], cext[3][1][cl]));
         }
     } else {  // E_DV
-        __syncthreads();
         double(*cdv)[2][3][GN] = reinterpret_cast<double(*)[2][3][GN]>(&lds[0][0][0]);  // [4][2][3][GN]
         __shared__ float smax[4][2];
-        // rows of the tile's second batch-element slot start at rsplit (the tile spans at most two: rows_per_batch >= GM)
-        const int rsplit = (row0 / a.rows_per_batch + 1) * a.rows_per_batch;
-        float amax_dv = 0.0f, amax_uh = 0.0f;
+        if (lr == 0) {
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const int cl = nt * 32 + i32, col = col0 + cl;
-            const bool cv = col < N;
-            const float un = cv ? isx / a.wscale[col] : 0.0f;
-            const float mean = cv ? a.ec[0][col] : 0.0f, rstd = cv ? a.ec[1][col] : 0.0f, sc = cv ? a.ec[2][col] : 0.0f,
-                        sh = cv ? a.ec[3][col] : 0.0f;
-            float s[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
+            for (int half = 0; half < 2; ++half)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = row0 + wave * 32 + mfma32_row(r, h);
-                if (row < P && cv) {
-                    const float u = a.U[(size_t)row * a.ldu + col];
-                    const float g = acc[nt][r] * un;
-                    const float dv = __builtin_fmaf(u, sc, sh) > 0.0f ? g : g * a.slope;
-                    const float uh = (u - mean) * rstd;
-                    a.Y[(size_t)row * a.ldy + col] = dv;
-                    const int sl = row >= rsplit ? 1 : 0;
-                    s[sl][0] += dv;
-                    s[sl][1] = __builtin_fmaf(dv, uh, s[sl][1]);
-                    s[sl][2] += uh;
-                    amax_dv = fmaxf(amax_dv, fabsf(dv));
-                    amax_uh = fmaxf(amax_uh, fabsf(uh));
-                }
-            }
+                for (int e = 0; e < 4; ++e) {
+                    const int cl = half * 64 + lc + e;
 #pragma unroll
-            for (int sl = 0; sl < 2; ++sl)
+                    for (int sl = 0; sl < 2; ++sl)
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    const double d = (double)s[sl][q] + (double)__shfl_xor(s[sl][q], 32);
-                    if (h == 0) cdv[wave][sl][q][cl] = d;
+                        for (int q = 0; q < 3; ++q) cdv[wave][sl][q][cl] = (double)dvs[half][e][sl * 3 + q];
                 }
         }
 #pragma unroll
@@ -420,8 +499,8 @@ __device__ __forceinline__ void wstage_store(const float (&t)[4][4] /* [column][
     }
 }
 
-template <int AMODE, int BMODE>
-__global__ __launch_bounds__(256) void hwgrad_kernel(const HWgradArgs a)
+template <int AMODE, int BMODE, int OCC>
+__global__ __launch_bounds__(256, OCC) void hwgrad_kernel(const HWgradArgs a)
 {
     __shared__ __attribute__((aligned(16))) _Float16 ah[128][WSTR], al[128][WSTR], bh[128][WSTR], bl[128][WSTR];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, i32 = lane & 31;
@@ -442,16 +521,31 @@ __global__ __launch_bounds__(256) void hwgrad_kernel(const HWgradArgs a)
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
     const int cq = threadIdx.x & 31, pq = threadIdx.x >> 5;
 
-    // per-thread column constants (the thread's four columns are the same in every stage)
-    float4 ca[5], cbv[2];
+    // per-thread column constants (the thread's four columns are the same in every stage), folded with the operand scales
+    // as in fill_ktable:  du sa = A dv + (Bc u + Cc);  z sb = LReLU(u (sc sb) + sh sb)
+    float qa[3][4], qb[2][4];
     {
         const int cm = m0 + 4 * cq < M ? m0 + 4 * cq : 0, cn = n0 + 4 * cq < Nn ? n0 + 4 * cq : 0;
-        if (AMODE == A_DU)
+        if (AMODE == A_DU) {
+            const float4 mean = *reinterpret_cast<const float4 *>(a.ac[0] + cm), rstd = *reinterpret_cast<const float4 *>(a.ac[1] + cm);
+            const float4 sc = *reinterpret_cast<const float4 *>(a.ac[2] + cm), c1 = *reinterpret_cast<const float4 *>(a.ac[3] + cm);
+            const float4 c2 = *reinterpret_cast<const float4 *>(a.ac[4] + cm);
 #pragma unroll
-            for (int i = 0; i < 5; ++i) ca[i] = *reinterpret_cast<const float4 *>(a.ac[i] + cm);
-        if (BMODE == B_BN)
+            for (int c = 0; c < 4; ++c) {
+                const float A = f4(sc, c) * sa;
+                qa[0][c] = A;
+                qa[1][c] = -A * f4(c2, c) * f4(rstd, c);
+                qa[2][c] = A * __builtin_fmaf(f4(c2, c) * f4(rstd, c), f4(mean, c), -f4(c1, c));
+            }
+        }
+        if (BMODE == B_BN) {
+            const float4 sc = *reinterpret_cast<const float4 *>(a.bc[0] + cn), sh = *reinterpret_cast<const float4 *>(a.bc[1] + cn);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) cbv[i] = *reinterpret_cast<const float4 *>(a.bc[i] + cn);
+            for (int c = 0; c < 4; ++c) {
+                qb[0][c] = f4(sc, c) * sb;
+                qb[1][c] = f4(sh, c) * sb;
+            }
+        }
     }
 
     f32x16 acc[2][2];
@@ -476,11 +570,11 @@ __global__ __launch_bounds__(256) void hwgrad_kernel(const HWgradArgs a)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     float x = f4(ra.v[i], c);
-                    if (AMODE == A_DU) x = du_of(x, f4(ra2.v[i], c), f4(ca[0], c), f4(ca[1], c), f4(ca[2], c), f4(ca[3], c), f4(ca[4], c));
-                    ta_[c][i] = on ? x * sa : 0.0f;
+                    x = AMODE == A_DU ? __builtin_fmaf(qa[0][c], x, __builtin_fmaf(qa[1][c], f4(ra2.v[i], c), qa[2][c])) : x * sa;
+                    ta_[c][i] = on ? x : 0.0f;
                     float y = f4(rb.v[i], c);
-                    if (BMODE == B_BN) y = lrelu_f(__builtin_fmaf(y, f4(cbv[0], c), f4(cbv[1], c)), a.slope);
-                    tb_[c][i] = on ? y * sb : 0.0f;
+                    y = BMODE == B_BN ? lrelu_f(__builtin_fmaf(y, qb[0][c], qb[1][c]), a.slope) : y * sb;
+                    tb_[c][i] = on ? y : 0.0f;
                 }
             }
             wstage_store(ta_, ah, al);
@@ -1121,6 +1215,12 @@ static int check_desc(const dgcnn_head_tail_desc *d, const char *who, bool param
         default: { constexpr int NCV = 8; CALL; } break; \
     }
 
+// experiments: DGCNN_HF_OCC=3 asks the gradient-operand kernels for three workgroups per CU (168 registers, a few spilled)
+static bool occ3()
+{
+    static const int v = getenv("DGCNN_HF_OCC") ? atoi(getenv("DGCNN_HF_OCC")) : 2;
+    return v == 3;
+}
 static unsigned keep16_of(float p) { return (unsigned)((1.0 - (double)p) * 65536.0 + 0.5); }
 // the survivors' scale: the reciprocal of the keep probability the mask REALISES (a multiple of 2^-16), so that the
 // expectation of dropout(z) is z exactly
@@ -1178,7 +1278,7 @@ extern "C" int dgcnn_head_tail_fwd(const dgcnn_head_tail_desc *d, const float *c
         a.Y = s.u7, a.ldy = C7;
         a.psum = d->training ? w.psum7 : nullptr, a.pext = w.pext7, a.zero = s.zmax;
         a.ncb = ceil_div(C7, GN), a.nrb = nrb;
-        hipLaunchKernelGGL((hgemm_kernel<X_RAW, E_STATS>), dim3(a.ncb * nrb), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((hgemm_kernel<X_RAW, E_STATS, 3>), dim3(a.ncb * nrb), dim3(256), 0, st, a);
         hipLaunchKernelGGL(stats_finalize_kernel, dim3(ceil_div(C7, 64)), dim3(64 * FW), 0, st, w.psum7, w.pext7, nrb, P, C7,
                            d->training, d->bn7.weight, d->bn7.bias, d->bn7.running_mean, d->bn7.running_var, d->eps7,
                            d->momentum7, d->slope, s.stats7, s.zmax);
@@ -1193,7 +1293,7 @@ extern "C" int dgcnn_head_tail_fwd(const dgcnn_head_tail_desc *d, const float *c
         a.Y = s.u8, a.ldy = C8;
         a.psum = d->training ? w.psum8 : nullptr, a.pext = w.pext8, a.zero = s.zmax + 1;
         a.ncb = ceil_div(C8, GN), a.nrb = nrb;
-        hipLaunchKernelGGL((hgemm_kernel<X_BN, E_STATS>), dim3(a.ncb * nrb), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((hgemm_kernel<X_BN, E_STATS, 3>), dim3(a.ncb * nrb), dim3(256), 0, st, a);
         hipLaunchKernelGGL(stats_finalize_kernel, dim3(ceil_div(C8, 64)), dim3(64 * FW), 0, st, w.psum8, w.pext8, nrb, P, C8,
                            d->training, d->bn8.weight, d->bn8.bias, d->bn8.running_mean, d->bn8.running_var, d->eps8,
                            d->momentum8, d->slope, s.stats8, s.zmax + 1);
@@ -1267,7 +1367,8 @@ extern "C" int dgcnn_head_tail_bwd(const dgcnn_head_tail_desc *d, const float *c
         a.ec[0] = mean7, a.ec[1] = rstd7, a.ec[2] = sc7, a.ec[3] = sh7;
         a.pdv = w.pdv7, a.oa = w.oa7, a.ob = w.ob7;
         a.ncb = ceil_div(C7, GN), a.nrb = nrb;
-        hipLaunchKernelGGL((hgemm_kernel<X_DU, E_DV>), dim3(a.ncb * nrb), dim3(256), 0, st, a);
+        if (occ3()) hipLaunchKernelGGL((hgemm_kernel<X_DU, E_DV, 3>), dim3(a.ncb * nrb), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((hgemm_kernel<X_DU, E_DV, 2>), dim3(a.ncb * nrb), dim3(256), 0, st, a);
     }
     {   // dW8 = du8^T z7: both operands formed at the load
         HWgradArgs a{};
@@ -1284,7 +1385,8 @@ extern "C" int dgcnn_head_tail_bwd(const dgcnn_head_tail_desc *d, const float *c
         a.partial = w.wpart;
         const int nch = ceil_div(P, a.chunk);
         const dim3 grid((unsigned)align_up((size_t)ceil_div(C8, 128) * a.ntiles_n * nch, 8));
-        hipLaunchKernelGGL((hwgrad_kernel<A_DU, B_BN>), grid, dim3(256), 0, st, a);
+        if (occ3()) hipLaunchKernelGGL((hwgrad_kernel<A_DU, B_BN, 3>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((hwgrad_kernel<A_DU, B_BN, 2>), grid, dim3(256), 0, st, a);
         launch_sum_partials(w.wpart, nch, C8 * C7, g->gw8, st);
     }
     hipLaunchKernelGGL(bwd_finalize_slots_kernel, dim3(ceil_div(C7, 64)), dim3(64 * FW), 0, st, w.pdv7, nrb, d->B, d->N, C7,
@@ -1298,7 +1400,8 @@ extern "C" int dgcnn_head_tail_bwd(const dgcnn_head_tail_desc *d, const float *c
         a.slope = d->slope;
         a.Y = g->gcat, a.ldy = g->ldgcat;
         a.ncb = ceil_div(F, GN), a.nrb = nrb;
-        hipLaunchKernelGGL((hgemm_kernel<X_DU, E_PLAIN>), dim3(a.ncb * nrb), dim3(256), 0, st, a);
+        if (occ3()) hipLaunchKernelGGL((hgemm_kernel<X_DU, E_PLAIN, 3>), dim3(a.ncb * nrb), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((hgemm_kernel<X_DU, E_PLAIN, 2>), dim3(a.ncb * nrb), dim3(256), 0, st, a);
     }
     {   // dW7c = du7^T cat
         HWgradArgs a{};
@@ -1314,7 +1417,8 @@ extern "C" int dgcnn_head_tail_bwd(const dgcnn_head_tail_desc *d, const float *c
         a.partial = w.wpart;
         const int nch = ceil_div(P, a.chunk);
         const dim3 grid((unsigned)align_up((size_t)ceil_div(C7, 128) * a.ntiles_n * nch, 8));
-        hipLaunchKernelGGL((hwgrad_kernel<A_DU, B_RAW>), grid, dim3(256), 0, st, a);
+        if (occ3()) hipLaunchKernelGGL((hwgrad_kernel<A_DU, B_RAW, 3>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((hwgrad_kernel<A_DU, B_RAW, 2>), grid, dim3(256), 0, st, a);
         launch_sum_partials(w.wpart, nch, C7 * F, g->gw7c, st);
     }
     DG_CHECK_LAUNCH("dgcnn_head_tail_bwd");

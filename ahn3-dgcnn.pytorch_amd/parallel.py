@@ -1,7 +1,8 @@
 """Data-parallel exchange step of the EdgeConv path: one process per GPU, batch elements sharded
 across ranks (they are independent units: kNN, gather and max-over-k never cross a batch element,
-SURVEY.md 8e), and ONE all-reduce per step of a single flat fp32 gradient buffer over
-torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
+SURVEY.md 8e), and ONE all-reduce per step of a single flat fp32 gradient buffer -- over
+torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests) or,
+with a `HipComm`, over the library's own RCCL binding behind the C ABI (dgcnn_comm_*).
 
 The reference has no distributed code at all (train.py:110-111 only prints the device count).
 
@@ -41,6 +42,64 @@ def broadcast(t, src=0, group=None):
     return t
 
 
+class HipComm:
+    """The exchange step behind the C ABI (dgcnn_comm_*, comm.hip): an RCCL communicator of this process's current HIP
+    device, reached without torch.distributed in the data path.  Bootstrap: rank 0 makes the 128-byte id, every rank
+    needs the same bytes -- pass `id_bytes`, or let an initialised torch.distributed group (any backend: it only carries
+    128 bytes once) broadcast them; then every rank constructs its HipComm (a collective call)."""
+
+    def __init__(self, rank, world, id_bytes=None, group=None):
+        import ctypes
+        from . import _lib
+        self._lib, self._libmod = _lib.load(), _lib
+        self.rank, self.world = int(rank), int(world)
+        if id_bytes is None:
+            buf = ctypes.create_string_buffer(128)
+            if self.rank == 0:
+                _lib.check(self._lib.dgcnn_comm_unique_id(buf), "dgcnn_comm_unique_id")
+            box = [bytes(buf.raw)]
+            if self.world > 1:
+                if not (dist.is_available() and dist.is_initialized()):
+                    raise RuntimeError("HipComm: pass id_bytes (rank 0's dgcnn_comm_unique_id) or initialise torch.distributed "
+                                       "so that it can be broadcast")
+                dist.broadcast_object_list(box, src=0, group=group)
+            id_bytes = box[0]
+        if len(id_bytes) != 128:
+            raise ValueError("HipComm: the id must be 128 bytes")
+        self._handle = ctypes.c_void_p()
+        _lib.check(self._lib.dgcnn_comm_init(ctypes.byref(self._handle), ctypes.c_char_p(id_bytes), self.world, self.rank),
+                   "dgcnn_comm_init")
+
+    def _check(self, t):
+        self._libmod.require_device(t, "buffer")
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise TypeError("HipComm moves contiguous float32 device buffers")
+
+    def all_reduce(self, t, average=False):
+        """in place, on the current stream: sum (or mean) over the ranks"""
+        self._check(t)
+        self._libmod.check(self._lib.dgcnn_comm_allreduce_f32(self._handle, self._libmod.ptr(t), t.numel(), 1 if average else 0,
+                                                            self._libmod.stream_ptr(t.device)), "dgcnn_comm_allreduce_f32")
+        return t
+
+    def broadcast(self, t, root=0):
+        self._check(t)
+        self._libmod.check(self._lib.dgcnn_comm_broadcast_f32(self._handle, self._libmod.ptr(t), t.numel(), int(root),
+                                                            self._libmod.stream_ptr(t.device)), "dgcnn_comm_broadcast_f32")
+        return t
+
+    def close(self):
+        if self._handle:
+            self._libmod.check(self._lib.dgcnn_comm_destroy(self._handle), "dgcnn_comm_destroy")
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class FlatGradAllReduce:
     """Keeps the gradients of `params` in one flat buffer and averages it across the process group with a
     single all-reduce.  `zero()` drops the .grad tensors, so that backward hands every parameter its
@@ -49,7 +108,10 @@ class FlatGradAllReduce:
     tensors stay (zeroed) views of the buffer and backward accumulates in place (gradient accumulation
     over several backward passes)."""
 
-    def __init__(self, params, group=None):
+    def __init__(self, params, group=None, comm=None):
+        """comm: a HipComm -- the all-reduce then runs through the C ABI (dgcnn_comm_allreduce_f32) instead of
+        torch.distributed"""
+        self.comm = comm
         self.params = [p for p in params if p.requires_grad]
         seen, uniq = set(), []
         for p in self.params:  # bnN and convN.1 alias the same tensors in the reference's layout
@@ -73,6 +135,8 @@ class FlatGradAllReduce:
 
     @property
     def world_size(self):
+        if self.comm is not None:
+            return self.comm.world
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
 
     def zero(self, set_to_none=True):
@@ -102,6 +166,10 @@ class FlatGradAllReduce:
         """sum over ranks, then divide by the world size (gradient of the mean loss over the global batch)."""
         self.pack()
         ws = self.world_size
+        if self.comm is not None:
+            if ws > 1:
+                self.comm.all_reduce(self.flat, average=True)
+            return self.flat
         if ws > 1:
             if self._avg is None:
                 self._avg = dist.get_backend(self.group) == "nccl"  # RCCL averages inside the collective

@@ -76,6 +76,9 @@ def parse_args():
                     help="nccl = RCCL over xGMI (the product path); gloo only to rehearse the N-rank code on a box "
                          "with fewer GPUs than ranks (together with --same-device)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--exchange", default="torch", choices=("torch", "abi"),
+                    help="the gradient all-reduce: torch.distributed's RCCL binding (default) or the library's own, behind the C "
+                         "ABI (dgcnn_comm_allreduce_f32; the id is handed out over the torch.distributed group)")
     return ap.parse_args()
 
 
@@ -121,6 +124,20 @@ def init_ranks(args):
         if dist.get_world_size() != args.gpus:
             raise SystemExit(2)
     return rank, world, dev
+
+
+_COMM = None
+
+
+def make_comm(args, rank, world):
+    """--exchange abi: one RCCL communicator behind the C ABI per process (kept for both workloads of a run)"""
+    global _COMM
+    if args.exchange != "abi":
+        return None
+    if _COMM is None:
+        from ahn3_dgcnn_pytorch_amd.parallel import HipComm
+        _COMM = HipComm(rank, world)
+    return _COMM
 
 
 def fence():
@@ -268,7 +285,7 @@ def run_block(args, rank, world, dev):
     B, N, k, C = args.batch or 8, args.points, args.k, args.channels
     stages = make_stages(C, args.stages, dev)
     params = [p for st in stages for p in st.parameters()]
-    sync = FlatGradAllReduce(params)
+    sync = FlatGradAllReduce(params, comm=make_comm(args, rank, world))
     g = torch.Generator().manual_seed(1000 + rank)
     x_pm = torch.randn(B, N, C, generator=g).to(dev).requires_grad_(True)   # resident in HBM
     cot = cotangent((B, 64, N), tag="bench").to(dev).transpose(1, 2).contiguous()  # [B, N, 64]
@@ -357,7 +374,8 @@ def run_block(args, rank, world, dev):
                                (" + conv 64->64 + BN + LeakyReLU" if args.stages == 2 else ""),
                    "batch_per_gpu": B, "points": N, "k": k, "channels": C, "stages": args.stages,
                    "parallelism": "dp%d (batch elements sharded, one all-reduce of the flat grad buffer)" % world,
-                   "launch": "eager", "ranks": world, "backend": args.backend if world > 1 else None},
+                   "launch": "eager", "ranks": world, "backend": args.backend if world > 1 else None,
+                   "exchange": args.exchange},
         "roofline": kernels[0] if kernels else None,
         "kernels": kernels[1:],
         "knn": {"ms": knn_ms, "algorithmic_flops": knn_flops, "tflops": knn_flops / (knn_ms * 1e-3) / 1e12 if knn_ms else None,
@@ -426,7 +444,7 @@ def run_train(args, rank, world, dev, steps, warmup, with_cpu):
     torch.manual_seed(0)                                  # the same initial weights on every rank
     model = DGCNN(5, 4, k, dropout=0.5, emb_dims=1024, cuda=True)
     model.train()
-    sync = FlatGradAllReduce(model.parameters())
+    sync = FlatGradAllReduce(model.parameters(), comm=make_comm(args, rank, world))
     opt = FlatAdam(model.parameters(), lr=1e-3, weight_decay=1e-4, grad_buffer=sync.flat)   # train.py:118
     if dist.is_initialized() and world > 1:
         broadcast(opt.flat, 0)
@@ -496,7 +514,7 @@ def run_train(args, rank, world, dev, steps, warmup, with_cpu):
                                "all-reduce of the flat gradient buffer, Adam), BASELINE.json configs[3]",
                    "global_batch": Bg, "batch_per_gpu": Bl, "points": N, "k": k, "emb_dims": 1024, "dropout": 0.5,
                    "parallelism": "dp%d (blocks sharded; per-replica BatchNorm statistics)" % world,
-                   "backend": (args.backend if world > 1 else None), "launch": "eager"},
+                   "backend": (args.backend if world > 1 else None), "launch": "eager", "exchange": args.exchange},
         "rccl_ranks": ranks,
         "allreduce": {"ms": ar_ms, "bytes": sync.flat.numel() * 4, "samples": len(ar_events),
                       "note": "pack (one multi-tensor copy) + one all-reduce (AVG) of %d floats" % sync.flat.numel()},

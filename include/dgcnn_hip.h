@@ -317,6 +317,27 @@ int dgcnn_adam_step(float *param, const float *grad, float *exp_avg, float *exp_
 /* float64 -> float32 of a point block (the `.float()` of train.py:176 / test.py:119 on the device). */
 int dgcnn_cast_f64_f32(const double *x, size_t n, float *y, void *stream);
 
+/* ---- exchange step: RCCL behind the C ABI -----------------------------------------------------------
+ * One process per GPU; batch elements are sharded across the ranks (independent units: no collective in the data path)
+ * and a training step ends with ONE all-reduce of the flat fp32 gradient buffer (980 864 floats = 3.9 MB for the
+ * reference's model, train.py:118,198-199); the reference itself has no distributed code (train.py:110-111).
+ * Bootstrap: rank 0 makes an id (dgcnn_comm_unique_id, DGCNN_COMM_ID_BYTES host bytes) and hands it to the other ranks over
+ * any side channel (the launcher's store, a file, MPI ...); then EVERY rank calls dgcnn_comm_init with the same id on its
+ * own current HIP device (a collective call).  buf is a device pointer; the collectives are enqueued on `stream` and
+ * operate in place; average != 0 divides the sum by the number of ranks inside the collective (ncclAvg).
+ * RCCL is bound at run time (dlopen of librccl.so.1: the copy the process already holds, e.g. PyTorch's, else ROCm's):
+ * the library links without it and these calls fail with a message where it is absent. */
+#define DGCNN_COMM_ID_BYTES 128
+typedef struct dgcnn_comm dgcnn_comm;
+int dgcnn_comm_rccl_version(void);  /* NCCL_VERSION_CODE of the bound library, -1 if it cannot be loaded */
+int dgcnn_comm_unique_id(uint8_t *id);
+int dgcnn_comm_init(dgcnn_comm **comm, const uint8_t *id, int world, int rank);
+int dgcnn_comm_destroy(dgcnn_comm *comm);
+int dgcnn_comm_world(const dgcnn_comm *comm);
+int dgcnn_comm_rank(const dgcnn_comm *comm);
+int dgcnn_comm_allreduce_f32(dgcnn_comm *comm, float *buf, size_t count, int average, void *stream);
+int dgcnn_comm_broadcast_f32(dgcnn_comm *comm, float *buf, size_t count, int root, void *stream);
+
 /* ---- measurement hook (bench.py) ----------------------------------------------------------------------
  * HIP events around the large kernels of the path, recorded on the stream each kernel is launched on.  Regions
  * (dgcnn_profile_region_name): the fp16 threshold pass, the fp16 filter and the exact refine of dgcnn_knn, the

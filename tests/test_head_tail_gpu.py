@@ -140,7 +140,7 @@ def test_head_tail_train_matches_float64(B, N):
     run_case(B, N, True, 0.0, seed=B)
 
 
-@pytest.mark.parametrize("B,N", [(2, 300), (1, 128)])
+@pytest.mark.parametrize("B,N", [(2, 300), (1, 128), (1, 1000)])
 def test_head_tail_eval_matches_float64(B, N):
     run_case(B, N, False, 0.5, seed=7)   # eval: no dropout whatever p says
 

@@ -150,3 +150,14 @@ def test_flat_adam_is_a_torch_optimizer_class():
         from ahn3_dgcnn_pytorch_amd import _lib
         with pytest.raises(_lib.HipExtensionError):     # no CPU fallback
             FlatAdam([torch.nn.Parameter(torch.zeros(4))])
+
+
+def test_rccl_binding_behind_the_c_abi_loads_without_a_gpu():
+    """dgcnn_comm_*: RCCL is bound at run time (the copy the process already holds); making an id needs no device"""
+    from ahn3_dgcnn_pytorch_amd import _lib
+    lib = _lib.load()
+    assert lib.dgcnn_comm_rccl_version() >= 20000
+    buf = ctypes.create_string_buffer(128)
+    assert lib.dgcnn_comm_unique_id(buf) == 0
+    assert any(b != 0 for b in buf.raw)
+    assert lib.dgcnn_comm_allreduce_f32(None, None, 0, 0, None) != 0 and b"null" in lib.dgcnn_last_error()

@@ -139,3 +139,26 @@ def test_bench_refuses_a_rank_count_mismatch():
     if torch.cuda.device_count() < 2:
         assert p.returncode != 0
         assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_exchange_behind_the_c_abi_single_rank(device):
+    """dgcnn_comm_*: communicator of one rank on the box's GPU (the N-rank form needs N GPUs: RCCL refuses two ranks on
+    one device) -- init, all-reduce (sum and mean), broadcast, FlatGradAllReduce over it, destroy"""
+    from ahn3_dgcnn_pytorch_amd.parallel import FlatGradAllReduce, HipComm
+    comm = HipComm(0, 1)
+    x = torch.arange(1000, dtype=torch.float32, device=device) * 0.25 - 3.0
+    want = x.clone()
+    comm.all_reduce(x)
+    comm.all_reduce(x, average=True)
+    comm.broadcast(x, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(x, want)
+    p = torch.nn.Parameter(torch.ones(7, 3, device=device))
+    sync = FlatGradAllReduce([p], comm=comm)
+    sync.zero()
+    (p * 2.0).sum().backward()
+    flat = sync.sync()
+    assert sync.world_size == 1 and torch.equal(flat, torch.full((21,), 2.0, device=device))
+    with pytest.raises(TypeError):
+        comm.all_reduce(torch.zeros(4, dtype=torch.float64, device=device))
+    comm.close()
