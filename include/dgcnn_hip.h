@@ -185,7 +185,10 @@ int dgcnn_rows_wgrad(const float *a, int lda, int M, const float *b, int ldb, in
  * conv7's share of the pooled feature, one row per batch element, model.py:179-184): the forward and input-gradient
  * products of conv6 .. conv8 (model.py:172, :184, :187; for dL/dx pass w = W^T).  fp32 in / fp32 out on the fp16 matrix
  * cores with both operands split in two halves at an exact power-of-two scale (three MFMAs per step, fp32 accumulate;
- * operand error 2^-23 relative) -- see head_gemm.hip.  amax_x / amax_w: the operands' dgcnn_rows_absmax words.  x rows
+ * one scale per TENSOR: an element is represented to 2^-23 relative while its low half stays a normal fp16 number --
+ * i.e. down to 2^-14 of the tensor's largest entry -- and to 2^-39 of that largest entry, absolute, below: rows far
+ * smaller than the largest lose relative accuracy; dgcnn_head_tail_* scales gradient operands per 128-row tile
+ * instead) -- see head_gemm.hip.  amax_x / amax_w: the operands' dgcnn_rows_absmax words.  x rows
  * have leading dimension ldx, w rows ldw, y rows ldy; K a multiple of 32, ldx and ldw multiples of 4, x and w 16-byte
  * aligned. */
 int dgcnn_rows_gemm(const float *x, int ldx, const float *w, int ldw, int P, int K, int N, const uint32_t *amax_x,

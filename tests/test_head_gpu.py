@@ -119,3 +119,22 @@ def test_classifier_rows_many_classes_uses_the_library_product():
     dev = torch.device("cuda:0")
     x, w = torch.randn(100, 64).to(dev), torch.randn(13, 64).to(dev)
     torch.testing.assert_close(ops.classifier_rows(x, w), x @ w.t(), rtol=1e-5, atol=1e-5)
+
+
+def test_rows_gemm_rows_far_below_the_largest_keep_the_absolute_bound():
+    # ONE power-of-two scale per tensor (include/dgcnn_hip.h): rows 1e-8 of the others are represented to about 2^-39 of
+    # the tensor's largest entry, absolute -- not to fp32's relative accuracy (dgcnn_head_tail_* scales per 128-row tile)
+    from ahn3_dgcnn_pytorch_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(600, 192, generator=g)
+    x[100:200] *= 1e-8
+    w = torch.randn(256, 192, generator=g)
+    got = ops.rows_gemm(x.to(dev), w.to(dev)).cpu().double()
+    want = x.double() @ w.double().t()
+    bound = 2.0 ** -36 * x.abs().max().double() * w.double().abs().sum(1)      # per output column
+    assert ((got - want).abs() <= bound.unsqueeze(0)).all()
+    big = torch.ones(600, dtype=torch.bool)
+    big[100:200] = False
+    rel = (got - want).abs()[big] / (x.double().abs() @ w.double().abs().t())[big]
+    assert rel.max().item() <= 2e-6
