@@ -97,6 +97,14 @@ SIGNATURES = {
     "dgcnn_embed_max_fwd": (_c_int, [_c_vp, _c_int, _c_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_vp, _c_vp,
                                      ctypes.POINTER(BnParams), _c_int, _c_f, _c_f, _c_f, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_sz,
                                      _c_vp]),
+    "dgcnn_embed_fwd_workspace_bytes": (_c_sz, [_c_int, _c_int, _c_int, _c_int]),
+    "dgcnn_embed_fwd": (_c_int, [_c_vp, _c_int, _c_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_vp, ctypes.POINTER(BnParams),
+                                 _c_int, _c_f, _c_f, _c_f, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp]),
+    "dgcnn_embed_bwd_workspace_bytes": (_c_sz, [_c_int, _c_int, _c_int, _c_int]),
+    "dgcnn_embed_bwd": (_c_int, [_c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_int,
+                                 _c_int, _c_int, _c_f, _c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp]),
+    "dgcnn_rows_stats_workspace_bytes": (_c_sz, [_c_int, _c_int]),
+    "dgcnn_rows_stats": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp]),
     "dgcnn_embed_max_bwd_prepare": (_c_int, [_c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_int, _c_int, _c_f, _c_vp, _c_vp, _c_vp,
                                              _c_vp, _c_vp, _c_vp]),
     "dgcnn_embed_max_bwd_scatter": (_c_int, [_c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_int, _c_int, _c_vp, _c_vp]),

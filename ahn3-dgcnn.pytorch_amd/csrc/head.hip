@@ -717,6 +717,35 @@ void launch_rows_gemm_colred(const float *x, int ldx, const float *w, int ldw, i
 int rows_gemm_row_blocks(int P);
 }  // namespace dgcnn
 
+namespace dgcnn {
+// launchers of this file's kernels for head_fused.hip (dgcnn_embed_fwd / _bwd)
+void launch_colstats_finalize(const double *partial, int nchunk, int P, int C, int training, const dgcnn_bn_params *bn, float eps,
+                              float momentum, float *stats, hipStream_t st)
+{
+    hipLaunchKernelGGL(colstats_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64 * FOLD_W), 0, st, partial, nchunk, P, C, training,
+                       bn->weight, bn->bias, bn->running_mean, bn->running_var, eps, momentum, stats);
+}
+void launch_colmax_finish(const unsigned long long *keys, const float *stats, int B, int C, float slope, float *g, int32_t *arg,
+                          float *uwin, hipStream_t st)
+{
+    hipLaunchKernelGGL(colmax_finish_kernel, dim3(ceil_div(B * C, 256)), dim3(256), 0, st, keys, stats, B, C, slope, g, arg, uwin);
+}
+void launch_embed_bwd_coef(const float *uwin, const float *gg, const float *stats, int B, int N, int C, int training, float slope,
+                           float *gweight, float *gbias, float *coef_a, float *coef_b, float *s, hipStream_t st)
+{
+    hipLaunchKernelGGL(embed_bwd_coef_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, uwin, gg, stats, B, N, C, training, slope,
+                       gweight, gbias, coef_a, coef_b, s);
+}
+void launch_embed_bwd_scatter(const int32_t *arg, const float *s, const float *w, int B, int N, int C, int F, float *dcat,
+                              hipStream_t st)
+{
+    int C2 = 1;
+    while (C2 < C) C2 <<= 1;
+    hipLaunchKernelGGL(embed_bwd_scatter_kernel, dim3(EMB_SHARES, B), dim3(256), (size_t)C2 * sizeof(unsigned long long), st, arg,
+                       s, w, N, C, F, C2, dcat);
+}
+}  // namespace dgcnn
+
 extern "C" size_t dgcnn_embed_max_fwd_workspace_bytes(int B, int N, int C)
 {
     if (B <= 0 || N <= 0 || C <= 0) return 0;

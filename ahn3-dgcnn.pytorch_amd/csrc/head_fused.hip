@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void wprep_kernel(WPrepArgs a)
 
 // ---- y = xeff . w^T with a prologue on x and an epilogue on y -----------------------------------------------------------
 enum { X_RAW = 0, X_BN = 1, X_DU = 2 };
-enum { E_PLAIN = 0, E_STATS = 1, E_DV = 2 };
+enum { E_PLAIN = 0, E_STATS = 1, E_DV = 2, E_COLRED = 3 };
 struct HGemmArgs {
     const float *X;  // X_RAW: x;  X_BN: u of the previous layer;  X_DU: dv of this layer
     int ldx;
@@ -95,6 +95,11 @@ struct HGemmArgs {
     double *psum;    // E_STATS: [nrb][2][N] sum, sum of squares (or NULL: extrema only)
     float *pext;     // E_STATS: [nrb][2][N] min, max
     unsigned *zero;  // E_STATS: one word zeroed by workgroup 0 (the finalize kernel behind this launch takes a maximum into it)
+    // E_COLRED (conv6 -> bn6 -> LeakyReLU -> max over the points, model.py:172-175): nothing is stored; psum as E_STATS and
+    // keys[b][col] <- max over the rows of batch element b of {ordered(u ^ flip), ~row}: BatchNorm + LeakyReLU is monotone per
+    // column (decreasing where gamma < 0: flip), so the extreme of u is the winner of the max; the first row among equals
+    unsigned long long *keys;  // [nbatch][N], zero at launch
+    const float *gamma;
     // E_DV: Y = (acc) . LReLU'(ec_sc U + ec_sh): the gradient wrt the pre-BatchNorm... of the PREVIOUS layer's activation
     const float *U;
     int ldu;
@@ -204,7 +209,14 @@ __global__ __launch_bounds__(256, OCC) void hgemm_kernel(const HGemmArgs a)
                   "epilogue images fit the staging area");
     _Float16(*xh)[GSTR] = lds[0], (*xl)[GSTR] = lds[1], (*wh)[GSTR] = lds[2], (*wl)[GSTR] = lds[3];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, i32 = lane & 31;
-    const int cb = (int)blockIdx.x % a.ncb, rb = (int)blockIdx.x / a.ncb;  // column blocks of a row block are neighbours
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, each with its own L2, so the column blocks of
+    // one row block -- which read the same x rows -- must be neighbours on ONE XCD, not in blockIdx: the grid (a multiple
+    // of 8) is cut into 8 contiguous runs of logical tiles, run x on XCD x.  (With the column blocks adjacent in blockIdx
+    // every one of them fetched its x tile from HBM: 2.8 GB instead of 1.4 for dL/dz7 at B = 32, PMC-measured, and the
+    // kernel ran at the HBM roofline on re-reads.)
+    const int lt = ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);
+    if (lt >= a.ncb * a.nrb) return;  // padding workgroups
+    const int cb = lt % a.ncb, rb = lt / a.ncb;
     const int row0 = rb * GM, col0 = cb * GN;
     const int P = a.P, K = a.K, N = a.N;
     float xbound;
@@ -213,7 +225,7 @@ __global__ __launch_bounds__(256, OCC) void hgemm_kernel(const HGemmArgs a)
     else
         xbound = __uint_as_float(*a.xmax);
     const float sx = pow2_scale(xbound, H_TOP);
-    if (EMODE == E_STATS && blockIdx.x == 0 && threadIdx.x == 0 && a.zero) *a.zero = 0u;
+    if (EMODE == E_STATS && lt == 0 && threadIdx.x == 0 && a.zero) *a.zero = 0u;
     if (XMODE != X_RAW) fill_ktable<XMODE>(a, sx, reinterpret_cast<float(*)[KT_MAX]>(kt));  // (visible behind the loop's first barrier)
 
     f32x16 acc[4];
@@ -260,11 +272,12 @@ __global__ __launch_bounds__(256, OCC) void hgemm_kernel(const HGemmArgs a)
     const int wrow0 = row0 + wave * 32;
     const int nvalid = P - wrow0 < 0 ? 0 : (P - wrow0 > 32 ? 32 : P - wrow0);  // rows of this wave inside the matrix
     // the tile spans at most two batch elements (rows_per_batch >= GM): rows >= rsplit belong to the second
-    const int b0 = (EMODE == E_DV || a.add) ? row0 / a.rows_per_batch : 0;
-    const int rsplit = (EMODE == E_DV || a.add) ? (b0 + 1) * a.rows_per_batch : 0x7fffffff;
+    const int b0 = (EMODE == E_DV || EMODE == E_COLRED || a.add) ? row0 / a.rows_per_batch : 0;
+    const int rsplit = (EMODE == E_DV || EMODE == E_COLRED || a.add) ? (b0 + 1) * a.rows_per_batch : 0x7fffffff;
     // per-lane results of the two 64-column halves, kept until the staging area is free for the cross-wave step
     double st_sum[2][4], st_sq[2][4];  // E_STATS
     float st_mn[2][4], st_mx[2][4];
+    unsigned long long kb[2][4][2];    // E_COLRED: [half][column][batch-element slot] best key
     float dvs[2][4][6];                // E_DV: [half][column][slot 0: dv, dv uhat, uhat; slot 1: the same]
     float amax_dv = 0.0f, amax_uh = 0.0f;
 #pragma unroll
@@ -295,6 +308,13 @@ __global__ __launch_bounds__(256, OCC) void hgemm_kernel(const HGemmArgs a)
         }
         float4 uv[4];  // (the rows of U, four at a time: eight in flight cost the kernel a workgroup per CU in registers)
         float S1[4] = {0.0f, 0.0f, 0.0f, 0.0f}, S2[4] = {0.0f, 0.0f, 0.0f, 0.0f}, cshift[4];
+        unsigned long long kbest[4][2] = {{0ull, 0ull}, {0ull, 0ull}, {0ull, 0ull}, {0ull, 0ull}};
+        unsigned kflip[4] = {0u, 0u, 0u, 0u};
+        if (EMODE == E_COLRED) {
+            const float4 gm = *reinterpret_cast<const float4 *>(a.gamma + cc);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) kflip[e] = f4(gm, e) < 0.0f ? 0x80000000u : 0u;
+        }
         float mn[4], mx[4];
         float ds[4][6];
 #pragma unroll
@@ -338,7 +358,14 @@ __global__ __launch_bounds__(256, OCC) void hgemm_kernel(const HGemmArgs a)
                 } else {
                     const float v = g + (second ? f4(ad1, e) : f4(ad0, e));
                     o[e] = v;
-                    if (EMODE == E_STATS) {
+                    if (EMODE == E_COLRED && on) {
+                        const unsigned ub = __float_as_uint(v) ^ kflip[e];
+                        const unsigned ord = (ub & 0x80000000u) ? ~ub : (ub | 0x80000000u);
+                        const unsigned rl = (unsigned)(row - (second ? rsplit : rsplit - a.rows_per_batch));
+                        const unsigned long long key = ((unsigned long long)ord << 32) | (unsigned long long)(0xffffffffu - rl);
+                        kbest[e][second ? 1 : 0] = key > kbest[e][second ? 1 : 0] ? key : kbest[e][second ? 1 : 0];
+                    }
+                    if (EMODE == E_STATS || EMODE == E_COLRED) {
                         // sums shifted by the value of the wave's first row (fp32 is enough for sum (v - c), sum (v - c)^2
                         // over 32 rows whatever the column's mean is; the shift is undone in fp64 below)
                         if (i == 0) cshift[e] = __shfl(v, lane & 15);
@@ -350,12 +377,24 @@ __global__ __launch_bounds__(256, OCC) void hgemm_kernel(const HGemmArgs a)
                     }
                 }
             }
-            if (on) *reinterpret_cast<float4 *>(a.Y + (size_t)row * a.ldy + cbase) = float4{o[0], o[1], o[2], o[3]};
+            if (EMODE != E_COLRED && on) *reinterpret_cast<float4 *>(a.Y + (size_t)row * a.ldy + cbase) = float4{o[0], o[1], o[2], o[3]};
         }
         // fold the four row groups of the wave (lanes lr = 0 .. 3 of a column group): lanes with lr == 0 end up with the sums
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            if (EMODE == E_STATS) {
+            if (EMODE == E_COLRED) {
+#pragma unroll
+                for (int sl = 0; sl < 2; ++sl) {
+                    unsigned long long kv = kbest[e][sl];
+#pragma unroll
+                    for (int o_ = 16; o_ <= 32; o_ <<= 1) {
+                        const unsigned long long ko = __shfl_xor(kv, o_);
+                        kv = ko > kv ? ko : kv;
+                    }
+                    kb[half][e][sl] = kv;
+                }
+            }
+            if (EMODE == E_STATS || EMODE == E_COLRED) {
 #pragma unroll
                 for (int o_ = 16; o_ <= 32; o_ <<= 1) {
                     S1[e] += __shfl_xor(S1[e], o_);
@@ -382,7 +421,22 @@ __global__ __launch_bounds__(256, OCC) void hgemm_kernel(const HGemmArgs a)
     }
     if (EMODE == E_PLAIN) return;
     __syncthreads();  // all images are consumed: the staging area becomes the scratch of the cross-wave step
-    if (EMODE == E_STATS) {
+    if (EMODE == E_COLRED) {
+        // keys of the tile's two batch-element slots meet in LDS, then one atomicMax per (batch element, column) and tile
+        unsigned long long(*kl)[GN] = reinterpret_cast<unsigned long long(*)[GN]>(reinterpret_cast<char *>(&lds[0][0][0]) + 4 * 2 * GN * 8 + 4 * 2 * GN * 4);  // [2][GN] behind csum / cext
+        for (int t = threadIdx.x; t < 2 * GN; t += 256) kl[t / GN][t % GN] = 0ull;
+        __syncthreads();
+        if (lr == 0) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int sl = 0; sl < 2; ++sl)
+                        if (kb[half][e][sl]) atomicMax(&kl[sl][half * 64 + lc + e], kb[half][e][sl]);
+        }
+    }
+    if (EMODE == E_STATS || EMODE == E_COLRED) {
         double(*csum)[2][GN] = reinterpret_cast<double(*)[2][GN]>(&lds[0][0][0]);                                            // [4][2][GN]
         float(*cext)[2][GN] = reinterpret_cast<float(*)[2][GN]>(reinterpret_cast<char *>(&lds[0][0][0]) + 4 * 2 * GN * 8);  // [4][2][GN]
         if (lr == 0) {
@@ -404,8 +458,15 @@ __global__ __launch_bounds__(256, OCC) void hgemm_kernel(const HGemmArgs a)
                 a.psum[((size_t)rb * 2 + 0) * N + col0 + cl] = (csum[0][0][cl] + csum[1][0][cl]) + (csum[2][0][cl] + csum[3][0][cl]);
                 a.psum[((size_t)rb * 2 + 1) * N + col0 + cl] = (csum[0][1][cl] + csum[1][1][cl]) + (csum[2][1][cl] + csum[3][1][cl]);
             }
-            a.pext[((size_t)rb * 2 + 0) * N + col0 + cl] = fminf(fminf(cext[0][0][cl], cext[1][0][cl]), fminf(cext[2][0][cl], cext[3][0][cl]));
-            a.pext[((size_t)rb * 2 + 1) * N + col0 + cl] = fmaxf(fmaxf(cext[0][1][cl], cext[1][1][cl]), fmaxf(cext[2][1][cl], cext[3][1][cl]));
+            if (EMODE == E_STATS) {
+                a.pext[((size_t)rb * 2 + 0) * N + col0 + cl] = fminf(fminf(cext[0][0][cl], cext[1][0][cl]), fminf(cext[2][0][cl], cext[3][0][cl]));
+                a.pext[((size_t)rb * 2 + 1) * N + col0 + cl] = fmaxf(fmaxf(cext[0][1][cl], cext[1][1][cl]), fmaxf(cext[2][1][cl], cext[3][1][cl]));
+            } else {
+                unsigned long long(*kl)[GN] = reinterpret_cast<unsigned long long(*)[GN]>(reinterpret_cast<char *>(&lds[0][0][0]) + 4 * 2 * GN * 8 + 4 * 2 * GN * 4);
+#pragma unroll
+                for (int sl = 0; sl < 2; ++sl)
+                    if (kl[sl][cl]) atomicMax(a.keys + (size_t)(b0 + sl) * N + col0 + cl, kl[sl][cl]);  // a maximum: order-independent
+            }
         }
     } else {  // E_DV
         double(*cdv)[2][3][GN] = reinterpret_cast<double(*)[2][3][GN]>(&lds[0][0][0]);  // [4][2][3][GN]
@@ -1073,6 +1134,137 @@ __global__ void dropout_mask_kernel(unsigned long long seed, int P, int K, unsig
     for (int e = 0; e < 4; ++e) mask[4 * q + e] = drop_keep(mix, e, keep16) ? 1 : 0;
 }
 
+// ---- conv6 -> bn6 -> LeakyReLU -> max over the points (model.py:172-175): the small pieces of its backward -------------------
+// With u = cat W^T the BatchNorm mean terms of dL/du are affine in u:  dL/du[p][c] = A_c + B_c u[p][c] + (s[b][c] at the winner),
+//   dcat = 1 (W^T A)^T + cat (W^T diag(B) W) + [winners]        dW = A (sum_p cat)^T + diag(B) W (cat^T cat) + [winners]
+// (ops._EmbedMax): two F x F products over the points instead of two C-wide ones.  Here: M = W^T diag(B) W and v = W^T A ...
+// partial[cs][f][g], g < F: the share of channel chunk cs (MV_CH channels) of M[f][g] = sum_c W[c][f] B_c W[c][g];
+// partial[cs][F * F + f]: its share of v[f] = sum_c W[c][f] A_c.  One workgroup = a 32 x 32 tile of (f, g) -- the tile column
+// behind the last g tile carries v -- over one chunk; launch_sum_partials adds the chunks in order.
+constexpr int MV_CH = 128;
+__global__ __launch_bounds__(256) void embed_mv_kernel(const float *__restrict__ W, int ldw, int C, int F,
+                                                       const float *__restrict__ coef_a, const float *__restrict__ coef_b,
+                                                       float *__restrict__ partial)
+{
+    __shared__ float sA[MV_CH][33], sB[MV_CH][33];
+    const int f0 = blockIdx.x * 32, g0 = blockIdx.y * 32, c0 = blockIdx.z * MV_CH;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // tx: g within the tile; ty: four rows f
+    for (int t = threadIdx.x; t < MV_CH * 32; t += 256) {
+        const int cc = t >> 5, j = t & 31, c = c0 + cc;
+        const bool cv = c < C;
+        sA[cc][j] = cv && f0 + j < F ? W[(size_t)c * ldw + f0 + j] : 0.0f;
+        const int g = g0 + j;
+        sB[cc][j] = !cv ? 0.0f : (g < F ? coef_b[c] * W[(size_t)c * ldw + g] : (g == F ? coef_a[c] : 0.0f));
+    }
+    __syncthreads();
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int cc = 0; cc < MV_CH; ++cc) {
+        const float b = sB[cc][tx];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = __builtin_fmaf(sA[cc][ty * 4 + r], b, acc[r]);
+    }
+    float *out = partial + (size_t)blockIdx.z * ((size_t)F * F + F);
+    const int g = g0 + tx;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int f = f0 + ty * 4 + r;
+        if (f < F) {
+            if (g < F) out[(size_t)f * F + g] = acc[r];
+            else if (g == F) out[(size_t)F * F + f] = acc[r];
+        }
+    }
+}
+
+// ... and dW[c][f] = sum_b s[b][c] cat[b N + arg[b][c]][f]  +  B_c sum_g W[c][g] G[g][f]  +  A_c catsum[f]   (G = cat^T cat),
+// four channels per workgroup, thread = column f; every sum in a fixed order
+constexpr int DW_CH = 4;
+__global__ __launch_bounds__(256) void embed_dw_kernel(const float *__restrict__ cat, int ldc, const float *__restrict__ W, int ldw,
+                                                       const int32_t *__restrict__ arg, const float *__restrict__ s,
+                                                       const float *__restrict__ coef_a, const float *__restrict__ coef_b,
+                                                       const float *__restrict__ G, const float *__restrict__ catsum, int B, int N,
+                                                       int C, int F, int training, float *__restrict__ dW)
+{
+    __shared__ float wrow[DW_CH][256];  // (F <= 256)
+    const int c0 = blockIdx.x * DW_CH;
+    if (training)
+        for (int t = threadIdx.x; t < DW_CH * F; t += 256) {
+            const int cc = t / F, g = t - cc * F;
+            wrow[cc][g] = c0 + cc < C ? W[(size_t)(c0 + cc) * ldw + g] : 0.0f;
+        }
+    __syncthreads();
+    for (int f = threadIdx.x; f < F; f += 256) {
+        float acc[DW_CH];
+#pragma unroll
+        for (int cc = 0; cc < DW_CH; ++cc) acc[cc] = 0.0f;
+        if (training) {
+            for (int g = 0; g < F; ++g) {
+                const float gv = G[(size_t)g * F + f];
+#pragma unroll
+                for (int cc = 0; cc < DW_CH; ++cc) acc[cc] = __builtin_fmaf(wrow[cc][g], gv, acc[cc]);
+            }
+        }
+#pragma unroll
+        for (int cc = 0; cc < DW_CH; ++cc) {
+            const int c = c0 + cc;
+            if (c >= C) continue;
+            float d = training ? __builtin_fmaf(coef_b[c], acc[cc], coef_a[c] * catsum[f]) : 0.0f;
+            for (int b = 0; b < B; ++b)
+                d = __builtin_fmaf(s[(size_t)b * C + c], cat[((size_t)b * N + arg[(size_t)b * C + c]) * ldc + f], d);
+            dW[(size_t)c * F + f] = d;
+        }
+    }
+}
+
+// max |x| (bits, into a zeroed word) and the column sums of a [rows][cols] array in one pass: a workgroup takes 256 rows
+// (a wave every fourth row, a lane four adjacent columns) and leaves one fp64 record; colsum_fold_kernel adds the records
+// in order.  cols a multiple of 4, cols <= 256.
+__global__ __launch_bounds__(256) void rows_stats_kernel(const float *__restrict__ x, int ld, int rows, int cols,
+                                                         unsigned *__restrict__ amax, double *__restrict__ partial)
+{
+    __shared__ double red[4][256];
+    __shared__ float rmax[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = 4 * lane;
+    const int r0 = blockIdx.x * 256, r1 = r0 + 256 < rows ? r0 + 256 : rows;
+    double sm[4] = {0.0, 0.0, 0.0, 0.0};
+    float m = 0.0f;
+    if (c < cols)
+        for (int r = r0 + wave; r < r1; r += 4) {
+            const float4 v = *reinterpret_cast<const float4 *>(x + (size_t)r * ld + c);
+            sm[0] += (double)v.x;
+            sm[1] += (double)v.y;
+            sm[2] += (double)v.z;
+            sm[3] += (double)v.w;
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[wave][4 * lane + e] = sm[e];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane == 0) rmax[wave] = m;
+    __syncthreads();
+    if ((int)threadIdx.x < cols) partial[(size_t)blockIdx.x * cols + threadIdx.x] =
+        (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (threadIdx.x == 0) atomicMax(amax, __float_as_uint(fmaxf(fmaxf(rmax[0], rmax[1]), fmaxf(rmax[2], rmax[3]))));
+}
+__global__ __launch_bounds__(64 * FW) void colsum_fold_kernel(const double *__restrict__ partial, int nrec, int cols,
+                                                              float *__restrict__ colsum)
+{
+    __shared__ double red[FW][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    double a = 0.0;
+    if (c < cols)
+        for (int g = wave; g < nrec; g += FW) a += partial[(size_t)g * cols + c];
+    red[wave][lane] = a;
+    __syncthreads();
+    if (wave != 0 || c >= cols) return;
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < FW; ++w) t += red[w][lane];
+    colsum[c] = (float)t;
+}
+
 // ---- host side: layouts and launch sequences ----------------------------------------------------------------------------
 struct Carver {
     char *base;
@@ -1278,7 +1470,7 @@ extern "C" int dgcnn_head_tail_fwd(const dgcnn_head_tail_desc *d, const float *c
         a.Y = s.u7, a.ldy = C7;
         a.psum = d->training ? w.psum7 : nullptr, a.pext = w.pext7, a.zero = s.zmax;
         a.ncb = ceil_div(C7, GN), a.nrb = nrb;
-        hipLaunchKernelGGL((hgemm_kernel<X_RAW, E_STATS, 3>), dim3(a.ncb * nrb), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((hgemm_kernel<X_RAW, E_STATS, 3>), dim3((unsigned)align_up((size_t)a.ncb * nrb, 8)), dim3(256), 0, st, a);
         hipLaunchKernelGGL(stats_finalize_kernel, dim3(ceil_div(C7, 64)), dim3(64 * FW), 0, st, w.psum7, w.pext7, nrb, P, C7,
                            d->training, d->bn7.weight, d->bn7.bias, d->bn7.running_mean, d->bn7.running_var, d->eps7,
                            d->momentum7, d->slope, s.stats7, s.zmax);
@@ -1293,7 +1485,7 @@ extern "C" int dgcnn_head_tail_fwd(const dgcnn_head_tail_desc *d, const float *c
         a.Y = s.u8, a.ldy = C8;
         a.psum = d->training ? w.psum8 : nullptr, a.pext = w.pext8, a.zero = s.zmax + 1;
         a.ncb = ceil_div(C8, GN), a.nrb = nrb;
-        hipLaunchKernelGGL((hgemm_kernel<X_BN, E_STATS, 3>), dim3(a.ncb * nrb), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((hgemm_kernel<X_BN, E_STATS, 3>), dim3((unsigned)align_up((size_t)a.ncb * nrb, 8)), dim3(256), 0, st, a);
         hipLaunchKernelGGL(stats_finalize_kernel, dim3(ceil_div(C8, 64)), dim3(64 * FW), 0, st, w.psum8, w.pext8, nrb, P, C8,
                            d->training, d->bn8.weight, d->bn8.bias, d->bn8.running_mean, d->bn8.running_var, d->eps8,
                            d->momentum8, d->slope, s.stats8, s.zmax + 1);
@@ -1367,8 +1559,8 @@ extern "C" int dgcnn_head_tail_bwd(const dgcnn_head_tail_desc *d, const float *c
         a.ec[0] = mean7, a.ec[1] = rstd7, a.ec[2] = sc7, a.ec[3] = sh7;
         a.pdv = w.pdv7, a.oa = w.oa7, a.ob = w.ob7;
         a.ncb = ceil_div(C7, GN), a.nrb = nrb;
-        if (occ3()) hipLaunchKernelGGL((hgemm_kernel<X_DU, E_DV, 3>), dim3(a.ncb * nrb), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((hgemm_kernel<X_DU, E_DV, 2>), dim3(a.ncb * nrb), dim3(256), 0, st, a);
+        if (occ3()) hipLaunchKernelGGL((hgemm_kernel<X_DU, E_DV, 3>), dim3((unsigned)align_up((size_t)a.ncb * nrb, 8)), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((hgemm_kernel<X_DU, E_DV, 2>), dim3((unsigned)align_up((size_t)a.ncb * nrb, 8)), dim3(256), 0, st, a);
     }
     {   // dW8 = du8^T z7: both operands formed at the load
         HWgradArgs a{};
@@ -1400,8 +1592,8 @@ extern "C" int dgcnn_head_tail_bwd(const dgcnn_head_tail_desc *d, const float *c
         a.slope = d->slope;
         a.Y = g->gcat, a.ldy = g->ldgcat;
         a.ncb = ceil_div(F, GN), a.nrb = nrb;
-        if (occ3()) hipLaunchKernelGGL((hgemm_kernel<X_DU, E_PLAIN, 3>), dim3(a.ncb * nrb), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((hgemm_kernel<X_DU, E_PLAIN, 2>), dim3(a.ncb * nrb), dim3(256), 0, st, a);
+        if (occ3()) hipLaunchKernelGGL((hgemm_kernel<X_DU, E_PLAIN, 3>), dim3((unsigned)align_up((size_t)a.ncb * nrb, 8)), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((hgemm_kernel<X_DU, E_PLAIN, 2>), dim3((unsigned)align_up((size_t)a.ncb * nrb, 8)), dim3(256), 0, st, a);
     }
     {   // dW7c = du7^T cat
         HWgradArgs a{};
@@ -1432,5 +1624,199 @@ extern "C" int dgcnn_dropout_mask(uint64_t seed, int P, int K, float p_drop, uin
     hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        (unsigned long long)seed, P, K, keep16_of(p_drop), mask);
     DG_CHECK_LAUNCH("dgcnn_dropout_mask");
+    return 0;
+}
+
+// ---- conv6 -> bn6 -> LeakyReLU -> max over the points as one forward and one backward call ---------------------------------
+namespace dgcnn {
+void launch_colstats_finalize(const double *partial, int nchunk, int P, int C, int training, const dgcnn_bn_params *bn, float eps,
+                              float momentum, float *stats, hipStream_t st);  // head.hip
+void launch_colmax_finish(const unsigned long long *keys, const float *stats, int B, int C, float slope, float *g, int32_t *arg,
+                          float *uwin, hipStream_t st);
+void launch_embed_bwd_coef(const float *uwin, const float *gg, const float *stats, int B, int N, int C, int training, float slope,
+                           float *gweight, float *gbias, float *coef_a, float *coef_b, float *s, hipStream_t st);
+void launch_embed_bwd_scatter(const int32_t *arg, const float *s, const float *w, int B, int N, int C, int F, float *dcat,
+                              hipStream_t st);
+namespace hf {
+struct EmbedFwdWs {
+    double *psum;
+    unsigned long long *keys;
+    Planes w;
+    size_t bytes;
+};
+static EmbedFwdWs embed_fwd_ws(int B, int N, int F, int C, void *p)
+{
+    Carver c(p);
+    EmbedFwdWs w;
+    w.psum = c.take<double>((size_t)ceil_div(B * N, GM) * 2 * C);
+    w.keys = c.take<unsigned long long>((size_t)B * C);
+    w.w = take_planes(c, C, F);
+    w.bytes = c.off;
+    return w;
+}
+struct EmbedBwdWs {
+    float *coef_a, *coef_b, *s, *M, *v, *G, *wpart, *mvpart;
+    Planes m;
+    size_t bytes;
+};
+static EmbedBwdWs embed_bwd_ws(int B, int N, int F, int C, void *p)
+{
+    Carver c(p);
+    EmbedBwdWs w;
+    w.coef_a = c.take<float>(C);
+    w.coef_b = c.take<float>(C);
+    w.s = c.take<float>((size_t)B * C);
+    w.M = c.take<float>((size_t)F * F + F);  // M [F][F], then v [F]: one fold of the channel chunks' shares
+    w.v = w.M + (size_t)F * F;
+    w.mvpart = c.take<float>((size_t)ceil_div(C, MV_CH) * ((size_t)F * F + F));
+    w.G = c.take<float>((size_t)F * F);
+    w.wpart = c.take<float>((size_t)wgrad_chunks(F, F, B * N) * F * F);
+    w.m = take_planes(c, F, F);
+    w.bytes = c.off;
+    return w;
+}
+static int embed_shape_ok(int B, int N, int F, int C, int ldc, int ldw, const char *who)
+{
+    DG_REQUIRE(B > 0 && N >= GM && F > 0 && C > 0, "%s: needs B > 0, N >= %d (B=%d N=%d F=%d C=%d)", who, GM, B, N, F, C);
+    DG_REQUIRE(F % 32 == 0 && F <= 256 && C % 4 == 0 && C <= 8192, "%s: F a multiple of 32 (<= 256), C a multiple of 4 (<= 8192)", who);
+    DG_REQUIRE(ldc >= F && ldc % 4 == 0 && ldw >= F && ldw % 4 == 0, "%s: ldc / ldw must be multiples of 4 and >= F", who);
+    DG_REQUIRE((size_t)B * N < ((size_t)1 << 23), "%s: more than 2^23 points", who);
+    return 0;
+}
+}  // namespace hf
+}  // namespace dgcnn
+
+extern "C" size_t dgcnn_rows_stats_workspace_bytes(int rows, int cols)
+{
+    return rows > 0 && cols > 0 ? align_up((size_t)ceil_div(rows, 256) * cols * sizeof(double), 256) : 0;
+}
+extern "C" int dgcnn_rows_stats(const float *x, int ld, int rows, int cols, uint32_t *amax, float *colsum, void *workspace,
+                                size_t workspace_bytes, void *stream)
+{
+    DG_REQUIRE(x && amax && colsum && workspace, "dgcnn_rows_stats: null pointer");
+    DG_REQUIRE(rows > 0 && cols > 0 && cols <= 256 && (cols & 3) == 0 && ld >= cols && (ld & 3) == 0 && ((uintptr_t)x & 15) == 0,
+               "dgcnn_rows_stats: cols a multiple of 4 (<= 256), 16-byte aligned rows (rows=%d cols=%d ld=%d)", rows, cols, ld);
+    DG_REQUIRE(workspace_bytes >= dgcnn_rows_stats_workspace_bytes(rows, cols), "dgcnn_rows_stats: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(amax, 0, 4, st) != hipSuccess) DG_FAIL("dgcnn_rows_stats: hipMemsetAsync failed");
+    const int nrec = ceil_div(rows, 256);
+    hipLaunchKernelGGL(rows_stats_kernel, dim3(nrec), dim3(256), 0, st, x, ld, rows, cols, amax, (double *)workspace);
+    hipLaunchKernelGGL(colsum_fold_kernel, dim3(ceil_div(cols, 64)), dim3(64 * FW), 0, st, (const double *)workspace, nrec, cols, colsum);
+    DG_CHECK_LAUNCH("dgcnn_rows_stats");
+    return 0;
+}
+
+extern "C" size_t dgcnn_embed_fwd_workspace_bytes(int B, int N, int F, int C)
+{
+    return embed_shape_ok(B, N, F, C, F, F, "dgcnn_embed_fwd_workspace_bytes") == 0 ? embed_fwd_ws(B, N, F, C, nullptr).bytes : 0;
+}
+extern "C" int dgcnn_embed_fwd(const float *cat, int ldc, const float *w, int ldw, int B, int N, int F, int C,
+                               const uint32_t *amax_cat, const dgcnn_bn_params *bn, int training, float eps, float momentum,
+                               float slope, float *g, int32_t *arg, float *uwin, float *stats, void *workspace,
+                               size_t workspace_bytes, void *stream)
+{
+    DG_REQUIRE(cat && w && amax_cat && bn && g && arg && uwin && stats && workspace, "dgcnn_embed_fwd: null pointer");
+    if (embed_shape_ok(B, N, F, C, ldc, ldw, "dgcnn_embed_fwd")) return 1;
+    DG_REQUIRE(((uintptr_t)cat & 15) == 0 && ((uintptr_t)w & 15) == 0, "dgcnn_embed_fwd: operands must be 16-byte aligned");
+    DG_REQUIRE(bn->weight && bn->bias, "dgcnn_embed_fwd: BatchNorm parameters missing");
+    DG_REQUIRE(training || (bn->running_mean && bn->running_var), "dgcnn_embed_fwd: eval mode needs running statistics");
+    const EmbedFwdWs ws = embed_fwd_ws(B, N, F, C, workspace);
+    DG_REQUIRE(workspace_bytes >= ws.bytes, "dgcnn_embed_fwd: workspace too small (%zu < %zu)", workspace_bytes, ws.bytes);
+    hipStream_t st = (hipStream_t)stream;
+    const int P = B * N, nrb = ceil_div(P, GM);
+    if (hipMemsetAsync(ws.keys, 0, (size_t)B * C * sizeof(unsigned long long), st) != hipSuccess) DG_FAIL("dgcnn_embed_fwd: memset failed");
+    {
+        WPrepArgs a{};
+        a.job[0] = WPrepJob{w, ldw, C, F, 0, ws.w.hi, ws.w.lo, ws.w.scale};
+        a.njobs = 1;
+        a.first_row[0] = 0;
+        a.first_row[1] = C;
+        hipLaunchKernelGGL(wprep_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, a);
+    }
+    {
+        HGemmArgs a{};
+        a.X = cat, a.ldx = ldc, a.P = P, a.K = F, a.N = C;
+        a.Wh = ws.w.hi, a.Wl = ws.w.lo, a.wscale = ws.w.scale;
+        a.xmax = amax_cat;
+        a.slope = slope;
+        a.rows_per_batch = N;
+        a.psum = training ? ws.psum : nullptr;
+        a.keys = ws.keys, a.gamma = bn->weight;
+        a.ncb = ceil_div(C, GN), a.nrb = nrb;
+        hipLaunchKernelGGL((hgemm_kernel<X_RAW, E_COLRED, 3>), dim3((unsigned)align_up((size_t)a.ncb * nrb, 8)), dim3(256), 0, st, a);
+    }
+    launch_colstats_finalize(ws.psum, nrb, P, C, training, bn, eps, momentum, stats, st);
+    launch_colmax_finish(ws.keys, stats, B, C, slope, g, arg, uwin, st);
+    DG_CHECK_LAUNCH("dgcnn_embed_fwd");
+    return 0;
+}
+
+extern "C" size_t dgcnn_embed_bwd_workspace_bytes(int B, int N, int F, int C)
+{
+    return embed_shape_ok(B, N, F, C, F, F, "dgcnn_embed_bwd_workspace_bytes") == 0 ? embed_bwd_ws(B, N, F, C, nullptr).bytes : 0;
+}
+extern "C" int dgcnn_embed_bwd(const float *cat, int ldc, const uint32_t *amax_cat, const float *catsum, const float *w, int ldw,
+                               const int32_t *arg, const float *uwin, const float *stats, const float *gg, int B, int N, int F, int C,
+                               int training, float slope, float *dcat, int lddcat, float *dw, float *gbn_w, float *gbn_b,
+                               void *workspace, size_t workspace_bytes, void *stream)
+{
+    DG_REQUIRE(cat && amax_cat && w && arg && uwin && stats && gg && dcat && dw && gbn_w && gbn_b && workspace, "dgcnn_embed_bwd: null pointer");
+    DG_REQUIRE(!training || catsum, "dgcnn_embed_bwd: training mode needs the column sums of cat");
+    if (embed_shape_ok(B, N, F, C, ldc, ldw, "dgcnn_embed_bwd")) return 1;
+    DG_REQUIRE(lddcat == F && ldw == F, "dgcnn_embed_bwd: dcat and w must be contiguous (lddcat = ldw = F)");
+    DG_REQUIRE(((uintptr_t)cat & 15) == 0 && ((uintptr_t)dcat & 15) == 0, "dgcnn_embed_bwd: rows must be 16-byte aligned");
+    const EmbedBwdWs ws = embed_bwd_ws(B, N, F, C, workspace);
+    DG_REQUIRE(workspace_bytes >= ws.bytes, "dgcnn_embed_bwd: workspace too small (%zu < %zu)", workspace_bytes, ws.bytes);
+    hipStream_t st = (hipStream_t)stream;
+    const int P = B * N, nrb = ceil_div(P, GM);
+    launch_embed_bwd_coef(uwin, gg, stats, B, N, C, training, slope, gbn_w, gbn_b, ws.coef_a, ws.coef_b, ws.s, st);
+    if (training) {
+        {
+            const int ncs = ceil_div(C, MV_CH);
+            hipLaunchKernelGGL(embed_mv_kernel, dim3(ceil_div(F, 32), F / 32 + 1, ncs), dim3(256), 0, st, w, ldw, C, F, ws.coef_a,
+                               ws.coef_b, ws.mvpart);
+            launch_sum_partials(ws.mvpart, ncs, F * F + F, ws.M, st);
+        }
+        {   // M is symmetric: its rows are the columns the product contracts with
+            WPrepArgs a{};
+            a.job[0] = WPrepJob{ws.M, F, F, F, 0, ws.m.hi, ws.m.lo, ws.m.scale};
+            a.njobs = 1;
+            a.first_row[0] = 0;
+            a.first_row[1] = F;
+            hipLaunchKernelGGL(wprep_kernel, dim3(ceil_div(F, 4)), dim3(256), 0, st, a);
+        }
+        {   // dcat = cat M + 1 v^T
+            HGemmArgs a{};
+            a.X = cat, a.ldx = ldc, a.P = P, a.K = F, a.N = F;
+            a.Wh = ws.m.hi, a.Wl = ws.m.lo, a.wscale = ws.m.scale;
+            a.xmax = amax_cat;
+            a.slope = slope;
+            a.add = ws.v, a.rows_per_batch = P;
+            a.Y = dcat, a.ldy = lddcat;
+            a.ncb = ceil_div(F, GN), a.nrb = nrb;
+            hipLaunchKernelGGL((hgemm_kernel<X_RAW, E_PLAIN, 3>), dim3((unsigned)align_up((size_t)a.ncb * nrb, 8)), dim3(256), 0, st, a);
+        }
+        {   // G = cat^T cat
+            HWgradArgs a{};
+            a.A = cat, a.lda = ldc, a.M = F;
+            a.Bm = cat, a.ldb = ldc, a.Nn = F, a.P = P;
+            const int chunks = wgrad_chunks(F, F, P);
+            a.chunk = (ceil_div(P, chunks) + 31) & ~31;
+            a.ntiles_n = ceil_div(F, 128);
+            a.slope = slope;
+            a.ta = amax_cat, a.amax_b = amax_cat;
+            a.partial = ws.wpart;
+            const int nch = ceil_div(P, a.chunk);
+            const dim3 grid((unsigned)align_up((size_t)ceil_div(F, 128) * a.ntiles_n * nch, 8));
+            hipLaunchKernelGGL((hwgrad_kernel<A_RAW, B_RAW, 3>), grid, dim3(256), 0, st, a);
+            launch_sum_partials(ws.wpart, nch, F * F, ws.G, st);
+        }
+    } else {
+        if (hipMemsetAsync(dcat, 0, (size_t)P * F * sizeof(float), st) != hipSuccess) DG_FAIL("dgcnn_embed_bwd: memset failed");
+    }
+    hipLaunchKernelGGL(embed_dw_kernel, dim3(ceil_div(C, DW_CH)), dim3(256), 0, st, cat, ldc, w, ldw, arg, ws.s, ws.coef_a, ws.coef_b,
+                       ws.G, catsum, B, N, C, F, training, dw);
+    launch_embed_bwd_scatter(arg, ws.s, w, B, N, C, F, dcat, st);
+    DG_CHECK_LAUNCH("dgcnn_embed_bwd");
     return 0;
 }

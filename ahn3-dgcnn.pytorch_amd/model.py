@@ -148,9 +148,11 @@ class DGCNN(nn.Module):
                     # tensor is never written (BN + LeakyReLU is monotone per column, see dgcnn_bn_lrelu_max_fwd)
                     # and its backward runs on 192-wide products only (ops._EmbedMax)
                     cat2 = cat.reshape(P, 192)
-                    amax_cat = ops.rows_absmax(cat2.detach())     # max |cat|, measured once for every product that reads cat
+                    # max |cat| (the operand scale of every product that reads cat) and its column sums (conv6's
+                    # backward), measured in one pass
+                    amax_cat, catsum = ops.rows_stats(cat2.detach())
                     g = ops.embed_max_rows(cat2, self.conv6[0].weight.squeeze(-1), self.bn6, B, N,
-                                           self.training, NEG_SLOPE, amax_cat).view(B, 1, emb)
+                                           self.training, NEG_SLOPE, amax_cat, catsum).view(B, 1, emb)
                     if depth == 6:
                         out = g.transpose(1, 2).contiguous()
                     else:

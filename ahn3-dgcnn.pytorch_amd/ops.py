@@ -369,6 +369,25 @@ def rows_absmax(x):
     return out
 
 
+def rows_stats(x):
+    """(amax word, column sums [cols]) of a 2-d float32 array in ONE pass (dgcnn_rows_stats): the operand magnitude every
+    product that reads x scales by, and sum_p x[p, :] (conv6's backward needs it of cat).  cols a multiple of 4, <= 256."""
+    _lib.require_device(x, "x")
+    if x.dtype != torch.float32 or x.dim() != 2:
+        raise TypeError("rows_stats needs a 2-d float32 tensor")
+    if x.stride(1) != 1 or x.stride(0) % 4 or x.data_ptr() % 16:
+        x = x.contiguous()
+    rows, cols = x.shape
+    lib = _lib.load()
+    amax = torch.empty((1,), dtype=torch.int32, device=x.device)
+    colsum = torch.empty((cols,), dtype=torch.float32, device=x.device)
+    ws_bytes = lib.dgcnn_rows_stats_workspace_bytes(rows, cols)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=x.device)
+    _lib.check(lib.dgcnn_rows_stats(_lib.ptr(x), x.stride(0), rows, cols, _lib.ptr(amax), _lib.ptr(colsum), _lib.ptr(ws), ws_bytes,
+                                    _lib.stream_ptr(x.device)), "dgcnn_rows_stats")
+    return amax, colsum
+
+
 def rows_wgrad(a, b, amax_a=None, amax_b=None):
     """sum over the rows p of a[p, :]^T b[p, :]:  a [P, M], b [P, N] (rows may be strided views) -> [M, N].
     The weight-gradient product of a 1x1 convolution on point-major rows, split over the points (dgcnn_rows_wgrad);
@@ -534,7 +553,7 @@ class _EmbedMax(torch.autograd.Function):
     matrix kernel's accumulators -- column sums and the running extreme are its epilogue."""
 
     @staticmethod
-    def forward(ctx, cat, w, weight, bias, rmean, rvar, B, N, training, eps, momentum, slope, amax_cat=None):
+    def forward(ctx, cat, w, weight, bias, rmean, rvar, B, N, training, eps, momentum, slope, amax_cat=None, catsum=None):
         P, F_ = cat.shape
         C = w.shape[0]
         lib = _lib.load()
@@ -549,7 +568,19 @@ class _EmbedMax(torch.autograd.Function):
         # max |cat|: this product and the two 192-wide ones of the backward (the caller's word when it has measured cat)
         ac = amax_cat if amax_cat is not None else rows_absmax(catd)
         fused = _gemm_ok(F_) and C % 4 == 0 and catd.stride(0) % 4 == 0 and catd.data_ptr() % 16 == 0
-        if fused:
+        # one call forward and one call backward (dgcnn_embed_fwd / _bwd) where the shape allows it
+        one_call = (fused and N >= 128 and F_ <= 256 and C <= 8192 and P < (1 << 23) and wd.is_contiguous() and wd.data_ptr() % 16 == 0
+                    and catd.is_contiguous() and (catsum is not None or not training))
+        ctx.one_call = one_call
+        if one_call:
+            uwin = torch.empty((B, C), dtype=torch.float32, device=dev)
+            ws_bytes = lib.dgcnn_embed_fwd_workspace_bytes(B, N, F_, C)
+            ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+            _lib.check(lib.dgcnn_embed_fwd(_lib.ptr(catd), catd.stride(0), _lib.ptr(wd), wd.stride(0), B, N, F_, C, _lib.ptr(ac),
+                                           ctypes.byref(bn), 1 if training else 0, eps, momentum, slope, _lib.ptr(g), _lib.ptr(arg),
+                                           _lib.ptr(uwin), _lib.ptr(stats), _lib.ptr(ws), ws_bytes, _lib.stream_ptr(dev)),
+                       "dgcnn_embed_fwd")
+        elif fused:
             # ONE pass: the [P, emb] product never leaves the matrix kernel's accumulators (dgcnn_embed_max_fwd)
             if wd.stride(1) != 1 or wd.stride(0) % 4 or wd.data_ptr() % 16:
                 wd = wd.contiguous()
@@ -569,13 +600,13 @@ class _EmbedMax(torch.autograd.Function):
                                                   slope, _lib.ptr(g), _lib.ptr(arg), _lib.ptr(stats), _lib.ptr(ws), ws_bytes,
                                                   _lib.stream_ptr(dev)), "dgcnn_bn_lrelu_max_fwd")
             uwin = torch.gather(u.view(B, N, C), 1, arg.long().unsqueeze(1)).squeeze(1).contiguous()   # [B, C]
-        ctx.save_for_backward(cat, w, arg, stats, uwin, ac)
+        ctx.save_for_backward(cat, w, arg, stats, uwin, ac, catsum if (one_call and training) else None)
         ctx.cfg = (B, N, training, slope)
         return g
 
     @staticmethod
     def backward(ctx, gg):
-        cat, w, arg, stats, uwin, ac = ctx.saved_tensors
+        cat, w, arg, stats, uwin, ac, catsum = ctx.saved_tensors
         B, N, training, slope = ctx.cfg
         P, F_ = cat.shape
         C = w.shape[0]
@@ -585,6 +616,17 @@ class _EmbedMax(torch.autograd.Function):
         gg = gg.contiguous()
         gw_bn = torch.empty((C,), dtype=torch.float32, device=dev)
         gb_bn = torch.empty((C,), dtype=torch.float32, device=dev)
+        if ctx.one_call:
+            catd, wd = cat.detach(), w.detach()
+            dcat = torch.empty((P, F_), dtype=torch.float32, device=dev)
+            dw = torch.empty((C, F_), dtype=torch.float32, device=dev)
+            ws_bytes = lib.dgcnn_embed_bwd_workspace_bytes(B, N, F_, C)
+            ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+            _lib.check(lib.dgcnn_embed_bwd(_lib.ptr(catd), catd.stride(0), _lib.ptr(ac), _lib.ptr(catsum) if catsum is not None else None,
+                                           _lib.ptr(wd), wd.stride(0), _lib.ptr(arg), _lib.ptr(uwin), _lib.ptr(stats), _lib.ptr(gg),
+                                           B, N, F_, C, 1 if training else 0, slope, _lib.ptr(dcat), F_, _lib.ptr(dw),
+                                           _lib.ptr(gw_bn), _lib.ptr(gb_bn), _lib.ptr(ws), ws_bytes, st), "dgcnn_embed_bwd")
+            return dcat, dw.view_as(w), gw_bn, gb_bn, None, None, None, None, None, None, None, None, None, None
         coef_a = torch.empty((C,), dtype=torch.float32, device=dev)
         coef_b = torch.empty((C,), dtype=torch.float32, device=dev)
         s = torch.empty((B, C), dtype=torch.float32, device=dev)
@@ -610,10 +652,10 @@ class _EmbedMax(torch.autograd.Function):
             dcat = torch.zeros_like(catd)
         _lib.check(lib.dgcnn_embed_max_bwd_scatter(_lib.ptr(arg), _lib.ptr(s), _lib.ptr(wd), B, N, C, F_, _lib.ptr(dcat), st),
                    "dgcnn_embed_max_bwd_scatter")
-        return dcat, dw.view_as(w), gw_bn, gb_bn, None, None, None, None, None, None, None, None, None
+        return dcat, dw.view_as(w), gw_bn, gb_bn, None, None, None, None, None, None, None, None, None, None
 
 
-def embed_max_rows(cat, w, bn, B, N, training, slope=0.2, amax_cat=None):
+def embed_max_rows(cat, w, bn, B, N, training, slope=0.2, amax_cat=None, catsum=None):
     """g[b] = max over the N points of batch element b of LeakyReLU(BatchNorm1d(cat W^T)): cat point-major rows
     [B*N, F], w [emb, F] (conv6's weight) -> [B, emb]; `bn` is the nn.BatchNorm1d module (running statistics updated
     in place when training)."""
@@ -623,7 +665,7 @@ def embed_max_rows(cat, w, bn, B, N, training, slope=0.2, amax_cat=None):
     use_batch_stats = training or bn.running_mean is None
     momentum = bn.momentum if bn.momentum is not None else 0.1
     g = _EmbedMax.apply(cat, w, bn.weight, bn.bias, bn.running_mean, bn.running_var, int(B), int(N),
-                        bool(use_batch_stats), float(bn.eps), float(momentum), float(slope), amax_cat)
+                        bool(use_batch_stats), float(bn.eps), float(momentum), float(slope), amax_cat, catsum)
     if training:
         _count_batch(bn)
     return g

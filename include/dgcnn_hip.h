@@ -219,6 +219,28 @@ int dgcnn_embed_max_fwd(const float *cat, int ldc, const float *w, int ldw, int 
                         float momentum, float slope, float *g, int32_t *arg, float *uwin, float *stats, void *workspace,
                         size_t workspace_bytes, void *stream);
 
+/* The same pass and its backward as ONE call each (round 3; head_fused.hip): the forward splits conv6's weight once into
+ * fp16 planes scaled per output channel (no operand-magnitude pass over w); the backward runs the whole of ops._EmbedMax's
+ * algebra -- with u = cat . W^T the BatchNorm mean terms of dL/du are affine in u, dL/du[p][c] = A_c + B_c u[p][c] + (s[b][c]
+ * at the winning point), hence  dcat = 1 (W^T A)^T + cat (W^T diag(B) W) + [winners],  dW = A (sum_p cat)^T + diag(B) W
+ * (cat^T cat) + [winners]: two F x F products over the points instead of two C-wide ones -- in eight launches without a
+ * library call.  catsum [F] = the column sums of cat (dgcnn_rows_stats; training mode only), gg = dL/dg [B][C]; dcat [B N][F]
+ * and dw [C][F] are OVERWRITTEN, contiguous.  N >= 128, F a multiple of 32 (<= 256), C a multiple of 4. */
+size_t dgcnn_embed_fwd_workspace_bytes(int B, int N, int F, int C);
+int dgcnn_embed_fwd(const float *cat, int ldc, const float *w, int ldw, int B, int N, int F, int C, const uint32_t *amax_cat,
+                    const dgcnn_bn_params *bn, int training, float eps, float momentum, float slope, float *g, int32_t *arg,
+                    float *uwin, float *stats, void *workspace, size_t workspace_bytes, void *stream);
+size_t dgcnn_embed_bwd_workspace_bytes(int B, int N, int F, int C);
+int dgcnn_embed_bwd(const float *cat, int ldc, const uint32_t *amax_cat, const float *catsum, const float *w, int ldw,
+                    const int32_t *arg, const float *uwin, const float *stats, const float *gg, int B, int N, int F, int C,
+                    int training, float slope, float *dcat, int lddcat, float *dw, float *gbn_w, float *gbn_b, void *workspace,
+                    size_t workspace_bytes, void *stream);
+/* amax[0] <- the bits of max |x| (as dgcnn_rows_absmax) and colsum[c] <- sum over the rows of x[r][c], in one pass over a
+ * [rows][cols] array (cols a multiple of 4, <= 256; fp64 records folded in a fixed order). */
+size_t dgcnn_rows_stats_workspace_bytes(int rows, int cols);
+int dgcnn_rows_stats(const float *x, int ld, int rows, int cols, uint32_t *amax, float *colsum, void *workspace,
+                     size_t workspace_bytes, void *stream);
+
 /* Backward of conv6 -> bn6 -> LeakyReLU -> max without the dense [B*N][C] gradient (model.py:172-175; host side in
  * ops.py, _EmbedMax).  With u = cat . W^T the BatchNorm mean terms of dL/du are affine in u, dL/du[p][c] = A_c +
  * B_c u[p][c] + (s[b][c] at the winning point), so the backward needs 192-wide library products only.

@@ -515,10 +515,11 @@ def test_head_bn_lrelu_max_rows(B, N, C, train, device):
         assert int(bn_d.num_batches_tracked) == int(bn.num_batches_tracked) == 1
 
 
+@pytest.mark.parametrize("one_call", [False, True])   # True: dgcnn_embed_fwd / _bwd (the caller has measured cat: ops.rows_stats)
 @pytest.mark.parametrize("train", [True, False])
 @pytest.mark.parametrize("B,N,F,C", [(3, 700, 192, 64), (2, 1030, 192, 1024), (1, 130, 48, 200), (4, 257, 192, 1024),
                                      (6, 40, 64, 128)])   # (the last: a 128-row tile of the fused kernel spans four batch elements)
-def test_head_embed_max_rows(B, N, F, C, train, device):
+def test_head_embed_max_rows(B, N, F, C, train, one_call, device):
     # conv6 (1x1) -> bn6 -> LeakyReLU -> max over the points (model.py:172-175) as one node whose backward stays
     # 192-wide: vs the PyTorch-CPU op sequence on the same rows
     from ahn3_dgcnn_pytorch_amd import ops
@@ -537,7 +538,8 @@ def test_head_embed_max_rows(B, N, F, C, train, device):
     yr = torch.nn.functional.leaky_relu(bn(torch.nn.functional.linear(cr, wr)), 0.2).view(B, N, C).max(dim=1)[0]
     (yr * R).sum().backward()
     cd, wd = cat.to(device).requires_grad_(True), w.to(device).requires_grad_(True)
-    yd = ops.embed_max_rows(cd, wd, bn_d, B, N, train, 0.2)
+    stats = ops.rows_stats(cd.detach()) if (one_call and F % 4 == 0) else (None, None)
+    yd = ops.embed_max_rows(cd, wd, bn_d, B, N, train, 0.2, *stats)
     (yd * R.to(device)).sum().backward()
     np.testing.assert_allclose(yd.detach().cpu().numpy(), yr.detach().numpy(), rtol=0, atol=1e-4)
     for got, want, what in ((cd.grad, cr.grad, "gcat"), (wd.grad, wr.grad, "gw"), (bn_d.weight.grad, bn.weight.grad, "gweight"),
@@ -551,8 +553,22 @@ def test_head_embed_max_rows(B, N, F, C, train, device):
     # fixed order: a second backward gives the same bits
     cd2, wd2 = cat.to(device).requires_grad_(True), w.to(device).requires_grad_(True)
     bn_d2 = copy.deepcopy(bn).to(device)
-    (ops.embed_max_rows(cd2, wd2, bn_d2, B, N, train, 0.2) * R.to(device)).sum().backward()
-    assert torch.equal(cd2.grad, cd.grad)
+    (ops.embed_max_rows(cd2, wd2, bn_d2, B, N, train, 0.2, *stats) * R.to(device)).sum().backward()
+    assert torch.equal(cd2.grad, cd.grad) and torch.equal(wd2.grad, wd.grad)
+
+
+def test_rows_stats(device):
+    # max |x| and the column sums of cat in one pass (dgcnn_rows_stats)
+    from ahn3_dgcnn_pytorch_amd import ops
+    g = torch.Generator().manual_seed(77)
+    for rows, cols in ((1000, 192), (257, 64), (5, 4), (56000, 192)):
+        x = torch.randn(rows, cols, generator=g) * 3.0 + 1.0
+        amax, colsum = ops.rows_stats(x.to(device))
+        assert amax.view(torch.float32).item() == x.abs().max().item()
+        want = x.double().sum(0)
+        assert ((colsum.cpu().double() - want).abs() <= 1e-6 * x.double().abs().sum(0)).all()
+        a2, c2 = ops.rows_stats(x.to(device))
+        assert torch.equal(c2, colsum)
 
 
 @pytest.mark.parametrize("P,M,N", [(5000, 256, 512), (1031, 5, 256), (777, 192, 192), (64, 130, 70), (20000, 512, 192)])
