@@ -1,4 +1,4 @@
-"""Full DGCNN (3 EdgeConv blocks on HIP kernels + head on stock PyTorch-ROCm) timings:
+"""Full DGCNN (3 EdgeConv blocks + the head, all on the HIP kernels of this repository) timings:
 BASELINE.json configs[2] (eval forward, B=8 N=7000 k=30) and a synthetic training step (configs[3] shape per GPU).
 Not the headline metric (bench.py is); recorded in DESIGN.md."""
 import os, sys, time
