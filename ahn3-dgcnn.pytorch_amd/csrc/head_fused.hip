@@ -234,21 +234,7 @@ __global__ __launch_bounds__(256, OCC) void hgemm_kernel(const HGemmArgs a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
 
-    XRegs rx, rx2;
-    WRegs rw;
-    load_x(a.X, a.ldx, row0, P, 0, rx);
-    if (XMODE == X_DU) load_x(a.X2, a.ldx2, row0, P, 0, rx2);
-    load_w(a.Wh, a.Wl, K, col0, N, 0, rw);
-    for (int k0 = 0; k0 < K; k0 += GK) {
-        __syncthreads();  // the previous chunk's LDS reads are done
-        store_x<XMODE>(rx, rx2, reinterpret_cast<const float(*)[KT_MAX]>(kt), k0, sx, a.slope, xh, xl);
-        store_w(rw, wh, wl);
-        __syncthreads();
-        if (k0 + GK < K) {  // next chunk in flight during the MFMAs
-            load_x(a.X, a.ldx, row0, P, k0 + GK, rx);
-            if (XMODE == X_DU) load_x(a.X2, a.ldx2, row0, P, k0 + GK, rx2);
-            load_w(a.Wh, a.Wl, K, col0, N, k0 + GK, rw);
-        }
+    auto mfma_chunk = [&]() {
 #pragma unroll
         for (int s = 0; s < GK / 16; ++s) {
             const half8 ahi = *reinterpret_cast<const half8 *>(&xh[wave * 32 + i32][16 * s + 8 * h]);
@@ -259,6 +245,25 @@ __global__ __launch_bounds__(256, OCC) void hgemm_kernel(const HGemmArgs a)
                 const half8 blo = *reinterpret_cast<const half8 *>(&wl[nt * 32 + i32][16 * s + 8 * h]);
                 acc[nt] = mfma3(ahi, alo, bhi, blo, acc[nt]);
             }
+        }
+    };
+    {
+        XRegs rx, rx2;
+        WRegs rw;
+        load_x(a.X, a.ldx, row0, P, 0, rx);
+        if (XMODE == X_DU) load_x(a.X2, a.ldx2, row0, P, 0, rx2);
+        load_w(a.Wh, a.Wl, K, col0, N, 0, rw);
+        for (int k0 = 0; k0 < K; k0 += GK) {
+            __syncthreads();  // the previous chunk's LDS reads are done
+            store_x<XMODE>(rx, rx2, reinterpret_cast<const float(*)[KT_MAX]>(kt), k0, sx, a.slope, xh, xl);
+            store_w(rw, wh, wl);
+            __syncthreads();
+            if (k0 + GK < K) {  // next chunk in flight during the MFMAs
+                load_x(a.X, a.ldx, row0, P, k0 + GK, rx);
+                if (XMODE == X_DU) load_x(a.X2, a.ldx2, row0, P, k0 + GK, rx2);
+                load_w(a.Wh, a.Wl, K, col0, N, k0 + GK, rw);
+            }
+            mfma_chunk();
         }
     }
 
@@ -534,6 +539,9 @@ struct HWgradArgs {
     const unsigned *amax_b;  // bits of max |beff|
     float *partial;
 };
+// (Measured and dropped: thread (cq = t / 8, pq = t % 8) instead of (t % 32, t / 32), which takes the transposed 8-byte LDS
+// writes of a wave from an 8-way to a 2-way bank conflict -- SQ_LDS_BANK_CONFLICT is 78 % of the weight-gradient kernels'
+// LDS cycles -- but makes a wave's loads 8 points x 128 bytes instead of 2 points x 512: 462 us against 429 / 409.)
 struct WStage {
     float4 v[4];  // v[i] = row p0 + 4 pq + i, columns c0 + 4 cq .. + 3
 };
