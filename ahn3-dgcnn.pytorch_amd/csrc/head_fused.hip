@@ -22,6 +22,7 @@
 
 #include "dgcnn_hip.h"
 #include "hsplit.h"
+#include "prof.h"
 
 namespace dgcnn {
 void launch_sum_partials(const float *partial, int nchunk, int n, float *out, hipStream_t st);  // pointgemm.hip
@@ -1478,7 +1479,9 @@ extern "C" int dgcnn_head_tail_fwd(const dgcnn_head_tail_desc *d, const float *c
         a.Y = s.u7, a.ldy = C7;
         a.psum = d->training ? w.psum7 : nullptr, a.pext = w.pext7, a.zero = s.zmax;
         a.ncb = ceil_div(C7, GN), a.nrb = nrb;
+        prof_begin(PROF_HEAD_CONV7, st);
         hipLaunchKernelGGL((hgemm_kernel<X_RAW, E_STATS, 3>), dim3((unsigned)align_up((size_t)a.ncb * nrb, 8)), dim3(256), 0, st, a);
+        prof_end(PROF_HEAD_CONV7, st);
         hipLaunchKernelGGL(stats_finalize_kernel, dim3(ceil_div(C7, 64)), dim3(64 * FW), 0, st, w.psum7, w.pext7, nrb, P, C7,
                            d->training, d->bn7.weight, d->bn7.bias, d->bn7.running_mean, d->bn7.running_var, d->eps7,
                            d->momentum7, d->slope, s.stats7, s.zmax);
@@ -1493,7 +1496,9 @@ extern "C" int dgcnn_head_tail_fwd(const dgcnn_head_tail_desc *d, const float *c
         a.Y = s.u8, a.ldy = C8;
         a.psum = d->training ? w.psum8 : nullptr, a.pext = w.pext8, a.zero = s.zmax + 1;
         a.ncb = ceil_div(C8, GN), a.nrb = nrb;
+        prof_begin(PROF_HEAD_CONV8, st);
         hipLaunchKernelGGL((hgemm_kernel<X_BN, E_STATS, 3>), dim3((unsigned)align_up((size_t)a.ncb * nrb, 8)), dim3(256), 0, st, a);
+        prof_end(PROF_HEAD_CONV8, st);
         hipLaunchKernelGGL(stats_finalize_kernel, dim3(ceil_div(C8, 64)), dim3(64 * FW), 0, st, w.psum8, w.pext8, nrb, P, C8,
                            d->training, d->bn8.weight, d->bn8.bias, d->bn8.running_mean, d->bn8.running_var, d->eps8,
                            d->momentum8, d->slope, s.stats8, s.zmax + 1);
@@ -1567,8 +1572,10 @@ extern "C" int dgcnn_head_tail_bwd(const dgcnn_head_tail_desc *d, const float *c
         a.ec[0] = mean7, a.ec[1] = rstd7, a.ec[2] = sc7, a.ec[3] = sh7;
         a.pdv = w.pdv7, a.oa = w.oa7, a.ob = w.ob7;
         a.ncb = ceil_div(C7, GN), a.nrb = nrb;
+        prof_begin(PROF_HEAD_DZ7, st);
         if (occ3()) hipLaunchKernelGGL((hgemm_kernel<X_DU, E_DV, 3>), dim3((unsigned)align_up((size_t)a.ncb * nrb, 8)), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((hgemm_kernel<X_DU, E_DV, 2>), dim3((unsigned)align_up((size_t)a.ncb * nrb, 8)), dim3(256), 0, st, a);
+        prof_end(PROF_HEAD_DZ7, st);
     }
     {   // dW8 = du8^T z7: both operands formed at the load
         HWgradArgs a{};
@@ -1585,8 +1592,10 @@ extern "C" int dgcnn_head_tail_bwd(const dgcnn_head_tail_desc *d, const float *c
         a.partial = w.wpart;
         const int nch = ceil_div(P, a.chunk);
         const dim3 grid((unsigned)align_up((size_t)ceil_div(C8, 128) * a.ntiles_n * nch, 8));
+        prof_begin(PROF_HEAD_DW8, st);
         if (occ3()) hipLaunchKernelGGL((hwgrad_kernel<A_DU, B_BN, 3>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((hwgrad_kernel<A_DU, B_BN, 2>), grid, dim3(256), 0, st, a);
+        prof_end(PROF_HEAD_DW8, st);
         launch_sum_partials(w.wpart, nch, C8 * C7, g->gw8, st);
     }
     hipLaunchKernelGGL(bwd_finalize_slots_kernel, dim3(ceil_div(C7, 64)), dim3(64 * FW), 0, st, w.pdv7, nrb, d->B, d->N, C7,
@@ -1600,8 +1609,10 @@ extern "C" int dgcnn_head_tail_bwd(const dgcnn_head_tail_desc *d, const float *c
         a.slope = d->slope;
         a.Y = g->gcat, a.ldy = g->ldgcat;
         a.ncb = ceil_div(F, GN), a.nrb = nrb;
+        prof_begin(PROF_HEAD_DCAT, st);
         if (occ3()) hipLaunchKernelGGL((hgemm_kernel<X_DU, E_PLAIN, 3>), dim3((unsigned)align_up((size_t)a.ncb * nrb, 8)), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((hgemm_kernel<X_DU, E_PLAIN, 2>), dim3((unsigned)align_up((size_t)a.ncb * nrb, 8)), dim3(256), 0, st, a);
+        prof_end(PROF_HEAD_DCAT, st);
     }
     {   // dW7c = du7^T cat
         HWgradArgs a{};
@@ -1617,8 +1628,10 @@ extern "C" int dgcnn_head_tail_bwd(const dgcnn_head_tail_desc *d, const float *c
         a.partial = w.wpart;
         const int nch = ceil_div(P, a.chunk);
         const dim3 grid((unsigned)align_up((size_t)ceil_div(C7, 128) * a.ntiles_n * nch, 8));
+        prof_begin(PROF_HEAD_DW7, st);
         if (occ3()) hipLaunchKernelGGL((hwgrad_kernel<A_DU, B_RAW, 3>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((hwgrad_kernel<A_DU, B_RAW, 2>), grid, dim3(256), 0, st, a);
+        prof_end(PROF_HEAD_DW7, st);
         launch_sum_partials(w.wpart, nch, C7 * F, g->gw7c, st);
     }
     DG_CHECK_LAUNCH("dgcnn_head_tail_bwd");
@@ -1751,7 +1764,9 @@ extern "C" int dgcnn_embed_fwd(const float *cat, int ldc, const float *w, int ld
         a.psum = training ? ws.psum : nullptr;
         a.keys = ws.keys, a.gamma = bn->weight;
         a.ncb = ceil_div(C, GN), a.nrb = nrb;
+        prof_begin(PROF_HEAD_CONV6, st);
         hipLaunchKernelGGL((hgemm_kernel<X_RAW, E_COLRED, 3>), dim3((unsigned)align_up((size_t)a.ncb * nrb, 8)), dim3(256), 0, st, a);
+        prof_end(PROF_HEAD_CONV6, st);
     }
     launch_colstats_finalize(ws.psum, nrb, P, C, training, bn, eps, momentum, stats, st);
     launch_colmax_finish(ws.keys, stats, B, C, slope, g, arg, uwin, st);

@@ -13,6 +13,14 @@ enum ProfRegion {
     PROF_EDGE_RGATHER,    // edge_rgather_kernel (both launches): backward gather over the reverse kNN graph
     PROF_EDGE_MLP_FWD,    // edge_mlp_fwd16_kernel (+ its idle fp32 fallback): second 64 -> 64 convolution of a two-stage block, forward
     PROF_EDGE_MLP_BWD,    // edge_mlp_bwd16_kernel (+ its idle fp32 fallback): its backward (recompute, weight and input gradients, dv1)
+    // the head, head_fused.hip:
+    PROF_HEAD_CONV6,      // hgemm<RAW, COLRED>: conv6 -> bn6 statistics -> max over the points (nothing stored)
+    PROF_HEAD_CONV7,      // hgemm<RAW, STATS>: u7 = cat W7c^T + add7, BatchNorm-7 column sums
+    PROF_HEAD_CONV8,      // hgemm<BN, STATS>: u8 = LReLU(BN7(u7)) W8^T, BatchNorm-8 column sums
+    PROF_HEAD_DZ7,        // hgemm<DU, DV>: dL/dz7 = du8 W8 -> dv7, BatchNorm-7 backward sums
+    PROF_HEAD_DCAT,       // hgemm<DU, PLAIN>: dL/dcat = du7 W7c
+    PROF_HEAD_DW8,        // hwgrad<DU, BN>: dW8 = du8^T z7
+    PROF_HEAD_DW7,        // hwgrad<DU, RAW>: dW7c = du7^T cat
     PROF_NREGION
 };
 

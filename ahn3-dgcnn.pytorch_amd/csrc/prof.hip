@@ -17,7 +17,8 @@ struct ProfState {
 } g_prof;
 const char *const kNames[PROF_NREGION] = {"knn_bound16s_kernel", "knn_filter16_kernel", "knn_refine_kernel",
                                           "edge_reduce_kernel", "edge_rgather_kernel", "edge_mlp_fwd_kernel",
-                                          "edge_mlp_bwd_kernel"};
+                                          "edge_mlp_bwd_kernel", "head_conv6_kernel", "head_conv7_kernel", "head_conv8_kernel",
+                                          "head_dz7_kernel", "head_dcat_kernel", "head_dw8_kernel", "head_dw7_kernel"};
 }  // namespace
 
 void prof_begin(int region, hipStream_t st)

@@ -493,7 +493,36 @@ def run_train(args, rank, world, dev, steps, warmup, with_cpu):
                                 "dgrad + wgrad of conv2 / conv4 per edge, 2 x 2 E 64 64 flops per launch (the kernel also "
                                 "recomputes the forward product); each executed as 3 split-fp16 products on fp16 MFMA"),
     }
-    kernels = kernel_entries(regions, work, {})
+    # the head's products (head_fused.hip): fp32 rows in and out, so their algorithmic work is bytes --
+    # what each has to read and write once -- against the HBM peak; conv6 stores nothing and is a matrix product
+    Pl, F_, C6, C7, C8 = Bl * N, 192, 1024, 512, 256
+    work.update({
+        "head_conv6_kernel": ("mfma", 2.0 * Pl * F_ * C6, PEAK_F16_MFMA_TFLOPS,
+                              "conv6 + bn6 statistics + max over the points, 2 P 192 1024 flops (3 split-fp16 products executed); "
+                              "the [P, 1024] product is never stored"),
+        "head_conv7_kernel": ("hbm", 4.0 * Pl * (F_ + C7), PEAK_HBM_GBS, "reads cat [P, 192], writes u7 [P, 512]; BatchNorm-7 sums in the epilogue"),
+        "head_conv8_kernel": ("hbm", 4.0 * Pl * (C7 + C8), PEAK_HBM_GBS, "reads u7 (BatchNorm-7 + LeakyReLU at the operand load), writes u8 [P, 256]"),
+        "head_dz7_kernel": ("hbm", 4.0 * Pl * (2 * C8 + 2 * C7), PEAK_HBM_GBS,
+                            "reads dv8, u8 (du8 formed at the load) and u7, writes dv7 [P, 512]; BatchNorm-7 backward sums in the epilogue"),
+        "head_dcat_kernel": ("hbm", 4.0 * Pl * (2 * C7 + F_), PEAK_HBM_GBS, "reads dv7, u7, writes dL/dcat [P, 192]"),
+        "head_dw8_kernel": ("hbm", 4.0 * Pl * (2 * C8 + C7), PEAK_HBM_GBS, "reads dv8, u8, u7 once (a contraction over the points: [256, 512] out)"),
+        "head_dw7_kernel": ("hbm", 4.0 * Pl * (2 * C7 + F_), PEAK_HBM_GBS, "reads dv7, u7, cat once ([512, 192] out)"),
+    })
+    head_traffic = {}
+    tpath = os.path.join(ROOT, "profiles", "r3_20_head_tail_traffic.json")
+    if (Bl, N) == (32, 7000) and os.path.exists(tpath):   # PMC passes of this shape (scripts/pmc_head_tail.sh), committed
+        with open(tpath) as f:
+            kk = json.load(f)["kernels"]
+        for region, pat in (("head_conv7_kernel", "hgemm_kernel<0, 1"), ("head_conv8_kernel", "hgemm_kernel<1, 1"),
+                            ("head_dz7_kernel", "hgemm_kernel<2, 2"), ("head_dcat_kernel", "hgemm_kernel<2, 0"),
+                            ("head_dw8_kernel", "hwgrad_kernel<2, 1"), ("head_dw7_kernel", "hwgrad_kernel<2, 0")):
+            for name, e in kk.items():
+                if name.startswith(pat):
+                    head_traffic[region] = e["hbm_MB"] * 1e6
+    kernels = kernel_entries(regions, work, head_traffic)
+    for e in kernels:
+        if "traffic_source" in e:
+            e["traffic_source"] = "profiles/r3_20_head_tail_traffic.json (rocprofv3 --pmc passes of scripts/bench_head_tail.py at this shape, committed; not re-measured in this run)"
     step_flops = 12.04e6 * Bl * N   # 12.04 MFLOP per point for the full training step
     out = {
         "metric": "DGCNN training-step points/sec (global B=%d,N=%d,k=%d)" % (Bg, N, k),
