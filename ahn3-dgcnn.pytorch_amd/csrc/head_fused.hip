@@ -1391,8 +1391,10 @@ static int check_desc(const dgcnn_head_tail_desc *d, const char *who, bool param
     DG_REQUIRE(d->B > 0 && d->N >= GM && d->B <= FW * SLOT_B, "%s: needs 1 <= B <= %d and N >= %d (B=%d N=%d)", who, FW * SLOT_B, GM,
                d->B, d->N);
     DG_REQUIRE((size_t)d->B * d->N < ((size_t)1 << 23), "%s: more than 2^23 points", who);
-    DG_REQUIRE(d->F > 0 && d->F % 32 == 0 && d->C7 > 0 && d->C7 % 32 == 0 && d->C8 > 0 && d->C8 % 32 == 0 && d->C8 <= 1024,
-               "%s: F, C7, C8 must be multiples of 32 (C8 <= 1024): F=%d C7=%d C8=%d", who, d->F, d->C7, d->C8);
+    DG_REQUIRE(d->F > 0 && d->F % 32 == 0 && d->C7 > 0 && d->C7 % 32 == 0 && d->C8 > 0 && d->C8 % 32 == 0 && d->C7 <= KT_MAX &&
+                   d->C8 <= KT_MAX,
+               "%s: F, C7, C8 must be multiples of 32 (C7, C8 <= %d: the per-k constants of a product live in LDS): F=%d C7=%d C8=%d",
+               who, KT_MAX, d->F, d->C7, d->C8);
     DG_REQUIRE(d->NC >= 1 && d->NC <= CLS_MAX, "%s: 1 <= classes <= %d (NC=%d)", who, CLS_MAX, d->NC);
     DG_REQUIRE(d->ldcat >= d->F && d->ldcat % 4 == 0 && d->ldw7 >= d->F && d->ldw7 % 4 == 0, "%s: ldcat / ldw7 must be multiples of 4 and >= F", who);
     DG_REQUIRE(d->p_drop >= 0.0f && d->p_drop < 1.0f, "%s: dropout probability %g outside [0, 1)", who, (double)d->p_drop);

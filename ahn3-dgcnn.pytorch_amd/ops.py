@@ -750,7 +750,7 @@ class _HeadTail(torch.autograd.Function):
 def head_tail_supported(B, N, F_, C7, C8, NC):
     """shapes dgcnn_head_tail_* takes (include/dgcnn_hip.h); others go through the per-layer operators"""
     return (N >= 128 and 1 <= B <= 64 and B * N < (1 << 23) and F_ % 32 == 0 and C7 % 32 == 0 and C8 % 32 == 0
-            and C8 <= 1024 and 1 <= NC <= 8)
+            and C7 <= 1024 and C8 <= 1024 and 1 <= NC <= 8)
 
 
 def head_tail_rows(cat, add7, w7c, bn7, w8, bn8, w9, B, N, training, slope=0.2, p_drop=0.0, amax_cat=None):

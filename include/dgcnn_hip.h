@@ -269,7 +269,7 @@ int dgcnn_embed_max_bwd_scatter(const int32_t *arg, const float *s, const float 
  * Dropout: element (p, k) is kept when dgcnn_dropout_mask says so for (seed, p_drop) -- a counter-based generator, the
  * backward regenerates the mask from the seed; survivors are scaled by the reciprocal of the realised keep probability
  * (a multiple of 2^-16).
- * Limits: F, C7, C8 multiples of 32, C8 <= 1024, NC <= 8, N >= 128, B <= 64, B N < 2^23; 16-byte aligned rows.
+ * Limits: F, C7, C8 multiples of 32, C7 and C8 <= 1024, NC <= 8, N >= 128, B <= 64, B N < 2^23; 16-byte aligned rows.
  * saved: opaque, forward -> backward (u7, u8, the statistics, this step's weight planes).  Every gradient is
  * OVERWRITTEN; all reductions have a fixed association (bit-stable). */
 typedef struct dgcnn_head_tail_desc {
@@ -366,7 +366,8 @@ int dgcnn_comm_broadcast_f32(dgcnn_comm *comm, float *buf, size_t count, int roo
 /* ---- measurement hook (bench.py) ----------------------------------------------------------------------
  * HIP events around the large kernels of the path, recorded on the stream each kernel is launched on.  Regions
  * (dgcnn_profile_region_name): the fp16 threshold pass, the fp16 filter and the exact refine of dgcnn_knn, the
- * forward gather/reduce pass and the backward reverse gather of dgcnn_edgeconv_*.  enable(1) resets the sample
+ * forward gather/reduce pass, the backward reverse gather and the second convolution's two kernels of dgcnn_edgeconv_*,
+ * and the seven products of the head (dgcnn_embed_fwd, dgcnn_head_tail_fwd / _bwd).  enable(1) resets the sample
  * rings; mean_ms(region) returns the mean time of the samples recorded since (call it after the stream has been
  * synchronised; at most 256 samples per region are kept).  enable(0) stops recording and keeps the samples,
  * resume() continues without resetting them (bench.py samples every few steps: an event record costs a few
