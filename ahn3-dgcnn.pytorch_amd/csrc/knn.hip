@@ -1523,7 +1523,10 @@ __global__ __launch_bounds__(256) void knn_filter32_kernel(const float *__restri
     }
 }
 
-// One wave = one 32-row block: exact pd of every listed survivor, selection, output.
+// One wave = one 32-row block (CAP = 64: k <= 32) or one HALF of it (CAP = 128: k <= 64 -- 128 keys per row are 32 KB for
+// 32 rows, three waves per CU, and the pass is bound by the latency of its row gathers: two waves per block, each taking
+// the list entries of its 16 rows -- the other half's entries are inert lanes of a batch -- bring seven to a CU:
+// knn_refine<64, 128> 1.99 -> 1.52 ms, <4, 128> 0.76 -> 0.52 ms at B = 8, N = 32768, k = 64): exact pd of every listed survivor, selection, output.
 template <int CP, int CAP>
 __global__ __launch_bounds__(64) void knn_refine_kernel(const float *__restrict__ x, const float *__restrict__ xx,
                                                         const unsigned *__restrict__ lists,
@@ -1536,20 +1539,23 @@ __global__ __launch_bounds__(64) void knn_refine_kernel(const float *__restrict_
     // compacted to its best k).  With the query rows that is 20.7 KB per wave at C = 64: 7 row blocks per CU,
     // so all 1760 row blocks of B = 8, N = 7000 are resident in one round.
     constexpr int STORE = CAP == 64 ? 48 : CAP;
-    __shared__ u64 keys[32][STORE];
-    __shared__ int cnts[32];
-    __shared__ u64 tkeys[32];  // key of the k-th best of a compacted row: later offers must beat it as KEYS (the list
-                               // is not index-ordered inside a chunk of four tiles, so an equal pd with a lower
-                               // index can arrive after the compaction and must still win)
-    __shared__ float xq[32][XS];
-    __shared__ float xxq[32];
+    constexpr int HALVES = CAP == 64 ? 1 : 2, ROWS = 32 / HALVES;  // rows of this wave
+    constexpr unsigned INERT = 0xffffffffu;                        // a lane without an entry of this wave's rows
+    __shared__ u64 keys[ROWS][STORE];
+    __shared__ int cnts[ROWS];
+    __shared__ u64 tkeys[ROWS];  // key of the k-th best of a compacted row: later offers must beat it as KEYS (the list
+                                 // is not index-ordered inside a chunk of four tiles, so an equal pd with a lower
+                                 // index can arrive after the compaction and must still win)
+    __shared__ float xq[ROWS][XS];
+    __shared__ float xxq[ROWS];
 
     const int lane = threadIdx.x;
-    const int b = blockIdx.x % B, rb = blockIdx.x / B;
+    const int half = HALVES == 2 ? (int)blockIdx.x & 1 : 0, bid = (int)blockIdx.x / HALVES;
+    const int b = bid % B, rb = bid / B;
     const int ntiles = Npad / 32;
     const int wid = b * ntiles + rb;
     if (rbflag[wid]) return;  // the exact fp32 kernel recomputes this row block
-    const int q0 = rb * 32;
+    const int q0 = rb * 32 + half * ROWS;  // first row of this wave
     const float *xxb = xx + (size_t)b * Npad;
     const float *xraw = x + (size_t)b * N * C;
     // the survivor list comes in `parts` segments (one per candidate part of the filter)
@@ -1562,11 +1568,11 @@ __global__ __launch_bounds__(64) void knn_refine_kernel(const float *__restrict_
     for (int pp = 0; pp < KNN_MAXPARTS; ++pp) ncum[pp + 1] = ncum[pp] + (pp < parts ? lcount[KNN_MAXPARTS * wid + pp] : 0);
     const int n = ncum[KNN_MAXPARTS];
 
-    for (int e = lane; e < 32 * CP; e += 64) {
+    for (int e = lane; e < ROWS * CP; e += 64) {
         const int r = e / CP, c = e % CP;
         xq[r][c] = (q0 + r < N && c < C) ? xraw[(size_t)(q0 + r) * C + c] : 0.0f;
     }
-    if (lane < 32) {
+    if (lane < ROWS) {
         xxq[lane] = xxb[q0 + lane];
         cnts[lane] = 0;
         tkeys[lane] = 0ull;
@@ -1578,16 +1584,18 @@ __global__ __launch_bounds__(64) void knn_refine_kernel(const float *__restrict_
     constexpr int NV = CP / 4;  // float4 per candidate row
     auto entry = [&](int base) -> unsigned {
         const int e = base + lane;
-        if (e >= n) return 0u;
+        if (e >= n) return INERT;
         int pp = 0;
 #pragma unroll
         for (int q = 1; q < KNN_MAXPARTS; ++q) pp += e >= ncum[q] ? 1 : 0;
         int before = 0;
 #pragma unroll
         for (int q = 1; q < KNN_MAXPARTS; ++q) before = e >= ncum[q] ? ncum[q] : before;
-        return list[pp * listcap + (e - before)];
+        const unsigned v = list[pp * listcap + (e - before)];
+        return (HALVES == 2 && (int)(v >> 31) != half) ? INERT : v;  // (bits 31..27 = the row inside the 32-row block)
     };
-    auto fetch = [&](unsigned qe, float4(&v)[NV], float &yy) {
+    auto fetch = [&](unsigned qe_, float4(&v)[NV], float &yy) {
+        const unsigned qe = qe_ == INERT ? 0u : qe_;  // inert lanes read candidate 0 (one address for all of them)
         const float *xl = xraw + (size_t)(qe & 0x7ffffffu) * C;
         yy = xxb[qe & 0x7ffffffu];
 #pragma unroll
@@ -1599,11 +1607,11 @@ __global__ __launch_bounds__(64) void knn_refine_kernel(const float *__restrict_
     float yc = 0.0f, yn = 0.0f;
     if (vec) fetch(qe_c, vc, yc);
     for (int base = 0; base < n; base += 64) {
-        const bool act = base + lane < n;
-        const unsigned qe = qe_c;
+        const bool act = qe_c != INERT;
+        const unsigned qe = act ? qe_c : 0u;
         const unsigned qe_nn = entry(base + 128);
         if (vec) fetch(qe_n, vn, yn);
-        const int row = (int)(qe >> 27), cand = (int)(qe & 0x7ffffffu);
+        const int row = (int)(qe >> 27) & (ROWS - 1), cand = (int)(qe & 0x7ffffffu);
         float dot = 0.0f, ycand;
         if (vec) {
             ycand = yc;
@@ -1655,7 +1663,7 @@ __global__ __launch_bounds__(64) void knn_refine_kernel(const float *__restrict_
     // fewer than k candidates in some row: the filter threshold was not a lower bound (cannot happen
     // while the bounds hold) -> hand the row block to the exact kernel
     const int need = k < N ? k : N;
-    const bool bad = lane < 32 && q0 + lane < N && cnts[lane] < need;
+    const bool bad = lane < ROWS && q0 + lane < N && cnts[lane] < need;
     if (__ballot(bad)) {
         if (lane == 0) rbflag[wid] = 1;
         return;
@@ -1714,7 +1722,7 @@ __global__ __launch_bounds__(64) void knn_refine_kernel(const float *__restrict_
                 if (g < k) out[g] = (int32_t)(0xffffffffu - (unsigned)w[g]);
         }
     } else {
-        for (int row = 0; row < 32; ++row) {
+        for (int row = 0; row < ROWS; ++row) {
             int c = cnts[row];
             c = c < STORE ? c : STORE;
             (void)compact_row<CAP, STORE>(&keys[row][0], c, k, lane);
@@ -1807,9 +1815,9 @@ static void knn_f16_launch(int cap, int parts, const KnnWs &w, const float *x, i
     if (cap == 64)
         hipLaunchKernelGGL((knn_refine_kernel<CP, 64>), grid, block, 0, st, x, w.xx, w.lists, w.lcount, w.rbflag, B, N, C,
                            Npad, k, parts, idx);
-    else
-        hipLaunchKernelGGL((knn_refine_kernel<CP, 128>), grid, block, 0, st, x, w.xx, w.lists, w.lcount, w.rbflag, B, N, C,
-                           Npad, k, parts, idx);
+    else  // (two waves per row block: knn_refine_kernel)
+        hipLaunchKernelGGL((knn_refine_kernel<CP, 128>), dim3(2 * grid.x), block, 0, st, x, w.xx, w.lists, w.lcount, w.rbflag, B,
+                           N, C, Npad, k, parts, idx);
     prof_end(PROF_KNN_REFINE, st);
 }
 
@@ -1923,8 +1931,8 @@ extern "C" int dgcnn_knn(const float *x, int B, int N, int C, int k, int32_t *id
         prof_end(PROF_KNN_FILTER, st);
         prof_begin(PROF_KNN_REFINE, st);
 #define DG_REFINE(CP_, CAP_)                                                                                          \
-    hipLaunchKernelGGL((knn_refine_kernel<CP_, CAP_>), rgrid, dim3(64), 0, st, x, w.xx, w.lists, w.lcount, w.rbflag, B, \
-                       N, C, Npad, k, fparts, idx)
+    hipLaunchKernelGGL((knn_refine_kernel<CP_, CAP_>), dim3(rgrid.x * (CAP_ == 64 ? 1 : 2)), dim3(64), 0, st, x, w.xx, w.lists, \
+                       w.lcount, w.rbflag, B, N, C, Npad, k, fparts, idx)
         if (CP == 4) {
             if (cap == 64) DG_REFINE(4, 64);
             else DG_REFINE(4, 128);

@@ -203,3 +203,17 @@ def test_head_tail_is_bit_stable():
 
 def test_head_tail_at_the_benchmark_size():
     run_case(8, 7000, True, 0.5, seed=13, strict=False)
+
+
+def test_head_tail_randomised_configurations():
+    # shapes, class counts, dropout rates, input scales and offsets drawn at random (fixed seed); small enough for the strict
+    # (near-tie free) comparison
+    import random
+    rnd = random.Random(20261005)
+    for case in range(10):
+        B = rnd.choice([1, 2, 3, 4])
+        N = rnd.choice([128, 129, 150, 200, 255, 256, 300])
+        if B * N > 700:
+            N = max(128, 700 // B)
+        run_case(B, N, rnd.random() < 0.7, rnd.choice([0.0, 0.1, 0.5, 0.8]), seed=50 + case, NC=rnd.choice([2, 3, 5, 7, 8]),
+                 cat_scale=10.0 ** rnd.uniform(-2, 2), cat_shift=rnd.choice([0.0, 0.0, 3.0, -20.0]))
