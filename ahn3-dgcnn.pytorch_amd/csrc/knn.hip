@@ -1527,7 +1527,7 @@ __global__ __launch_bounds__(256) void knn_filter32_kernel(const float *__restri
 // 32 rows, three waves per CU, and the pass is bound by the latency of its row gathers: two waves per block, each taking
 // the list entries of its 16 rows -- the other half's entries are inert lanes of a batch -- bring seven to a CU:
 // knn_refine<64, 128> 1.99 -> 1.52 ms, <4, 128> 0.76 -> 0.52 ms at B = 8, N = 32768, k = 64): exact pd of every listed survivor, selection, output.
-template <int CP, int CAP>
+template <int CP, int CAP, int HALVES_ = (CAP == 64 ? 1 : 2)>
 __global__ __launch_bounds__(64) void knn_refine_kernel(const float *__restrict__ x, const float *__restrict__ xx,
                                                         const unsigned *__restrict__ lists,
                                                         const int *__restrict__ lcount, int *__restrict__ rbflag,
@@ -1539,7 +1539,7 @@ __global__ __launch_bounds__(64) void knn_refine_kernel(const float *__restrict_
     // compacted to its best k).  With the query rows that is 20.7 KB per wave at C = 64: 7 row blocks per CU,
     // so all 1760 row blocks of B = 8, N = 7000 are resident in one round.
     constexpr int STORE = CAP == 64 ? 48 : CAP;
-    constexpr int HALVES = CAP == 64 ? 1 : 2, ROWS = 32 / HALVES;  // rows of this wave
+    constexpr int HALVES = HALVES_, ROWS = 32 / HALVES;  // rows of this wave
     constexpr unsigned INERT = 0xffffffffu;                        // a lane without an entry of this wave's rows
     __shared__ u64 keys[ROWS][STORE];
     __shared__ int cnts[ROWS];
@@ -1675,11 +1675,12 @@ __global__ __launch_bounds__(64) void knn_refine_kernel(const float *__restrict_
         // against 32 wave-wide sorts of ~250.
         static_assert(STORE == 48, "two lanes x 24 keys");
         const int h = lane >> 5, j = lane & 31;
-        int c = cnts[j];
+        const int jr = j < ROWS ? j : 0;  // (two waves per block: lanes of rows this wave does not own sort zeros)
+        int c = j < ROWS ? cnts[jr] : 0;
         c = c < STORE ? c : STORE;
         u64 v[32];
 #pragma unroll
-        for (int i = 0; i < 24; ++i) v[i] = h * 24 + i < c ? keys[j][h * 24 + i] : 0ull;
+        for (int i = 0; i < 24; ++i) v[i] = h * 24 + i < c ? keys[jr][h * 24 + i] : 0ull;
 #pragma unroll
         for (int i = 24; i < 32; ++i) v[i] = 0ull;
         auto cex = [](u64 &hi, u64 &lo) {  // compare-exchange: hi >= lo afterwards
@@ -1715,7 +1716,7 @@ __global__ __launch_bounds__(64) void knn_refine_kernel(const float *__restrict_
                 if ((i ^ stride) > i) cex(w[i], w[i ^ stride]);
         }
         const int q = q0 + j;
-        if (h == 0 && q < N) {
+        if (h == 0 && j < ROWS && q < N) {
             int32_t *out = idx + ((size_t)b * N + q) * k;
 #pragma unroll
             for (int g = 0; g < 32; ++g)
@@ -1812,6 +1813,8 @@ static void knn_f16_launch(int cap, int parts, const KnnWs &w, const float *x, i
                        st, w.xh, w.xxc, w.tau0, w.eps, w.bmax, B, Npad, parts, w.lists, w.lcount, w.rbflag);
     prof_end(PROF_KNN_FILTER, st);
     prof_begin(PROF_KNN_REFINE, st);
+    // (two waves per block for k <= 32 as well -- knn_refine_kernel<CP, 64, 2> -- measured: 125 us against 80 at B = 8,
+    // N = 7000: at 21 KB per wave that variant is not short of resident waves, and half-inert batches double its work)
     if (cap == 64)
         hipLaunchKernelGGL((knn_refine_kernel<CP, 64>), grid, block, 0, st, x, w.xx, w.lists, w.lcount, w.rbflag, B, N, C,
                            Npad, k, parts, idx);
