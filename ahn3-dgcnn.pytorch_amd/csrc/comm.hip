@@ -32,7 +32,8 @@ struct RcclApi {
     ncclResult_t (*GetVersion)(int *) = nullptr;
 };
 
-// 0 = ok; the library stays mapped for the life of the process
+// 0 = ok; the library stays mapped for the life of the process.  (Called from the thread that drives the GPU: one process
+// per GPU, one thread per process is the deployment model; the first call is not guarded against a concurrent one.)
 int rccl_api(const RcclApi **out)
 {
     static RcclApi api;
@@ -57,7 +58,10 @@ int rccl_api(const RcclApi **out)
         }
         state = ok ? 1 : -1;
     }
-    if (state != 1) DG_FAIL("dgcnn_comm: librccl.so.1 could not be loaded (%s)", dlerror() ? dlerror() : "symbol missing");
+    if (state != 1) {
+        const char *why = dlerror();  // (one call: it hands the message over and clears it)
+        DG_FAIL("dgcnn_comm: librccl.so.1 could not be loaded (%s)", why ? why : "a symbol is missing");
+    }
     *out = &api;
     return 0;
 }

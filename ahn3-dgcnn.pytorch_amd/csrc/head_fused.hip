@@ -101,7 +101,8 @@ struct HGemmArgs {
     // column (decreasing where gamma < 0: flip), so the extreme of u is the winner of the max; the first row among equals
     unsigned long long *keys;  // [nbatch][N], zero at launch
     const float *gamma;
-    // E_DV: Y = (acc) . LReLU'(ec_sc U + ec_sh): the gradient wrt the pre-BatchNorm... of the PREVIOUS layer's activation
+    // E_DV: the product is dL/dz of the PREVIOUS layer; Y = acc . LReLU'(ec_sc U + ec_sh) = its dv (U = that layer's
+    // pre-activation, ec = its statistics), with the BatchNorm backward sums of that layer as column sums
     const float *U;
     int ldu;
     const float *ec[4];  // per column n: mean, rstd, sc, sh
