@@ -59,8 +59,9 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", choices=("block", "train"), default="block")
-    ap.add_argument("--profile-every", type=int, default=5,
-                    help="record the per-kernel HIP events on every n-th timed step (an event record costs GPU time)")
+    ap.add_argument("--profile-every", type=int, default=0,
+                    help="record the per-kernel HIP events on every n-th timed step (an event record costs GPU time: some "
+                         "twenty records per sampled step); 0 = two (up to 30 steps) or three sampled steps, spread over the timed region")
     ap.add_argument("--stages", type=int, default=1, choices=(1, 2),
                     help="block workload: 1 = conv5-shaped block (128->64); 2 = conv3+conv4-shaped block (128->64->64)")
     ap.add_argument("--batch", type=int, default=None,
@@ -157,6 +158,13 @@ def max_over_ranks(value, dev):
     t = torch.tensor([value], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def sample_stride(args, steps):
+    """every how many timed steps the per-kernel events are recorded"""
+    if args.profile_every > 0:
+        return args.profile_every
+    return max(1, -(-steps // (2 if steps <= 30 else 3)))   # two sampled steps in a short run, three otherwise
 
 
 def timed_steps(step, n, every, dev):
@@ -315,7 +323,7 @@ def run_block(args, rank, world, dev):
         step(False)
     lib.dgcnn_profile_enable(1)  # reset the sample rings ...
     lib.dgcnn_profile_enable(0)  # ... recording is switched on for the sampled steps only
-    dt = timed_steps(step, args.steps, max(1, args.profile_every), dev)
+    dt = timed_steps(step, args.steps, sample_stride(args, args.steps), dev)
     knn_ms = sum(a.elapsed_time(b) for a, b in knn_events) / max(1, len(knn_events))
     regions = region_times(lib)
     dist_ms = per_step_ms(step, min(args.steps, 50))
@@ -477,7 +485,7 @@ def run_train(args, rank, world, dev, steps, warmup, with_cpu):
         step(False)
     lib.dgcnn_profile_enable(1)
     lib.dgcnn_profile_enable(0)
-    dt = timed_steps(step, steps, max(1, min(args.profile_every, steps)), dev)
+    dt = timed_steps(step, steps, sample_stride(args, steps), dev)
     regions = region_times(lib)
     ar_ms = sum(a.elapsed_time(b) for a, b in ar_events) / max(1, len(ar_events))
     dist_ms = per_step_ms(step, min(steps, 20))
