@@ -909,22 +909,30 @@ constexpr int FW = 16;
 // forward: BatchNorm1d batch statistics (or the running ones) -> stats [4][C] = mean, rstd, sc, sh; running statistics
 // updated when training; zmax <- bits of max |LReLU(BN(u))| over the whole tensor, exact: per column the activation is
 // monotone in u, so its extremes are the images of the column's extremes.
+// gridDim.y > 1 (fold_psum / fold_pext given): the launch only FOLDS -- slice y takes a contiguous run of the records and
+// leaves one folded record in the same formats -- and a second launch (gridDim.y = 1) over the gridDim.y folded records
+// finalizes: one workgroup per 64 columns reads 2.7 MB of records at B = 32 at the bandwidth of ONE CU (55 us); eight
+// slices read an eighth each.  The association stays a function of the record count.  pext may be NULL (no extrema).
 __global__ __launch_bounds__(64 * FW) void stats_finalize_kernel(const double *__restrict__ psum, const float *__restrict__ pext,
-                                                                 int nrec, int P, int C, int training,
+                                                                 int nrec_all, int P, int C, int training,
                                                                  const float *__restrict__ gamma, const float *__restrict__ beta,
                                                                  float *__restrict__ rmean, float *__restrict__ rvar, float eps,
                                                                  float momentum, float slope, float *__restrict__ stats,
-                                                                 unsigned *__restrict__ zmax)
+                                                                 unsigned *__restrict__ zmax, double *__restrict__ fold_psum,
+                                                                 float *__restrict__ fold_pext)
 {
     __shared__ double red[FW][2][64];
     __shared__ float rex[FW][2][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     const bool live = c < C;
+    const bool fold_only = gridDim.y > 1;
+    const int per = (nrec_all + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int rbeg = (int)blockIdx.y * per, nrec = rbeg + per < nrec_all ? rbeg + per : nrec_all;
     double a0 = 0.0, a1 = 0.0;
     float mn = __builtin_inff(), mx = -__builtin_inff();
     if (live) {
-        int g = wave;
+        int g = rbeg + wave;
         for (; g + 7 * FW < nrec; g += 8 * FW) {
             double va[8], vb[8];
             float ea[8], eb[8];
@@ -933,8 +941,8 @@ __global__ __launch_bounds__(64 * FW) void stats_finalize_kernel(const double *_
                 const size_t o = (size_t)(g + u * FW) * 2 * C + c;
                 va[u] = training ? psum[o] : 0.0;
                 vb[u] = training ? psum[o + C] : 0.0;
-                ea[u] = pext[o];
-                eb[u] = pext[o + C];
+                ea[u] = pext ? pext[o] : 0.0f;
+                eb[u] = pext ? pext[o + C] : 0.0f;
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -950,8 +958,8 @@ __global__ __launch_bounds__(64 * FW) void stats_finalize_kernel(const double *_
                 a0 += psum[o];
                 a1 += psum[o + C];
             }
-            mn = fminf(mn, pext[o]);
-            mx = fmaxf(mx, pext[o + C]);
+            mn = fminf(mn, pext ? pext[o] : 0.0f);
+            mx = fmaxf(mx, pext ? pext[o + C] : 0.0f);
         }
     }
     red[wave][0][lane] = a0;
@@ -967,6 +975,20 @@ __global__ __launch_bounds__(64 * FW) void stats_finalize_kernel(const double *_
         ss += red[w][1][lane];
         mn = fminf(mn, rex[w][0][lane]);
         mx = fmaxf(mx, rex[w][1][lane]);
+    }
+    if (fold_only) {
+        if (live) {
+            const size_t o = (size_t)blockIdx.y * 2 * C + c;
+            if (training) {
+                fold_psum[o] = s;
+                fold_psum[o + C] = ss;
+            }
+            if (pext) {
+                fold_pext[o] = mn;
+                fold_pext[o + C] = mx;
+            }
+        }
+        return;
     }
     float zm = 0.0f;
     if (live) {
@@ -1077,24 +1099,32 @@ __global__ __launch_bounds__(64 * FW) void bwd_finalize_kernel(const double *__r
 // wave sums in wave order; then gw, gb, cc as above and the gradient of the per-batch-element row that was added to u:
 //   gadd[b][c] = sum over the rows of b of du = sc (sum_b dv - N c1 - c2 sum_b uhat).
 constexpr int SLOT_B = 4;  // batch elements per wave: B <= 64
+// Two launches when there are many tiles (bsum given): gridDim.y = B -- workgroup (column group, b) adds up batch element b's
+// tiles into bsum [B][3][C] (the 128 waves of the one-launch form read 40 MB at B = 32: 64 us) -- then gridDim.y = 1 takes the
+// per-batch-element sums from bsum.
 __global__ __launch_bounds__(64 * FW) void bwd_finalize_slots_kernel(const double *__restrict__ pdv, int nrb, int B, int N, int C,
                                                                      int training, const float *__restrict__ stats,
                                                                      float *__restrict__ gw, float *__restrict__ gb,
                                                                      float *__restrict__ cc, unsigned *__restrict__ sb,
-                                                                     float *__restrict__ gadd)
+                                                                     float *__restrict__ gadd, double *__restrict__ bsum)
 {
     __shared__ double red[FW][2][64];
     __shared__ float scc[2][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     const bool live = c < C;
+    const bool first_level = gridDim.y > 1;  // (launched with 64 threads: wave 0 only)
     double bdv[SLOT_B], bdu[SLOT_B], buh[SLOT_B];
     double a0 = 0.0, a1 = 0.0;
 #pragma unroll
     for (int i = 0; i < SLOT_B; ++i) {
-        const int b = wave + i * FW;
+        const int b = first_level ? (i == 0 ? (int)blockIdx.y : B) : wave + i * FW;
         double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-        if (live && b < B) {
+        if (live && b < B && bsum && !first_level) {
+            s0 = bsum[((size_t)b * 3 + 0) * C + c];
+            s1 = bsum[((size_t)b * 3 + 1) * C + c];
+            s2 = bsum[((size_t)b * 3 + 2) * C + c];
+        } else if (live && b < B) {
             const int t0 = (int)(((long long)b * N) / 128);
             int t1 = (int)((((long long)(b + 1)) * N - 1) / 128);
             t1 = t1 < nrb - 1 ? t1 : nrb - 1;
@@ -1120,12 +1150,18 @@ __global__ __launch_bounds__(64 * FW) void bwd_finalize_slots_kernel(const doubl
                 }
             }
         }
+        if (first_level && live && b < B) {
+            bsum[((size_t)b * 3 + 0) * C + c] = s0;
+            bsum[((size_t)b * 3 + 1) * C + c] = s1;
+            bsum[((size_t)b * 3 + 2) * C + c] = s2;
+        }
         bdv[i] = s0;
         bdu[i] = s1;
         buh[i] = s2;
         a0 += s0;
         a1 += s1;
     }
+    if (first_level) return;
     red[wave][0][lane] = a0;
     red[wave][1][lane] = a1;
     __syncthreads();
@@ -1342,8 +1378,8 @@ static Saved saved_layout(const dgcnn_head_tail_desc *d, void *p)
 }
 static int row_blocks(const dgcnn_head_tail_desc *d) { return ceil_div(d->B * d->N, GM); }
 struct FwdWs {
-    double *psum7, *psum8;
-    float *pext7, *pext8;
+    double *psum7, *psum8, *fpsum;
+    float *pext7, *pext8, *fpext;
     size_t bytes;
 };
 static FwdWs fwd_ws(const dgcnn_head_tail_desc *d, void *p)
@@ -1355,6 +1391,9 @@ static FwdWs fwd_ws(const dgcnn_head_tail_desc *d, void *p)
     w.pext7 = c.take<float>(nrb * 2 * d->C7);
     w.psum8 = c.take<double>(nrb * 2 * d->C8);
     w.pext8 = c.take<float>(nrb * 2 * d->C8);
+    const size_t cmax = d->C7 > d->C8 ? d->C7 : d->C8;
+    w.fpsum = c.take<double>((size_t)8 * 2 * cmax);  // FIN_SLICES folded records (launch_stats_finalize)
+    w.fpext = c.take<float>((size_t)8 * 2 * cmax);
     w.bytes = c.off;
     return w;
 }
@@ -1373,7 +1412,7 @@ struct BwdWs {
     size_t zero_words;
     unsigned *oa8, *ob8, *oa7, *ob7, *sb8, *sb7;
     float *dv8, *dv7, *pdw9, *cc8, *cc7, *wpart;
-    double *pbn8, *pdv7;
+    double *pbn8, *pdv7, *bsum7;
     size_t bytes;
 };
 static BwdWs bwd_ws(const dgcnn_head_tail_desc *d, void *p)
@@ -1396,6 +1435,7 @@ static BwdWs bwd_ws(const dgcnn_head_tail_desc *d, void *p)
     w.cc8 = c.take<float>(2 * (size_t)d->C8);
     w.pdv7 = c.take<double>(nrb * 2 * 3 * d->C7);
     w.cc7 = c.take<float>(2 * (size_t)d->C7);
+    w.bsum7 = c.take<double>((size_t)d->B * 3 * d->C7);
     const size_t wp8 = (size_t)wgrad_chunks(d->C8, d->C7, (int)P) * d->C8 * d->C7, wp7 = (size_t)wgrad_chunks(d->C7, d->F, (int)P) * d->C7 * d->F;
     w.wpart = c.take<float>(wp8 > wp7 ? wp8 : wp7);
     w.bytes = c.off;
@@ -1440,6 +1480,26 @@ static bool occ3()
 {
     static const int v = getenv("DGCNN_HF_OCC") ? atoi(getenv("DGCNN_HF_OCC")) : 2;
     return v == 3;
+}
+// BatchNorm statistics from the products' records: one launch for few records, a fold over FIN_SLICES slices + the finalizer
+// for many (fold buffers: fpsum [FIN_SLICES][2][C] doubles, fpext the same in floats)
+constexpr int FIN_SLICES = 8;
+static void launch_stats_finalize(const double *psum, const float *pext, int nrec, int P, int C, int training,
+                                  const dgcnn_bn_params &bn, float eps, float momentum, float slope, float *stats, unsigned *zmax,
+                                  double *fpsum, float *fpext, hipStream_t st)
+{
+    const dim3 block(64 * FW);
+    const int gx = ceil_div(C, 64);
+    if (nrec > 256 && fpsum && (training || pext)) {
+        hipLaunchKernelGGL(stats_finalize_kernel, dim3(gx, FIN_SLICES), block, 0, st, psum, pext, nrec, P, C, training, bn.weight,
+                           bn.bias, bn.running_mean, bn.running_var, eps, momentum, slope, stats, zmax, fpsum, pext ? fpext : nullptr);
+        hipLaunchKernelGGL(stats_finalize_kernel, dim3(gx, 1), block, 0, st, (const double *)fpsum, pext ? (const float *)fpext : nullptr,
+                           FIN_SLICES, P, C, training, bn.weight, bn.bias, bn.running_mean, bn.running_var, eps, momentum, slope,
+                           stats, zmax, (double *)nullptr, (float *)nullptr);
+    } else {
+        hipLaunchKernelGGL(stats_finalize_kernel, dim3(gx, 1), block, 0, st, psum, pext, nrec, P, C, training, bn.weight, bn.bias,
+                           bn.running_mean, bn.running_var, eps, momentum, slope, stats, zmax, (double *)nullptr, (float *)nullptr);
+    }
 }
 static unsigned keep16_of(float p) { return (unsigned)((1.0 - (double)p) * 65536.0 + 0.5); }
 // the survivors' scale: the reciprocal of the keep probability the mask REALISES (a multiple of 2^-16), so that the
@@ -1501,9 +1561,8 @@ extern "C" int dgcnn_head_tail_fwd(const dgcnn_head_tail_desc *d, const float *c
         prof_begin(PROF_HEAD_CONV7, st);
         hipLaunchKernelGGL((hgemm_kernel<X_RAW, E_STATS, 3>), dim3((unsigned)align_up((size_t)a.ncb * nrb, 8)), dim3(256), 0, st, a);
         prof_end(PROF_HEAD_CONV7, st);
-        hipLaunchKernelGGL(stats_finalize_kernel, dim3(ceil_div(C7, 64)), dim3(64 * FW), 0, st, w.psum7, w.pext7, nrb, P, C7,
-                           d->training, d->bn7.weight, d->bn7.bias, d->bn7.running_mean, d->bn7.running_var, d->eps7,
-                           d->momentum7, d->slope, s.stats7, s.zmax);
+        launch_stats_finalize(w.psum7, w.pext7, nrb, P, C7, d->training, d->bn7, d->eps7, d->momentum7, d->slope, s.stats7, s.zmax,
+                              w.fpsum, w.fpext, st);
     }
     {   // u8 = LReLU(BN7(u7)) . W8^T: the activation is formed where the product loads its operand
         HGemmArgs a{};
@@ -1518,9 +1577,8 @@ extern "C" int dgcnn_head_tail_fwd(const dgcnn_head_tail_desc *d, const float *c
         prof_begin(PROF_HEAD_CONV8, st);
         hipLaunchKernelGGL((hgemm_kernel<X_BN, E_STATS, 3>), dim3((unsigned)align_up((size_t)a.ncb * nrb, 8)), dim3(256), 0, st, a);
         prof_end(PROF_HEAD_CONV8, st);
-        hipLaunchKernelGGL(stats_finalize_kernel, dim3(ceil_div(C8, 64)), dim3(64 * FW), 0, st, w.psum8, w.pext8, nrb, P, C8,
-                           d->training, d->bn8.weight, d->bn8.bias, d->bn8.running_mean, d->bn8.running_var, d->eps8,
-                           d->momentum8, d->slope, s.stats8, s.zmax + 1);
+        launch_stats_finalize(w.psum8, w.pext8, nrb, P, C8, d->training, d->bn8, d->eps8, d->momentum8, d->slope, s.stats8,
+                              s.zmax + 1, w.fpsum, w.fpext, st);
     }
     {   // logits = dropout(LReLU(BN8(u8))) . W9^T
         ClsArgs a{};
@@ -1617,8 +1675,15 @@ extern "C" int dgcnn_head_tail_bwd(const dgcnn_head_tail_desc *d, const float *c
         prof_end(PROF_HEAD_DW8, st);
         launch_sum_partials(w.wpart, nch, C8 * C7, g->gw8, st);
     }
-    hipLaunchKernelGGL(bwd_finalize_slots_kernel, dim3(ceil_div(C7, 64)), dim3(64 * FW), 0, st, w.pdv7, nrb, d->B, d->N, C7,
-                       d->training, s.stats7, g->gbn7_w, g->gbn7_b, w.cc7, w.sb7, g->gadd7);
+    if (nrb > 256) {
+        hipLaunchKernelGGL(bwd_finalize_slots_kernel, dim3(ceil_div(C7, 64), d->B), dim3(64), 0, st, w.pdv7, nrb, d->B, d->N, C7,
+                           d->training, s.stats7, g->gbn7_w, g->gbn7_b, w.cc7, w.sb7, g->gadd7, w.bsum7);
+        hipLaunchKernelGGL(bwd_finalize_slots_kernel, dim3(ceil_div(C7, 64), 1), dim3(64 * FW), 0, st, w.pdv7, nrb, d->B, d->N, C7,
+                           d->training, s.stats7, g->gbn7_w, g->gbn7_b, w.cc7, w.sb7, g->gadd7, w.bsum7);
+    } else {
+        hipLaunchKernelGGL(bwd_finalize_slots_kernel, dim3(ceil_div(C7, 64), 1), dim3(64 * FW), 0, st, w.pdv7, nrb, d->B, d->N, C7,
+                           d->training, s.stats7, g->gbn7_w, g->gbn7_b, w.cc7, w.sb7, g->gadd7, (double *)nullptr);
+    }
     {   // dL/dcat = du7 . W7c
         HGemmArgs a{};
         a.X = w.dv7, a.ldx = C7, a.X2 = s.u7, a.ldx2 = C7, a.P = P, a.K = C7, a.N = F;
@@ -1679,7 +1744,7 @@ void launch_embed_bwd_scatter(const int32_t *arg, const float *s, const float *w
                               hipStream_t st);
 namespace hf {
 struct EmbedFwdWs {
-    double *psum;
+    double *psum, *fpsum;
     unsigned long long *keys;
     Planes w;
     size_t bytes;
@@ -1690,6 +1755,7 @@ static EmbedFwdWs embed_fwd_ws(int B, int N, int F, int C, void *p)
     EmbedFwdWs w;
     w.psum = c.take<double>((size_t)ceil_div(B * N, GM) * 2 * C);
     w.keys = c.take<unsigned long long>((size_t)B * C);
+    w.fpsum = c.take<double>((size_t)8 * 2 * C);
     w.w = take_planes(c, C, F);
     w.bytes = c.off;
     return w;
@@ -1787,7 +1853,7 @@ extern "C" int dgcnn_embed_fwd(const float *cat, int ldc, const float *w, int ld
         hipLaunchKernelGGL((hgemm_kernel<X_RAW, E_COLRED, 3>), dim3((unsigned)align_up((size_t)a.ncb * nrb, 8)), dim3(256), 0, st, a);
         prof_end(PROF_HEAD_CONV6, st);
     }
-    launch_colstats_finalize(ws.psum, nrb, P, C, training, bn, eps, momentum, stats, st);
+    launch_stats_finalize(ws.psum, nullptr, nrb, P, C, training, *bn, eps, momentum, slope, stats, nullptr, ws.fpsum, nullptr, st);
     launch_colmax_finish(ws.keys, stats, B, C, slope, g, arg, uwin, st);
     DG_CHECK_LAUNCH("dgcnn_embed_fwd");
     return 0;
