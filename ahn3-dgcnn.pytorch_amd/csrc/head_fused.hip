@@ -709,64 +709,75 @@ struct ClsArgs {
 };
 constexpr int CLS_ROWS = 8, CLS_MAX = 8;
 
+// sum over the 16 lanes of a DPP row (every lane ends up with the sum): xor 1, xor 2 inside the quads, then the mirrored
+// half-row and the mirrored row
+__device__ __forceinline__ float row16_sum(float v)
+{
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+    return v;
+}
+
+// Sixteen lanes per row (lane part p of a DPP row takes the 16-byte pieces p, p + 16, .. of its row: 256 contiguous bytes
+// per row and instruction), four rows per wave instruction, sixteen rows per iteration; the NC dot products of a row are
+// folded over its sixteen lanes with four DPP additions each.  (The first form -- 64 lanes on one row, eight rows in flight
+// -- spent its time in 240 wave-wide shuffle reductions per eight rows: 98 us for 229 MB at B = 32.)
+constexpr int CLS_GROUPS = 4;  // groups of four rows per iteration
 template <int NC, bool DROP>
 __global__ __launch_bounds__(256) void cls_fwd_fused_kernel(const ClsArgs a)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int part = lane & 15, rsub = lane >> 4;
     const int nk = a.K / 4, P = a.P;
-    for (int p0 = (blockIdx.x * 4 + wave) * CLS_ROWS; p0 < P; p0 += gridDim.x * 4 * CLS_ROWS) {
-        float acc[CLS_ROWS][NC];
+    const int rows_it = 4 * CLS_GROUPS;
+    for (int p0 = (blockIdx.x * 4 + wave) * rows_it; p0 < P; p0 += gridDim.x * 4 * rows_it) {
+        float acc[CLS_GROUPS][NC];
 #pragma unroll
-        for (int r = 0; r < CLS_ROWS; ++r)
+        for (int g = 0; g < CLS_GROUPS; ++g)
 #pragma unroll
-            for (int c = 0; c < NC; ++c) acc[r][c] = 0.0f;
-        for (int q = lane; q < nk; q += 64) {
+            for (int c = 0; c < NC; ++c) acc[g][c] = 0.0f;
+        for (int q = part; q < nk; q += 16) {
+            float4 uv[CLS_GROUPS];
+#pragma unroll
+            for (int g = 0; g < CLS_GROUPS; ++g) {
+                const int p = p0 + 4 * g + rsub < P ? p0 + 4 * g + rsub : P - 1;
+                uv[g] = reinterpret_cast<const float4 *>(a.u + (size_t)p * a.K)[q];
+            }
             float4 wv[NC];
 #pragma unroll
             for (int c = 0; c < NC; ++c) wv[c] = reinterpret_cast<const float4 *>(a.w + (size_t)c * a.K)[q];
             const float4 sc = reinterpret_cast<const float4 *>(a.sc)[q], sh = reinterpret_cast<const float4 *>(a.sh)[q];
-            float4 uv[CLS_ROWS];
 #pragma unroll
-            for (int r = 0; r < CLS_ROWS; ++r) {
-                const int p = p0 + r < P ? p0 + r : P - 1;
-                uv[r] = reinterpret_cast<const float4 *>(a.u + (size_t)p * a.K)[q];
-            }
-#pragma unroll
-            for (int r = 0; r < CLS_ROWS; ++r) {
-                const int p = p0 + r < P ? p0 + r : P - 1;
+            for (int g = 0; g < CLS_GROUPS; ++g) {
+                const int p = p0 + 4 * g + rsub < P ? p0 + 4 * g + rsub : P - 1;
                 const unsigned long long mix = DROP ? drop_mix(a.seed, (unsigned long long)p * nk + q) : 0ull;
                 float d[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float z = lrelu_f(__builtin_fmaf(f4(uv[r], e), f4(sc, e), f4(sh, e)), a.slope);
+                    const float z = lrelu_f(__builtin_fmaf(f4(uv[g], e), f4(sc, e), f4(sh, e)), a.slope);
                     d[e] = DROP ? (drop_keep(mix, e, a.keep16) ? z * a.inv_keep : 0.0f) : z;
                 }
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
-                    acc[r][c] = __builtin_fmaf(d[0], wv[c].x, acc[r][c]);
-                    acc[r][c] = __builtin_fmaf(d[1], wv[c].y, acc[r][c]);
-                    acc[r][c] = __builtin_fmaf(d[2], wv[c].z, acc[r][c]);
-                    acc[r][c] = __builtin_fmaf(d[3], wv[c].w, acc[r][c]);
+                    acc[g][c] = __builtin_fmaf(d[0], wv[c].x, acc[g][c]);
+                    acc[g][c] = __builtin_fmaf(d[1], wv[c].y, acc[g][c]);
+                    acc[g][c] = __builtin_fmaf(d[2], wv[c].z, acc[g][c]);
+                    acc[g][c] = __builtin_fmaf(d[3], wv[c].w, acc[g][c]);
                 }
             }
         }
 #pragma unroll
-        for (int r = 0; r < CLS_ROWS; ++r)
+        for (int g = 0; g < CLS_GROUPS; ++g) {
+            float mine = 0.0f;
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
-                float v = acc[r][c];
-#pragma unroll
-                for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-                acc[r][c] = v;
+                const float t = row16_sum(acc[g][c]);
+                mine = part == c ? t : mine;
             }
-        if (lane < CLS_ROWS * NC) {
-            const int r = lane / NC, c = lane - r * NC;
-            float v = 0.0f;
-#pragma unroll
-            for (int rr = 0; rr < CLS_ROWS; ++rr)
-#pragma unroll
-                for (int cc = 0; cc < NC; ++cc) v = (rr == r && cc == c) ? acc[rr][cc] : v;
-            if (p0 + r < P) a.y[(size_t)(p0 + r) * NC + c] = v;
+            const int p = p0 + 4 * g + rsub;
+            if (part < NC && p < P) a.y[(size_t)p * NC + part] = mine;
         }
     }
 }
@@ -1270,8 +1281,19 @@ __global__ __launch_bounds__(256) void embed_dw_kernel(const float *__restrict__
             const int c = c0 + cc;
             if (c >= C) continue;
             float d = training ? __builtin_fmaf(coef_b[c], acc[cc], coef_a[c] * catsum[f]) : 0.0f;
-            for (int b = 0; b < B; ++b)
-                d = __builtin_fmaf(s[(size_t)b * C + c], cat[((size_t)b * N + arg[(size_t)b * C + c]) * ldc + f], d);
+            // the winners' rows, eight batch elements in flight (arg -> row is a dependent load), added in batch order
+            for (int b0 = 0; b0 < B; b0 += 8) {
+                float sv[8], xv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int b = b0 + u < B ? b0 + u : B - 1;
+                    sv[u] = s[(size_t)b * C + c];
+                    xv[u] = cat[((size_t)b * N + arg[(size_t)b * C + c]) * ldc + f];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (b0 + u < B) d = __builtin_fmaf(sv[u], xv[u], d);
+            }
             dW[(size_t)c * F + f] = d;
         }
     }
@@ -1291,13 +1313,23 @@ __global__ __launch_bounds__(256) void rows_stats_kernel(const float *__restrict
     double sm[4] = {0.0, 0.0, 0.0, 0.0};
     float m = 0.0f;
     if (c < cols)
-        for (int r = r0 + wave; r < r1; r += 4) {
-            const float4 v = *reinterpret_cast<const float4 *>(x + (size_t)r * ld + c);
-            sm[0] += (double)v.x;
-            sm[1] += (double)v.y;
-            sm[2] += (double)v.z;
-            sm[3] += (double)v.w;
-            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        for (int rr = r0 + wave; rr < r1; rr += 32) {  // eight of the wave's rows in flight, added in row order
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int r = rr + 4 * u < r1 ? rr + 4 * u : r1 - 1;
+                v[u] = *reinterpret_cast<const float4 *>(x + (size_t)r * ld + c);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (rr + 4 * u < r1) {
+                    sm[0] += (double)v[u].x;
+                    sm[1] += (double)v[u].y;
+                    sm[2] += (double)v[u].z;
+                    sm[3] += (double)v[u].w;
+                    m = fmaxf(fmaxf(m, fmaxf(fabsf(v[u].x), fabsf(v[u].y))), fmaxf(fabsf(v[u].z), fabsf(v[u].w)));
+                }
+            }
         }
 #pragma unroll
     for (int e = 0; e < 4; ++e) red[wave][4 * lane + e] = sm[e];
@@ -1588,7 +1620,7 @@ extern "C" int dgcnn_head_tail_fwd(const dgcnn_head_tail_desc *d, const float *c
         const bool drop = d->training && d->p_drop > 0.0f;
         a.keep16 = keep16_of(d->p_drop), a.inv_keep = inv_keep_of(d->p_drop), a.seed = d->seed;
         a.y = logits;
-        int grid = ceil_div(P, 4 * CLS_ROWS);
+        int grid = ceil_div(P, 4 * 4 * CLS_GROUPS);
         grid = grid > 4096 ? 4096 : grid;
         if (drop) {
             HF_CLS_DISPATCH(d->NC, hipLaunchKernelGGL((cls_fwd_fused_kernel<NCV, true>), dim3(grid), dim3(256), 0, st, a));
