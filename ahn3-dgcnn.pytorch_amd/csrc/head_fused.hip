@@ -520,6 +520,206 @@ __global__ __launch_bounds__(256, OCC) void hgemm_kernel(const HGemmArgs a)
     }
 }
 
+// ---- the same product for a SHORT contraction (K = 192: conv6 and conv7 on cat, model.py:172,181), x held in registers ----
+// hgemm_kernel gives every (row block, column block) pair a workgroup of its own: with six chunks of K the workgroup's life is
+// its start-up (first loads from HBM with nothing to overlap), six load -> split -> LDS -> product steps with one chunk of
+// look-ahead, and the epilogue; every column block splits the same x rows again (conv6: eight times).  Measured at B = 32:
+// conv6 479 us, conv7 252 us, the matrix pipe a quarter busy.  Here a workgroup owns a ROW block and walks all column blocks:
+// the x tile is read and split ONCE (all six chunks in flight together), each wave keeps the A fragments of its 32 rows in 96
+// registers, and only W -- fp16 planes, resident in L2 -- streams through a two-stage LDS ring, the next chunk in registers,
+// across the column blocks without a break.  The epilogue works in the accumulator layout (a lane owns a column of a 32-column
+// block: the column sums, extrema and keys are per-lane sequences, one exchange between the two lane halves), Y leaves as
+// 128-byte row segments.
+constexpr int RK = 192, RCH = RK / GK;
+__device__ __forceinline__ void load_w_flat(const HGemmArgs &a, int f, WRegs &r)
+{
+    const int t = f / RCH, kc = f - t * RCH;
+    load_w(a.Wh, a.Wl, RK, t * GN, a.N, kc * GK, r);
+}
+template <int EMODE>
+__global__ __launch_bounds__(256, 2) void hrow_kernel(const HGemmArgs a)
+{
+    static_assert(EMODE == E_STATS || EMODE == E_COLRED, "epilogues of the two forward products on cat");
+    __shared__ __attribute__((aligned(16))) _Float16 ring[2][2][GM][GSTR];  // [stage][plane]
+    __shared__ __attribute__((aligned(16))) double csum[4][2][GN];           // per wave: sum, sum of squares
+    __shared__ __attribute__((aligned(16))) unsigned long long cx[4][2][GN];  // E_COLRED: keys per batch-element slot; E_STATS: min, max (floats)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, i32 = lane & 31;
+    const int rb = blockIdx.x, row0 = rb * GM;
+    const int P = a.P, N = a.N;
+    const float sx = pow2_scale(__uint_as_float(*a.xmax), H_TOP);
+    if (EMODE == E_STATS && rb == 0 && threadIdx.x == 0 && a.zero) *a.zero = 0u;
+    const int total = a.ncb * RCH;  // W chunks of the walk
+
+    half8 Ah[RCH][2], Al[RCH][2];
+    WRegs rw;
+    {
+        XRegs rx[RCH];
+#pragma unroll
+        for (int c = 0; c < RCH; ++c) load_x(a.X, a.ldx, row0, P, c * GK, rx[c]);
+        load_w_flat(a, 0, rw);
+#pragma unroll
+        for (int c = 0; c < RCH; ++c) {
+            // (stage c & 1 was last read two chunks ago, before the barrier of the chunk between)
+            store_x<X_RAW>(rx[c], rx[c], nullptr, c * GK, sx, a.slope, ring[c & 1][0], ring[c & 1][1]);
+            __syncthreads();
+#pragma unroll
+            for (int s_ = 0; s_ < 2; ++s_) {
+                Ah[c][s_] = *reinterpret_cast<const half8 *>(&ring[c & 1][0][wave * 32 + i32][16 * s_ + 8 * h]);
+                Al[c][s_] = *reinterpret_cast<const half8 *>(&ring[c & 1][1][wave * 32 + i32][16 * s_ + 8 * h]);
+            }
+        }
+    }
+    store_w(rw, ring[0][0], ring[0][1]);  // (stage 0 held x chunk 4: read before the barrier of chunk 5)
+    load_w_flat(a, 1, rw);
+    __syncthreads();
+
+    const float isx = 1.0f / sx;
+    const int wrow0 = row0 + wave * 32;
+    const int b0 = row0 / a.rows_per_batch, rsplit = (b0 + 1) * a.rows_per_batch;
+    const bool two = rsplit < P && row0 + GM > rsplit;  // the tile reaches into a second batch element
+    for (int t = 0; t < a.ncb; ++t) {
+        f32x16 acc[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
+#pragma unroll
+        for (int kc = 0; kc < RCH; ++kc) {
+            const int f = t * RCH + kc;
+            _Float16(*wh)[GSTR] = ring[kc & 1][0], (*wl)[GSTR] = ring[kc & 1][1];
+            if (f + 1 < total) store_w(rw, ring[(kc + 1) & 1][0], ring[(kc + 1) & 1][1]);  // (chunk f + 1, in flight since step f - 1; that stage was read in step f - 1)
+#pragma unroll
+            for (int s_ = 0; s_ < 2; ++s_) {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const half8 bhi = *reinterpret_cast<const half8 *>(&wh[nt * 32 + i32][16 * s_ + 8 * h]);
+                    const half8 blo = *reinterpret_cast<const half8 *>(&wl[nt * 32 + i32][16 * s_ + 8 * h]);
+                    acc[nt] = mfma3(Ah[kc][s_], Al[kc][s_], bhi, blo, acc[nt]);
+                }
+                if (s_ == 0 && f + 2 < total) load_w_flat(a, f + 2, rw);  // (behind the LDS reads that follow its store)
+            }
+            __syncthreads();
+        }
+        // ---- epilogue of column block t in the accumulator layout: lane (i32, h) owns column nt 32 + i32, rows mfma32_row(r, h).
+        // Tiles inside the matrix and inside one batch element (all but one in 55 at N = 7000) take the form without row masks
+        // and with one key slot: eight vector instructions per element instead of twenty-two.
+        const int col0 = t * GN;
+        auto epilogue = [&](auto full_c) {
+            constexpr bool FULL = decltype(full_c)::value;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int cl = nt * 32 + i32, col = col0 + cl;
+                const float un = isx / a.wscale[col];
+                float ad0 = 0.0f, ad1 = 0.0f;
+                if (EMODE == E_STATS && a.add) {
+                    ad0 = a.add[(size_t)b0 * N + col];
+                    ad1 = a.add[(size_t)(two ? b0 + 1 : b0) * N + col];
+                }
+                const unsigned kflip = (EMODE == E_COLRED && a.gamma[col] < 0.0f) ? 0x80000000u : 0u;
+                float S1 = 0.0f, S2 = 0.0f, mn = __builtin_inff(), mx = -__builtin_inff(), shift = 0.0f;
+                float bw0 = -__builtin_inff(), bw1 = -__builtin_inff();  // E_COLRED: best of u ^ flip per slot, and its r
+                int br0 = -1, br1 = -1;
+                int cnt = FULL ? 16 : 0;
+                float *yrow = EMODE == E_STATS ? a.Y + (size_t)(wrow0 + 4 * h) * a.ldy + col : nullptr;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wrow0 + mfma32_row(r, h);
+                    const bool on = FULL || row < P, second = !FULL && row >= rsplit;
+                    const float v = __builtin_fmaf(acc[nt][r], un, second ? ad1 : ad0);
+                    if (EMODE == E_STATS && on) yrow[(size_t)mfma32_row(r, 0) * a.ldy] = v;
+                    // sums shifted by the lane's first value (fp32 is enough for sum (v - c), sum (v - c)^2 over 16 rows whatever
+                    // the column's mean is; the shift is undone in fp64 below)
+                    if (r == 0) shift = v;
+                    const float d = on ? v - shift : 0.0f;
+                    S1 += d;
+                    S2 = __builtin_fmaf(d, d, S2);
+                    if (!FULL) cnt += on ? 1 : 0;
+                    if (EMODE == E_STATS) {
+                        mn = on ? fminf(mn, v) : mn;
+                        mx = on ? fmaxf(mx, v) : mx;
+                    } else {
+                        // (rows ascend with r: a strict comparison keeps the first row among equals)
+                        const float w_ = __uint_as_float(__float_as_uint(v) ^ kflip);
+                        const bool b0_ = on && !second && w_ > bw0, b1_ = on && second && w_ > bw1;
+                        bw0 = b0_ ? w_ : bw0;
+                        br0 = b0_ ? r : br0;
+                        if (!FULL) {
+                            bw1 = b1_ ? w_ : bw1;
+                            br1 = b1_ ? r : br1;
+                        }
+                    }
+                }
+                const double c = (double)shift, n = (double)cnt;
+                double s1 = (double)S1 + n * c, s2 = (double)S2 + 2.0 * c * (double)S1 + n * c * c;
+                s1 += __shfl_xor(s1, 32);  // the two lane halves: rows 4 h + ..
+                s2 += __shfl_xor(s2, 32);
+                unsigned long long k0 = 0ull, k1 = 0ull;
+                if (EMODE == E_STATS) {
+                    mn = fminf(mn, __shfl_xor(mn, 32));
+                    mx = fmaxf(mx, __shfl_xor(mx, 32));
+                } else {
+                    auto key_of = [&](float bw, int br, int base) -> unsigned long long {
+                        if (br < 0) return 0ull;
+                        const unsigned ub = __float_as_uint(bw);
+                        const unsigned ord = (ub & 0x80000000u) ? ~ub : (ub | 0x80000000u);
+                        const unsigned rl = (unsigned)(wrow0 + (br & 3) + 8 * (br >> 2) + 4 * h - base);
+                        return ((unsigned long long)ord << 32) | (unsigned long long)(0xffffffffu - rl);
+                    };
+                    k0 = key_of(bw0, br0, rsplit - a.rows_per_batch);
+                    if (!FULL) k1 = key_of(bw1, br1, rsplit);
+                    const unsigned long long o0 = __shfl_xor(k0, 32), o1 = FULL ? 0ull : __shfl_xor(k1, 32);
+                    k0 = o0 > k0 ? o0 : k0;
+                    k1 = o1 > k1 ? o1 : k1;
+                }
+                if (h == 0) {
+                    csum[wave][0][cl] = s1;
+                    csum[wave][1][cl] = s2;
+                    if (EMODE == E_STATS) {
+                        reinterpret_cast<float *>(&cx[wave][0][cl])[0] = mn;
+                        reinterpret_cast<float *>(&cx[wave][0][cl])[1] = mx;
+                    } else {
+                        cx[wave][0][cl] = k0;
+                        cx[wave][1][cl] = k1;
+                    }
+                }
+            }
+        };
+        if (row0 + GM <= P && !two) epilogue(std::true_type{});
+        else epilogue(std::false_type{});
+        __syncthreads();  // (the exchange area is rewritten one column block -- six barriers -- later)
+        if (threadIdx.x < GN) {
+            const int cl = threadIdx.x, col = col0 + cl;
+            if (a.psum) {
+                a.psum[((size_t)rb * 2 + 0) * N + col] = (csum[0][0][cl] + csum[1][0][cl]) + (csum[2][0][cl] + csum[3][0][cl]);
+                a.psum[((size_t)rb * 2 + 1) * N + col] = (csum[0][1][cl] + csum[1][1][cl]) + (csum[2][1][cl] + csum[3][1][cl]);
+            }
+            if (EMODE == E_STATS) {
+                float lo = __builtin_inff(), hi = -__builtin_inff();
+#pragma unroll
+                for (int w_ = 0; w_ < 4; ++w_) {
+                    lo = fminf(lo, reinterpret_cast<const float *>(&cx[w_][0][cl])[0]);
+                    hi = fmaxf(hi, reinterpret_cast<const float *>(&cx[w_][0][cl])[1]);
+                }
+                a.pext[((size_t)rb * 2 + 0) * N + col] = lo;
+                a.pext[((size_t)rb * 2 + 1) * N + col] = hi;
+            } else {
+#pragma unroll
+                for (int sl = 0; sl < 2; ++sl) {
+                    unsigned long long kv = cx[0][sl][cl];
+#pragma unroll
+                    for (int w_ = 1; w_ < 4; ++w_) kv = cx[w_][sl][cl] > kv ? cx[w_][sl][cl] : kv;
+                    if (kv) atomicMax(a.keys + (size_t)(b0 + sl) * N + col, kv);  // a maximum: order-independent
+                }
+            }
+        }
+    }
+}
+static bool row_form(const HGemmArgs &a)
+{
+    static const int off = getenv("DGCNN_HF_ROW") ? atoi(getenv("DGCNN_HF_ROW")) == 0 : 0;
+    return !off && a.K == RK && a.N % GN == 0;
+}
+
 // ---- weight gradient dW[M][Nn] = sum_p aeff[p][m] beff[p][n] with prologues on both operands ---------------------------
 // (the structure of rows_wgrad16_kernel, head_gemm.hip: stages of 32 points, loaded in 16-byte row pieces, transformed,
 // split and written to LDS TRANSPOSED as fp16 planes [column][point]; one 128 x 128 tile of dW over one chunk of the
@@ -1591,7 +1791,8 @@ extern "C" int dgcnn_head_tail_fwd(const dgcnn_head_tail_desc *d, const float *c
         a.psum = d->training ? w.psum7 : nullptr, a.pext = w.pext7, a.zero = s.zmax;
         a.ncb = ceil_div(C7, GN), a.nrb = nrb;
         prof_begin(PROF_HEAD_CONV7, st);
-        hipLaunchKernelGGL((hgemm_kernel<X_RAW, E_STATS, 3>), dim3((unsigned)align_up((size_t)a.ncb * nrb, 8)), dim3(256), 0, st, a);
+        if (row_form(a)) hipLaunchKernelGGL((hrow_kernel<E_STATS>), dim3(nrb), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((hgemm_kernel<X_RAW, E_STATS, 3>), dim3((unsigned)align_up((size_t)a.ncb * nrb, 8)), dim3(256), 0, st, a);
         prof_end(PROF_HEAD_CONV7, st);
         launch_stats_finalize(w.psum7, w.pext7, nrb, P, C7, d->training, d->bn7, d->eps7, d->momentum7, d->slope, s.stats7, s.zmax,
                               w.fpsum, w.fpext, st);
@@ -1882,7 +2083,8 @@ extern "C" int dgcnn_embed_fwd(const float *cat, int ldc, const float *w, int ld
         a.keys = ws.keys, a.gamma = bn->weight;
         a.ncb = ceil_div(C, GN), a.nrb = nrb;
         prof_begin(PROF_HEAD_CONV6, st);
-        hipLaunchKernelGGL((hgemm_kernel<X_RAW, E_COLRED, 3>), dim3((unsigned)align_up((size_t)a.ncb * nrb, 8)), dim3(256), 0, st, a);
+        if (row_form(a)) hipLaunchKernelGGL((hrow_kernel<E_COLRED>), dim3(nrb), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((hgemm_kernel<X_RAW, E_COLRED, 3>), dim3((unsigned)align_up((size_t)a.ncb * nrb, 8)), dim3(256), 0, st, a);
         prof_end(PROF_HEAD_CONV6, st);
     }
     launch_stats_finalize(ws.psum, nullptr, nrb, P, C, training, *bn, eps, momentum, slope, stats, nullptr, ws.fpsum, nullptr, st);
