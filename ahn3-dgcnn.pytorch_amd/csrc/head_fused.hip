@@ -588,6 +588,7 @@ __global__ __launch_bounds__(256, 2) void hrow_kernel(const HGemmArgs a)
             const int f = t * RCH + kc;
             _Float16(*wh)[GSTR] = ring[kc & 1][0], (*wl)[GSTR] = ring[kc & 1][1];
             if (f + 1 < total) store_w(rw, ring[(kc + 1) & 1][0], ring[(kc + 1) & 1][1]);  // (chunk f + 1, in flight since step f - 1; that stage was read in step f - 1)
+            if (f + 2 < total) load_w_flat(a, f + 2, rw);  // (an LDS write takes its data at issue: the registers are free)
 #pragma unroll
             for (int s_ = 0; s_ < 2; ++s_) {
 #pragma unroll
@@ -596,7 +597,6 @@ __global__ __launch_bounds__(256, 2) void hrow_kernel(const HGemmArgs a)
                     const half8 blo = *reinterpret_cast<const half8 *>(&wl[nt * 32 + i32][16 * s_ + 8 * h]);
                     acc[nt] = mfma3(Ah[kc][s_], Al[kc][s_], bhi, blo, acc[nt]);
                 }
-                if (s_ == 0 && f + 2 < total) load_w_flat(a, f + 2, rw);  // (behind the LDS reads that follow its store)
             }
             __syncthreads();
         }
