@@ -212,6 +212,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr float KNN_AUG_K1 = 32768.0f, KNN_AUG_K2 = 16.0f, KNN_AUG_K3 = 0.0078125f;
 // per-pair slack of the fp16 dot product: 2 * 2^-10 * 1.01 = 1.973e-3, with room for the fp16 rounding of its two factors
 constexpr float KNN_PAIR_SLACK = 2.1e-3f;
+// the same slack for SPLIT operands (C <= 4, see knn_prep_split4_kernel): the product is hi.hi + hi.lo + lo.hi of two-piece
+// fp16 operands -- the dropped lo.lo term, the rounding of lo and the fp32 accumulation are each below 2^-22 |x| |y|
+constexpr float KNN_PAIR_SLACK_SPLIT = 4.0e-6f;
 constexpr float KNN_PAD_NORM = 1073741824.0f;  // 2^30: the "norm" of a padding candidate (never a neighbour, no inf - inf)
 constexpr float KNN_F16_CMAX = 1.0e8f;         // largest centred norm the fp16 streams accept (|T| stays below 2^31)
 
@@ -383,6 +386,83 @@ __global__ __launch_bounds__(256) void knn_prep16_kernel(const float *__restrict
         }
         reinterpret_cast<float4 *>(xt + (size_t)b * Npad * CP + (size_t)tile * 32 * CP)[v] = out;
     }
+}
+
+// Preparation for C <= 4 (the raw point features of the first EdgeConv block, model.py:147): the fp16 streams take the
+// features as TWO fp16 pieces per channel, y' = hi + lo (|y' - y| <= 2^-22 |y|), laid out so that one 16-deep slab carries
+// hi.hi + hi.lo + lo.hi (knn_stream_a<.., SPLIT>): the all-pairs passes of this block run on the matrix cores like those of
+// the 64-channel blocks (their exact fp32 forms, knn_bound_kernel<4> + knn_filter32_kernel<4>, are vector-ALU passes:
+// 0.49 ms of a training step at B = 32, N = 7000).  One wave = one 32-point tile (a workgroup takes four); everything
+// knn_prep16_kernel leaves is left here too: xx, xxc, xh (data slab + augmented slab), xt (the layout of
+// knn_tile_kernel<2>, CP = 4), bmax, rbflag.
+__global__ __launch_bounds__(256) void knn_prep_split4_kernel(const float *__restrict__ x, int N, int C, int Npad,
+                                                              float *__restrict__ xx, float *__restrict__ xxc,
+                                                              half8 *__restrict__ xh, float *__restrict__ xt,
+                                                              unsigned *__restrict__ bmax, int *__restrict__ rbflag)
+{
+    __shared__ float ms[128];
+    __shared__ float cred[256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y, tile = blockIdx.x * 4 + wave, ntiles = Npad / 32;  // (Npad is a multiple of 128)
+    const int n = tile * 32 + j;
+    const bool real = n < N;
+    float v[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] = (real && c < C) ? x[((size_t)b * N + n) * C + c] : 0.0f;
+    knn_centre(x, b, N, C, cred, ms);
+    __syncthreads();
+    if (lane == 0) rbflag[(size_t)b * ntiles + tile] = 0;
+    float raw = 0.0f, cen = 0.0f, d[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        d[c] = c < C ? v[c] - ms[c] : 0.0f;
+        raw = __builtin_fmaf(v[c], v[c], raw);  // (channels past C add fma(0, 0, acc): the oracle's chain over c < C)
+        cen = __builtin_fmaf(d[c], d[c], cen);
+    }
+    if (h == 0) {
+        xx[(size_t)b * Npad + n] = real ? raw : __builtin_inff();
+        xxc[(size_t)b * Npad + n] = real ? cen : __builtin_inff();
+    }
+    unsigned mr = real ? __float_as_uint(raw) : 0u, mc = real ? __float_as_uint(cen) : 0u;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+        const unsigned t0 = __shfl_xor(mr, o), t1 = __shfl_xor(mc, o);
+        mr = mr > t0 ? mr : t0;
+        mc = mc > t1 ? mc : t1;
+    }
+    if (lane == 0) {
+        bmax[((size_t)b * 2 + 0) * ntiles + tile] = mc;
+        bmax[((size_t)b * 2 + 1) * ntiles + tile] = mr;
+    }
+    half8 out;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const _Float16 hi = (_Float16)(real ? d[c] : 0.0f);
+        out[c] = hi;
+        out[4 + c] = (_Float16)(real ? d[c] - (float)hi : 0.0f);
+    }
+    half8 *xtile = xh + ((size_t)b * ntiles + tile) * 2 * 64;
+    xtile[lane] = out;
+    half8 aug;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) aug[e] = (_Float16)0.0f;
+    if (h == 0) {
+        const float yy = real ? cen : KNN_PAD_NORM;
+        const Half3 p = knn_split3(yy);
+        aug[0] = p.p1;
+        aug[1] = p.p2;
+        aug[2] = p.p3;
+        aug[3] = (_Float16)KNN_AUG_K1;
+        aug[4] = (_Float16)KNN_AUG_K2;
+        aug[5] = (_Float16)KNN_AUG_K3;
+        aug[6] = (_Float16)(real ? __builtin_sqrtf(cen) : 0.0f);  // candidate factor of the pair slack
+    }
+    xtile[64 + lane] = aug;
+    // fp32 operand tile of the exact fallback (knn_tile_kernel<2>, CP = 4): element e = channel 2 e + h
+    float2 o2;
+    o2.x = h == 0 ? v[0] : v[1];
+    o2.y = h == 0 ? v[2] : v[3];
+    reinterpret_cast<float2 *>(xt + (size_t)b * Npad * 4)[(size_t)tile * 64 + lane] = o2;
 }
 
 __device__ __forceinline__ unsigned f32_to_ordered(float f)
@@ -580,11 +660,26 @@ struct Stage16 {
 // query-side operand of a wave: the row tile's features times -2 and the augmented slab with the row constant T
 // cs: the row's factor of the per-pair slack, +-KNN_PAIR_SLACK sqrt(yy_i) (+: the pre-pass lowers every candidate's
 // value by its slack; -: the filter raises it), 0 for padding rows
-template <int KS1>
+// SPLIT (C <= 4, one data slab): the candidate vector of a point is {hi(4), lo(4)} in BOTH lane halves; the query side is
+// {hi, hi} in lanes h = 0 and {lo, 0} in lanes h = 1, so that the 16-deep product is hi.hi + hi.lo + lo.hi -- formed here
+// from the point's own candidate vector, lane by lane.
+template <int KS1, bool SPLIT = false>
 __device__ __forceinline__ void knn_stream_a(const half8 *__restrict__ xbatch, int rb, int lane, float T, float cs, half8 (&a)[KS1])
 {
+    if (SPLIT) {
+        static_assert(!SPLIT || KS1 == 2, "split operands: one data slab");
+        const half8 v = xbatch[((size_t)rb * KS1) * 64 + lane];
+        half8 q;
 #pragma unroll
-    for (int ks = 0; ks < KS1 - 1; ++ks) a[ks] = xbatch[((size_t)rb * KS1 + ks) * 64 + lane] * (_Float16)(-2.0f);
+        for (int e = 0; e < 4; ++e) {
+            q[e] = lane < 32 ? v[e] : v[4 + e];
+            q[4 + e] = lane < 32 ? v[e] : (_Float16)0.0f;
+        }
+        a[0] = q * (_Float16)(-2.0f);
+    } else {
+#pragma unroll
+        for (int ks = 0; ks < KS1 - 1; ++ks) a[ks] = xbatch[((size_t)rb * KS1 + ks) * 64 + lane] * (_Float16)(-2.0f);
+    }
     half8 aug;
 #pragma unroll
     for (int e = 0; e < 8; ++e) aug[e] = (_Float16)0.0f;
@@ -687,7 +782,7 @@ __device__ __forceinline__ void knn_bound_finish(const float (&m0)[16], const fl
 // accumulator pair) are folded a few registers per group, so that neither an LDS latency nor the vector epilogue ever
 // stands between two MFMAs of the wave.  Measured on the way (B = 8, N = 7000, C = 64; the compiler's own order of the
 // same work: 70 us): MFMAs alone 36 us, + epilogue 42, + LDS reads 55, + staging 62.
-template <int CP>
+template <int CP, bool SPLIT = false>
 __global__ __launch_bounds__(KNN_ST_THREADS, 2) void knn_bound16s_kernel(const half8 *__restrict__ xh, const float *__restrict__ xxc,
                                                            const float *__restrict__ xx_raw,
                                                            const unsigned *__restrict__ bmax, int B, int Npad, int k,
@@ -721,7 +816,8 @@ __global__ __launch_bounds__(KNN_ST_THREADS, 2) void knn_bound16s_kernel(const h
     for (int rt = 0; rt < RT; ++rt) {
         const int rbc = rb0 + rt < ntiles ? rb0 + rt : ntiles - 1;
         const float yy = yb[rbc * 32 + (lane & 31)];  // (+inf for padding rows)
-        knn_stream_a<KS1>(xbatch, rbc, lane, 0.0f, yy < KNN_PAD_NORM ? KNN_PAIR_SLACK * __builtin_sqrtf(yy) : 0.0f, a[rt]);
+        knn_stream_a<KS1, SPLIT>(xbatch, rbc, lane, 0.0f,
+                                 yy < KNN_PAD_NORM ? (SPLIT ? KNN_PAIR_SLACK_SPLIT : KNN_PAIR_SLACK) * __builtin_sqrtf(yy) : 0.0f, a[rt]);
     }
     // class minima of acc = yy_l - 2 d16 = -t: even candidate tiles feed m0, odd ones m1 (64 classes per row with the
     // 32 candidate lanes)
@@ -1160,7 +1256,7 @@ constexpr int KNN_MAXPARTS = 4;   // candidate parts of the filter (list segment
 // kernel -- as soon as ~1000 survivors of a block met in one quarter of the candidates.)
 constexpr int KNN_LISTCAP = 4096;
 
-template <int CP>
+template <int CP, bool SPLIT = false>
 __global__ __launch_bounds__(KNN_ST_THREADS, 2) void knn_filter16_kernel(const half8 *__restrict__ xh, const float *__restrict__ xxc,
                                                            const float *__restrict__ tau0,
                                                            const float *__restrict__ epsr,
@@ -1210,8 +1306,8 @@ __global__ __launch_bounds__(KNN_ST_THREADS, 2) void knn_filter16_kernel(const h
         const float v = (tau - epsr[(size_t)b * Npad + row]) + yy;
         const float thr = v - (__builtin_fabsf(v) + __builtin_fabsf(tau) + yy) * 2.4e-7f;
         // padding rows (yy = +inf) give NaN: nothing may pass there (T = +inf: the accumulator is +inf)
-        knn_stream_a<KS1>(xbatch, rbc, lane, (thr != thr || !real) ? __builtin_inff() : thr,
-                          yy < KNN_PAD_NORM ? -KNN_PAIR_SLACK * __builtin_sqrtf(yy) : 0.0f, a[rt]);
+        knn_stream_a<KS1, SPLIT>(xbatch, rbc, lane, (thr != thr || !real) ? __builtin_inff() : thr,
+                                 yy < KNN_PAD_NORM ? -(SPLIT ? KNN_PAIR_SLACK_SPLIT : KNN_PAIR_SLACK) * __builtin_sqrtf(yy) : 0.0f, a[rt]);
     }
 
     // staged survivors: a ring in LDS per row block (no data movement on flush), entries already in the HBM list
@@ -1793,11 +1889,11 @@ static KnnWs knn_ws(int B, int C, int N, void *base)
     w.tau0 = (float *)take((size_t)B * npad * sizeof(float));
     w.eps = (float *)take((size_t)B * npad * sizeof(float));
     w.mu = (float *)take((size_t)B * cp * sizeof(float));
-    w.xh = (half8 *)take((size_t)B * npad * (cp + 16) * sizeof(_Float16));  // + the augmented slab
+    w.xh = (half8 *)take((size_t)B * npad * ((cp < 16 ? 16 : cp) + 16) * sizeof(_Float16));  // + the augmented slab (C <= 4: one split slab)
     w.lcount = (int *)take((size_t)B * (npad / 32) * KNN_MAXPARTS * sizeof(int));
     w.bmax = (unsigned *)take((size_t)B * 2 * (npad / 32) * sizeof(unsigned));
     w.rbflag = (int *)take((size_t)B * (npad / 32) * sizeof(int));
-    w.exch = (unsigned *)take(cp >= 16 ? (size_t)B * npad * 2 * 64 * sizeof(unsigned) : 0);
+    w.exch = (unsigned *)take((cp >= 16 || C <= 4) ? (size_t)B * npad * 2 * 64 * sizeof(unsigned) : 0);
     w.lists = (unsigned *)take((size_t)B * (npad / 32) * KNN_MAXPARTS * KNN_LISTCAP * sizeof(unsigned));
     w.bytes = off;
     return w;
@@ -1859,7 +1955,14 @@ extern "C" int dgcnn_knn(const float *x, int B, int N, int C, int k, int32_t *id
     // path: two candidate halves; small C: knn_bound_kernel's WIDE variant) up to k = 64 (about 1.4 k survivors per row)
     const bool prepass = N >= 256 && !prepass_off && (k <= 40 || (k <= 64 && (CP < 16 || parts == 2)));
     const bool f16path = prepass && CP >= 16 && !f16_off;
-    if (prepass && CP >= 16) {
+    // C <= 4: the same fp16 streams over two-piece operands (knn_prep_split4_kernel); more than 40 neighbours need the 128
+    // threshold classes of two candidate parts
+    static const bool split4_off = getenv("DGCNN_KNN_NO_SPLIT4") != nullptr;
+    const bool split4 = prepass && C <= 4 && !f16_off && !split4_off && (k <= 40 || parts == 2);
+    if (split4) {
+        hipLaunchKernelGGL(knn_prep_split4_kernel, dim3(Npad / 128, B), dim3(256), 0, st, x, N, C, Npad, xx, w.xxc, w.xh, xt, w.bmax,
+                           w.rbflag);
+    } else if (prepass && CP >= 16) {
         // one pass over x: norms, fp16 and fp32 operand tiles, norm maxima (after the centre of each batch element)
         if (C == 64 && CP == 64)
             hipLaunchKernelGGL(knn_prep16_kernel<64>, dim3(Npad / 32, B), dim3(256), 0, st, x, N, C, Npad, CP, xx, w.xxc, w.xh,
@@ -1889,13 +1992,14 @@ extern "C" int dgcnn_knn(const float *x, int B, int N, int C, int k, int32_t *id
     if (fparts_env >= 1 && fparts_env <= KNN_MAXPARTS && Npad / (32 * KNN_ST_TILES) >= fparts_env) fparts = fparts_env;
     if (prepass) {
         // (knn_bound_kernel writes tau0 for every row, padded rows included)
-        if (CP >= 16) {
+        if (CP >= 16 || split4) {
             const dim3 bgrid(B * parts * ceil_div(Npad / 32, KNN_ST_ROWS)), bblock(KNN_ST_THREADS);
             prof_begin(PROF_KNN_BOUND, st);
-#define DG_BOUND16(CP_)                                                                                              \
-    hipLaunchKernelGGL((knn_bound16s_kernel<CP_>), bgrid, bblock, 0, st, w.xh, w.xxc, xx, w.bmax, B, Npad, k, parts, \
+#define DG_BOUND16(...)                                                                                                      \
+    hipLaunchKernelGGL((knn_bound16s_kernel<__VA_ARGS__>), bgrid, bblock, 0, st, w.xh, w.xxc, xx, w.bmax, B, Npad, k, parts, \
                        w.exch, w.tau0, w.eps)
-            switch (CP) {
+            switch (split4 ? 4 : CP) {
+                case 4: DG_BOUND16(16, true); break;
                 case 16: DG_BOUND16(16); break;
                 case 32: DG_BOUND16(32); break;
                 case 64: DG_BOUND16(64); break;
@@ -1918,7 +2022,24 @@ extern "C" int dgcnn_knn(const float *x, int B, int N, int C, int k, int32_t *id
         tau0 = w.tau0;
     }
     static const bool f32filter_off = getenv("DGCNN_KNN_NO_F32_FILTER") != nullptr;
-    if (prepass && CP < 16 && !f32filter_off) {
+    if (split4) {
+        // two-piece fp16 filter + exact refine; the exact fp32 kernel below only runs the row blocks these kernels flagged
+        rbflag = w.rbflag;
+        prof_begin(PROF_KNN_FILTER, st);
+        hipLaunchKernelGGL((knn_filter16_kernel<16, true>), dim3(B * fparts * ceil_div(Npad / 32, KNN_ST_ROWS)), dim3(KNN_ST_THREADS),
+                           0, st, w.xh, w.xxc, w.tau0, w.eps, w.bmax, B, Npad, fparts, w.lists, w.lcount, w.rbflag);
+        prof_end(PROF_KNN_FILTER, st);
+        prof_begin(PROF_KNN_REFINE, st);
+        const dim3 rgrid(B * (Npad / 32));
+        if (cap == 64)
+            hipLaunchKernelGGL((knn_refine_kernel<4, 64>), rgrid, dim3(64), 0, st, x, w.xx, w.lists, w.lcount, w.rbflag, B, N, C, Npad,
+                               k, fparts, idx);
+        else
+            hipLaunchKernelGGL((knn_refine_kernel<4, 128>), dim3(2 * rgrid.x), dim3(64), 0, st, x, w.xx, w.lists, w.lcount, w.rbflag,
+                               B, N, C, Npad, k, fparts, idx);
+        prof_end(PROF_KNN_REFINE, st);
+        DG_CHECK_LAUNCH("knn_filter16_kernel<16, split> / knn_refine_kernel");
+    } else if (prepass && CP < 16 && !f32filter_off) {
         // small C: exact fp32 filter + exact refine (see knn_filter32_kernel); knn_kernel below only runs flagged blocks
         if (hipMemsetAsync(w.rbflag, 0, (size_t)B * (Npad / 32) * sizeof(int), st) != hipSuccess)
             DG_FAIL("dgcnn_knn: memset failed");
