@@ -8,10 +8,19 @@ namespace dgcnn {
 // ---- pointgemm.hip : per-point fp32 MFMA contractions --------------------------------------
 // forward per-point product of a block's first convolution w1 [64][2C]:
 //   W1 . [x_j - x_i ; x_i] = Wa . x_j + (Wb - Wa) . x_i,  Wcat = [Wa ; Wb - Wa]:  TP = x Wa^T, TQ = x (Wb - Wa)^T.
-// Every workgroup builds Wcat^T in LDS from w1; workgroup 0 also leaves wcat [128][C] for the backward's dgrad and
-// zeroes zero_words[0 .. nzero) (the fold.h counters of the statistics passes behind it).
-void launch_rowgemm_fwd(const float *x, int C, const float *w1, float *TP, float *TQ, float *wcat, int *zero_words,
-                        int nzero, int P, hipStream_t st);
+// Every workgroup builds Wcat^T in LDS from w1; workgroup 0 also leaves wcat [128][C] for the backward's dgrad,
+// zeroes zero_words[0 .. nzero) (the fold.h counters of the statistics passes behind it) and, in eval mode (nbn = 1 or 2),
+// writes the BatchNorm affine pairs of the block's layers from their running statistics (ST_* layout of edge_common.h).
+struct FwdSide {
+    float *wcat;
+    int *zero_words;
+    int nzero;
+    int nbn;
+    float eps;
+    dgcnn_bn_params bn[2];
+    float *stats[2];
+};
+void launch_rowgemm_fwd(const float *x, int C, const float *w1, float *TP, float *TQ, const FwdSide &sd, int P, hipStream_t st);
 // Y(p, n) = sum_k A(p, k) W[k][n];  A = [A0 | A1] (K0 + K1 columns), Y = [Y0 | Y1] (NO0 + rest)
 void launch_rowgemm(const float *A0, int K0, const float *A1, int K1, const float *W, int NO, float *Y0, int NO0,
                     float *Y1, int P, hipStream_t st);
@@ -32,8 +41,6 @@ int edge_grid(int P);
 // itself (fold.h; fs.ctr must be zero at launch) -> fin->stats, running statistics updated.
 void launch_edge_reduce(const float *TP, const float *TQ, const int32_t *idx, int N, int k, int P, const float *gamma,
                         float *usel, float *usum, uint8_t *hitj, const FoldSet &fs, const BnBatchStats *fin, hipStream_t st);
-// eval mode: stats[ST_*] from the running statistics
-void launch_bn_eval_stats(const dgcnn_bn_params &bn, float eps, float *stats, hipStream_t st);
 // y = LeakyReLU(sc * usel + sh)
 void launch_edge_out(const float *usel, const float *stats, float slope, int P, float *y, hipStream_t st);
 // last-stage BN backward sums from per-point quantities, finished in the same launch: gbn_w, gbn_b and cc = [c1 | c2]

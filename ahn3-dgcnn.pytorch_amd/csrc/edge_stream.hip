@@ -142,19 +142,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     if (FIN) fold_and_finalize<2, EDGE_WAVES>(acc, fs, fin);
 }
 
-// BatchNorm affine pair from the RUNNING statistics (eval mode): no reduction.
-__global__ __launch_bounds__(64) void bn_eval_stats_kernel(dgcnn_bn_params bn, float eps, float *__restrict__ stats)
-{
-    const int c = threadIdx.x;
-    const float mean = bn.running_mean[c], var = bn.running_var[c];
-    const float rstd = (float)(1.0 / sqrt((double)var + (double)eps));
-    const float sc = bn.weight[c] * rstd;
-    stats[ST_MEAN + c] = mean;
-    stats[ST_RSTD + c] = rstd;
-    stats[ST_SC + c] = sc;
-    stats[ST_SH + c] = bn.bias[c] - mean * sc;
-}
-
 __global__ void edge_out_kernel(const float *__restrict__ usel, const float *__restrict__ stats, float slope,
                                 size_t n4, float *__restrict__ y)
 {
@@ -959,11 +946,6 @@ void launch_edge_reduce(const float *TP, const float *TQ, const int32_t *idx, in
                            hitj, fs, f);
     }
     prof_end(PROF_EDGE_REDUCE, st);
-}
-
-void launch_bn_eval_stats(const dgcnn_bn_params &bn, float eps, float *stats, hipStream_t st)
-{
-    hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(1), dim3(64), 0, st, bn, eps, stats);
 }
 
 void launch_edge_out(const float *usel, const float *stats, float slope, int P, float *y, hipStream_t st)

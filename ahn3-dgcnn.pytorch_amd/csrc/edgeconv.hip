@@ -8,7 +8,7 @@
 //                    running statistics -- and, for a one-stage block, the selected extreme over k
 //   2 stages: edge_mlp_fwd  a1 = LReLU(BN1(u)); u2 = W2 a1 (MFMA, per edge); BN2 sums (finished in the launch) + extreme
 //   edge_out         y = LReLU(BN(extreme))      == max over k of the activations, exactly
-// (eval mode: bn_eval_stats per stage instead of the batch statistics.)
+// (eval mode: the affine pairs come from the running statistics, written by workgroup 0 of the per-point product.)
 //
 // Backward (autograd nodes listed in SURVEY.md 2.1 "Bw"; formulas Appendix C.5):
 //   rev_count, rev_slots, rev_place   reverse adjacency of the neighbour graph, lists sorted by edge id (the first
@@ -212,13 +212,16 @@ extern "C" int dgcnn_edgeconv_fwd(const dgcnn_edgeconv_desc *d, const float *x, 
     const int P = d->B * d->N, N = d->N, C = d->C, k = d->k;
     const double E = (double)P * k;
 
-    launch_rowgemm_fwd(x, C, d->w1, s.TP, s.TQ, s.wcat, w.zero, Z_WORDS, P, st);
+    FwdSide sd{};
+    sd.wcat = s.wcat, sd.zero_words = w.zero, sd.nzero = Z_WORDS;
+    if (!d->training) {  // BatchNorm constants from the running statistics: written by workgroup 0 of the per-point product
+        sd.nbn = d->n_stage, sd.eps = d->eps;
+        sd.bn[0] = d->bn1, sd.stats[0] = s.stats1;
+        sd.bn[1] = d->bn2, sd.stats[1] = s.stats2;
+    }
+    launch_rowgemm_fwd(x, C, d->w1, s.TP, s.TQ, sd, P, st);
     const FoldSet fs1{w.f1.rec, w.f1.folded, w.zero + Z_FOLD_A}, fs2{w.f2.rec, w.f2.folded, w.zero + Z_FOLD_B};
     const BnBatchStats fin1{d->bn1, E, d->eps, d->momentum, s.stats1}, fin2{d->bn2, E, d->eps, d->momentum, s.stats2};
-    if (!d->training) {
-        launch_bn_eval_stats(d->bn1, d->eps, s.stats1, st);
-        if (d->n_stage == 2) launch_bn_eval_stats(d->bn2, d->eps, s.stats2, st);
-    }
     if (d->n_stage == 1) {
         launch_edge_reduce(s.TP, s.TQ, idx, N, k, P, d->bn1.weight, s.usel, s.usum, s.hitj, fs1, d->training ? &fin1 : nullptr,
                            st);

@@ -22,12 +22,25 @@ __device__ __forceinline__ float wcat_at(const float *__restrict__ w1, int C, in
 {
     return o < EC ? w1[(size_t)o * 2 * C + c] : w1[(size_t)(o - EC) * 2 * C + C + c] - w1[(size_t)(o - EC) * 2 * C + c];
 }
-__device__ __forceinline__ void fwd_side_jobs(const float *__restrict__ w1, int C, float *__restrict__ wcat,
-                                              int *__restrict__ zero_words, int nzero)
+__device__ __forceinline__ void fwd_side_jobs(const float *__restrict__ w1, int C, const FwdSide &sd)
 {
     if (blockIdx.x != 0) return;
-    for (int i = threadIdx.x; i < nzero; i += 256) zero_words[i] = 0;
-    for (int e = threadIdx.x; e < 128 * C; e += 256) wcat[e] = wcat_at(w1, C, e / C, e % C);
+    for (int i = threadIdx.x; i < sd.nzero; i += 256) sd.zero_words[i] = 0;
+    for (int e = threadIdx.x; e < 128 * C; e += 256) sd.wcat[e] = wcat_at(w1, C, e / C, e % C);
+    // eval mode: the BatchNorm affine pairs of the block from the RUNNING statistics (no reduction; they were a launch of 64
+    // threads per layer: 4.8 us each, ten per eval forward of the model)
+    if ((int)threadIdx.x < 64 * sd.nbn) {
+        const int l = threadIdx.x >> 6, c = threadIdx.x & 63;
+        const dgcnn_bn_params &bn = sd.bn[l];
+        const float mean = bn.running_mean[c], var = bn.running_var[c];
+        const float rstd = (float)(1.0 / sqrt((double)var + (double)sd.eps));
+        const float sc = bn.weight[c] * rstd;
+        float *stats = sd.stats[l];
+        stats[ST_MEAN + c] = mean;
+        stats[ST_RSTD + c] = rstd;
+        stats[ST_SC + c] = sc;
+        stats[ST_SH + c] = bn.bias[c] - mean * sc;
+    }
 }
 
 // One wave = one 32-row tile of points x all NO (<= 32 NT) output columns.
@@ -45,8 +58,7 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(const float *__restrict__ 
                                                       const float *__restrict__ A1, int K1,
                                                       const float *__restrict__ W, int NO,
                                                       float *__restrict__ Y0, int NO0, float *__restrict__ Y1,
-                                                      int P, float *__restrict__ wcat, int *__restrict__ zero_words,
-                                                      int nzero)
+                                                      int P, const FwdSide sd)
 {
     // the weights are read by every wave at every step: stage them in LDS (the kernel was bound by the
     // latency of those loads: 73 % of its wave cycles in s_waitcnt)
@@ -54,7 +66,7 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(const float *__restrict__ 
     const int K = K0 + K1, KH = (K + 1) >> 1;
     const bool staged = K * NO <= RG_LDS_FLOATS;
     if (FROM_W1) {  // K = C <= 64, NO = 128: always staged
-        fwd_side_jobs(W, K, wcat, zero_words, nzero);
+        fwd_side_jobs(W, K, sd);
         for (int e = threadIdx.x; e < K * 128; e += 256) wl[e] = wcat_at(W, K, e & 127, e >> 7);
     } else if (staged) {
         for (int e = threadIdx.x; e < K * NO; e += 256) wl[e] = W[e];
@@ -131,15 +143,14 @@ template <int KH, int NT, bool FROM_W1>
 __global__ __launch_bounds__(256) void rowgemm_fast_kernel(const float *__restrict__ A0, int K0,
                                                            const float *__restrict__ A1, int K1,
                                                            const float *__restrict__ W, float *__restrict__ Y0, int NO0,
-                                                           float *__restrict__ Y1, int P, float *__restrict__ wcat,
-                                                           int *__restrict__ zero_words, int nzero)
+                                                           float *__restrict__ Y1, int P, const FwdSide sd)
 {
     constexpr int K = 2 * KH, NO = 32 * NT;
     __shared__ float wl[K * NO];
     if (FROM_W1) {  // K = C = 64, NO = 128: wl[c][o] = Wcat[o][c]; lanes run over o (conflict-free LDS writes), each
                     // reads 16 bytes of row o of w1
         static_assert(!FROM_W1 || (K == 64 && NO == 128), "forward shape");
-        fwd_side_jobs(W, K, wcat, zero_words, nzero);
+        fwd_side_jobs(W, K, sd);
         for (int e = threadIdx.x; e < 128 * (K / 4); e += 256) {
             const int o = e & 127, c4 = (e >> 7) * 4;
             const float *row = W + (size_t)(o & 63) * 2 * K;
@@ -208,8 +219,7 @@ template <int KH, int NT, bool FROM_W1>
 __global__ __launch_bounds__(256) void rowgemm_split_kernel(const float *__restrict__ A0, int K0,
                                                             const float *__restrict__ A1, int K1,
                                                             const float *__restrict__ W, float *__restrict__ Y0, int NO0,
-                                                            float *__restrict__ Y1, int P, float *__restrict__ wcat,
-                                                            int *__restrict__ zero_words, int nzero)
+                                                            float *__restrict__ Y1, int P, const FwdSide sd)
 {
     constexpr int K = 2 * KH, NO = 32 * NT, ROWB = K * 2, PLANE = NO * ROWB;
     static_assert(K * NO == 8192 && (K == 64 || K == 128), "the two shapes of the 64-channel blocks");
@@ -224,7 +234,7 @@ __global__ __launch_bounds__(256) void rowgemm_split_kernel(const float *__restr
     for (int i = 0; i < KH / 4; ++i) av[i] = reinterpret_cast<const float4 *>(src)[i];
 
     // ---- W: item e of a thread = four consecutive k of one output column n
-    if (FROM_W1) fwd_side_jobs(W, K, wcat, zero_words, nzero);
+    if (FROM_W1) fwd_side_jobs(W, K, sd);
     float4 wv[8];
     float wmax = 0.0f;
 #pragma unroll
@@ -485,19 +495,15 @@ static bool rowgemm_split_fwd()
     return v != 0;
 }
 
-void launch_rowgemm_fwd(const float *x, int C, const float *w1, float *TP, float *TQ, float *wcat, int *zero_words,
-                        int nzero, int P, hipStream_t st)
+void launch_rowgemm_fwd(const float *x, int C, const float *w1, float *TP, float *TQ, const FwdSide &sd, int P, hipStream_t st)
 {
     const dim3 grid(ceil_div(ceil_div(P, 32), 4)), block(256);
     if (C == 64 && rowgemm_split_fwd())
-        hipLaunchKernelGGL((rowgemm_split_kernel<32, 4, true>), grid, block, 0, st, x, C, nullptr, 0, w1, TP, EC, TQ, P, wcat,
-                           zero_words, nzero);
+        hipLaunchKernelGGL((rowgemm_split_kernel<32, 4, true>), grid, block, 0, st, x, C, nullptr, 0, w1, TP, EC, TQ, P, sd);
     else if (C == 64)
-        hipLaunchKernelGGL((rowgemm_fast_kernel<32, 4, true>), grid, block, 0, st, x, C, nullptr, 0, w1, TP, EC, TQ, P, wcat,
-                           zero_words, nzero);
+        hipLaunchKernelGGL((rowgemm_fast_kernel<32, 4, true>), grid, block, 0, st, x, C, nullptr, 0, w1, TP, EC, TQ, P, sd);
     else
-        hipLaunchKernelGGL((rowgemm_kernel<4, true>), grid, block, 0, st, x, C, nullptr, 0, w1, 128, TP, EC, TQ, P, wcat,
-                           zero_words, nzero);
+        hipLaunchKernelGGL((rowgemm_kernel<4, true>), grid, block, 0, st, x, C, nullptr, 0, w1, 128, TP, EC, TQ, P, sd);
 }
 
 void launch_rowgemm(const float *A0, int K0, const float *A1, int K1, const float *W, int NO, float *Y0, int NO0,
@@ -511,32 +517,29 @@ void launch_rowgemm(const float *A0, int K0, const float *A1, int K1, const floa
         if (!rowgemm_force_f32() && ((K == 64 && NO == 128) || (K == 128 && NO == 64))) {
             if (K == 64)
                 hipLaunchKernelGGL((rowgemm_split_kernel<32, 4, false>), grid, block, 0, st, A0, K0, A1, K1, W, Y0, NO0, Y1, P,
-                                   nullptr, nullptr, 0);
+                                   FwdSide{});
             else
                 hipLaunchKernelGGL((rowgemm_split_kernel<64, 2, false>), grid, block, 0, st, A0, K0, A1, K1, W, Y0, NO0, Y1, P,
-                                   nullptr, nullptr, 0);
+                                   FwdSide{});
             return;
         }
         if (K == 64 && NO == 128) {
             hipLaunchKernelGGL((rowgemm_fast_kernel<32, 4, false>), grid, block, 0, st, A0, K0, A1, K1, W, Y0, NO0, Y1, P,
-                               nullptr, nullptr, 0);
+                               FwdSide{});
             return;
         }
         if (K == 128 && NO == 64) {
             hipLaunchKernelGGL((rowgemm_fast_kernel<64, 2, false>), grid, block, 0, st, A0, K0, A1, K1, W, Y0, NO0, Y1, P,
-                               nullptr, nullptr, 0);
+                               FwdSide{});
             return;
         }
     }
     if (nt <= 1)
-        hipLaunchKernelGGL((rowgemm_kernel<1, false>), grid, block, 0, st, A0, K0, A1, K1, W, NO, Y0, NO0, Y1, P, nullptr,
-                           nullptr, 0);
+        hipLaunchKernelGGL((rowgemm_kernel<1, false>), grid, block, 0, st, A0, K0, A1, K1, W, NO, Y0, NO0, Y1, P, FwdSide{});
     else if (nt == 2)
-        hipLaunchKernelGGL((rowgemm_kernel<2, false>), grid, block, 0, st, A0, K0, A1, K1, W, NO, Y0, NO0, Y1, P, nullptr,
-                           nullptr, 0);
+        hipLaunchKernelGGL((rowgemm_kernel<2, false>), grid, block, 0, st, A0, K0, A1, K1, W, NO, Y0, NO0, Y1, P, FwdSide{});
     else
-        hipLaunchKernelGGL((rowgemm_kernel<4, false>), grid, block, 0, st, A0, K0, A1, K1, W, NO, Y0, NO0, Y1, P, nullptr,
-                           nullptr, 0);
+        hipLaunchKernelGGL((rowgemm_kernel<4, false>), grid, block, 0, st, A0, K0, A1, K1, W, NO, Y0, NO0, Y1, P, FwdSide{});
 }
 
 // wgrad_kernel for M0 = M1 = 64, C = 64 (the 64-channel blocks): a workgroup of FOUR waves takes 256 points, wave w

@@ -1,5 +1,7 @@
 """dev helper: randomised GPU-vs-oracle comparison of the kNN index lists (bit-exact gate) over shapes, scales,
-offsets, quantisation (exact ties) and cluster structure.  Prints every mismatching configuration."""
+offsets, quantisation (exact ties) and cluster structure.  Prints every mismatching configuration.
+
+    python scripts/fuzz_knn.py [seed] [cases] [channel counts, e.g. 1,2,3,4]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -9,10 +11,11 @@ from ahn3_dgcnn_pytorch_amd import ops
 dev = torch.device("cuda:0")
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 80
+channels = [int(c) for c in sys.argv[3].split(",")] if len(sys.argv) > 3 else [3, 4, 5, 8, 9, 16, 24, 32, 64, 100, 128]
 bad = 0
 t0 = time.time()
 for it in range(n_cases):
-    C = int(rng.choice([3, 4, 5, 8, 9, 16, 24, 32, 64, 100, 128]))
+    C = int(rng.choice(channels))
     N = int(rng.choice([257, 300, 512, 777, 1000, 1500, 2048, 3000]))
     B = int(rng.choice([1, 2, 3]))
     k = int(rng.choice([1, 8, 20, 30, 32, 33, 40, 41, 64])); k = min(k, N)

@@ -132,9 +132,10 @@ def test_knn_f16_path_c16_c32_c128(device):
 
 
 def test_knn_small_c_filter_path_is_exact(device):
-    # C <= 8 (raw coordinates of the first block): fp32 pre-pass + fp32 filter + refine; offsets, scales, duplicates
+    # C <= 8 (raw coordinates of the first block): C <= 4 through the fp16 streams on two-piece operands, C = 8 through the fp32
+    # pre-pass + fp32 filter, both followed by the exact refine; offsets, scales, duplicates
     rng = np.random.default_rng(21)
-    for C in (3, 4, 8):
+    for C in (1, 2, 3, 4, 8):
         base = rng.standard_normal((2, C, 1200)).astype(np.float32)
         cases = {
             "plain": base,
