@@ -61,7 +61,7 @@ def parse_args():
     ap.add_argument("--workload", choices=("block", "train"), default="block")
     ap.add_argument("--profile-every", type=int, default=0,
                     help="record the per-kernel HIP events on every n-th timed step (an event record costs GPU time: some "
-                         "twenty records per sampled step); 0 = two (up to 30 steps) or three sampled steps, spread over the timed region")
+                         "twenty records per sampled step); 0 = one (up to 30 steps) or three sampled steps, spread over the timed region")
     ap.add_argument("--stages", type=int, default=1, choices=(1, 2),
                     help="block workload: 1 = conv5-shaped block (128->64); 2 = conv3+conv4-shaped block (128->64->64)")
     ap.add_argument("--batch", type=int, default=None,
@@ -164,7 +164,9 @@ def sample_stride(args, steps):
     """every how many timed steps the per-kernel events are recorded"""
     if args.profile_every > 0:
         return args.profile_every
-    return max(1, -(-steps // (2 if steps <= 30 else 3)))   # two sampled steps in a short run, three otherwise
+    # one sampled step in a short run, three otherwise: an event record is a barrier packet between two kernels (about 8 us
+    # each, 20-odd per sampled step of the block workload: two sampled steps of twenty cost the mean 3 %)
+    return max(1, -(-steps // (1 if steps <= 30 else 3)))
 
 
 def timed_steps(step, n, every, dev):
@@ -173,7 +175,7 @@ def timed_steps(step, n, every, dev):
     fence()
     t0 = time.perf_counter()
     for i in range(n):
-        step(every > 0 and i % every == 0)
+        step(every > 0 and i % every == every // 2)   # (the middle of each stride: never the first step behind the fence)
     fence()
     return max_over_ranks(time.perf_counter() - t0, dev)
 
@@ -327,6 +329,8 @@ def run_block(args, rank, world, dev):
     knn_ms = sum(a.elapsed_time(b) for a, b in knn_events) / max(1, len(knn_events))
     regions = region_times(lib)
     dist_ms = per_step_ms(step, min(args.steps, 50))
+    if os.environ.get("DGCNN_BENCH_DEBUG"):
+        sys.stderr.write("per-step ms (separate pass): %s\n" % " ".join("%.3f" % v for v in dist_ms[:12]))
     if rank != 0:
         return None
     P, E = B * N, B * N * k
