@@ -741,9 +741,9 @@ struct HWgradArgs {
     const unsigned *amax_b;  // bits of max |beff|
     float *partial;
 };
-// (Measured and dropped: thread (cq = t / 8, pq = t % 8) instead of (t % 32, t / 32), which takes the transposed 8-byte LDS
-// writes of a wave from an 8-way to a 2-way bank conflict -- SQ_LDS_BANK_CONFLICT is 78 % of the weight-gradient kernels'
-// LDS cycles -- but makes a wave's loads 8 points x 128 bytes instead of 2 points x 512: 462 us against 429 / 409.)
+// (Measured and dropped: thread (cq = t / 8, pq = t % 8) instead of (t % 32, t / 32), which also takes the transposed 8-byte
+// LDS writes of a wave to a 2-way bank conflict, but makes a wave's loads 8 points x 128 bytes instead of 2 points x 512:
+// 462 us against 429 / 409.  The row permutation wrow() below gets the same without touching the loads.)
 struct WStage {
     float4 v[4];  // v[i] = row p0 + 4 pq + i, columns c0 + 4 cq .. + 3
 };
@@ -757,6 +757,13 @@ __device__ __forceinline__ void wstage_load(const float *__restrict__ src, int l
         r.v[i] = *reinterpret_cast<const float4 *>(src + (size_t)(p < pend ? p : pend - 1) * ld + col);
     }
 }
+// LDS row of column j of the 128-column tile: 32 (j & 3) + (j >> 2).  A thread holds four consecutive columns (one 16-byte
+// load), so with row = column the 32 lanes of a store -- columns 4 cq + c -- are 320 bytes apart, i.e. on TWO 8-byte bank
+// positions: a 16-way conflict on every transposed write (SQ_LDS_BANK_CONFLICT was 78 % of these kernels' LDS cycles).
+// Here consecutive lanes write consecutive rows (80 bytes apart: eight positions, 2-way), the loads stay whole 512-byte row
+// pieces, and the matrix instructions read rows as before: only the column a tile row STANDS FOR changes (wcol).
+__device__ __forceinline__ constexpr int wrow(int j) { return 32 * (j & 3) + (j >> 2); }
+__device__ __forceinline__ constexpr int wcol(int r) { return 4 * (r & 31) + (r >> 5); }
 // the four columns of this thread, transformed, for the stage's four points -> transposed, split, stored
 __device__ __forceinline__ void wstage_store(const float (&t)[4][4] /* [column][point] */, _Float16 (*hi)[WSTR], _Float16 (*lo)[WSTR])
 {
@@ -765,8 +772,8 @@ __device__ __forceinline__ void wstage_store(const float (&t)[4][4] /* [column][
     for (int c = 0; c < 4; ++c) {
         u32x2 h, l;
         split4(t[c], h, l);
-        *reinterpret_cast<u32x2 *>(&hi[4 * cq + c][4 * pq]) = h;
-        *reinterpret_cast<u32x2 *>(&lo[4 * cq + c][4 * pq]) = l;
+        *reinterpret_cast<u32x2 *>(&hi[wrow(4 * cq + c)][4 * pq]) = h;
+        *reinterpret_cast<u32x2 *>(&lo[wrow(4 * cq + c)][4 * pq]) = l;
     }
 }
 
@@ -879,10 +886,10 @@ __global__ __launch_bounds__(256, OCC) void hwgrad_kernel(const HWgradArgs a)
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-            const int n = n0 + wn + nt * 32 + i32;
+            const int n = n0 + wcol(wn + nt * 32 + i32);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm + mt * 32 + mfma32_row(r, h);
+                const int m = m0 + wcol(wm + mt * 32 + mfma32_row(r, h));
                 if (m < M && n < Nn) out[(size_t)m * Nn + n] = acc[mt][nt][r] * un;
             }
         }
