@@ -287,6 +287,10 @@ __global__ __launch_bounds__(256, OCC) void hgemm_kernel(const HGemmArgs a)
     unsigned long long kb[2][4][2];    // E_COLRED: [half][column][batch-element slot] best key
     float dvs[2][4][6];                // E_DV: [half][column][slot 0: dv, dv uhat, uhat; slot 1: the same]
     float amax_dv = 0.0f, amax_uh = 0.0f;
+    // (a tile inside the matrix and inside one batch element -- all but one in 55 at N = 7000 -- runs without row masks and
+    // without the second batch-element slot: the compiler drops the selects and the slot's sums)
+    auto halves = [&](auto full_c) {
+    constexpr bool FULL = decltype(full_c)::value;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -341,10 +345,10 @@ __global__ __launch_bounds__(256, OCC) void hgemm_kernel(const HGemmArgs a)
                 }
             }
             const int row = wrow0 + lr + 4 * i;
-            const bool on = cv && row < P;
+            const bool on = cv && (FULL || row < P);
             const float4 t4 = *reinterpret_cast<const float4 *>(&wbuf[(lr + 4 * i) * EST + lc]);
             float o[4];
-            const bool second = row >= rsplit;
+            const bool second = !FULL && row >= rsplit;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float g = f4(t4, e) * un[e];
@@ -426,6 +430,9 @@ __global__ __launch_bounds__(256, OCC) void hgemm_kernel(const HGemmArgs a)
         }
         __builtin_amdgcn_wave_barrier();  // the image is read: the next half may overwrite it
     }
+    };
+    if (row0 + GM <= P && row0 + GM <= rsplit) halves(std::true_type{});
+    else halves(std::false_type{});
     if (EMODE == E_PLAIN) return;
     __syncthreads();  // all images are consumed: the staging area becomes the scratch of the cross-wave step
     if (EMODE == E_COLRED) {
@@ -840,11 +847,12 @@ __global__ __launch_bounds__(256, OCC) void hwgrad_kernel(const HWgradArgs a)
     wstage_load(a.Bm, a.ldb, Nn, n0, pbeg, pend, rb);
     for (int p0 = pbeg; p0 < pend; p0 += WK) {
         __syncthreads();
-        {
+        auto stage = [&](auto full_c) {  // (only a chunk's last stage can reach past its end: the others run without masks)
+            constexpr bool FULL = decltype(full_c)::value;
             float ta_[4][4], tb_[4][4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const bool on = p0 + 4 * pq + i < pend;  // points past the chunk add nothing
+                const bool on = FULL || p0 + 4 * pq + i < pend;  // points past the chunk add nothing
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     float x = f4(ra.v[i], c);
@@ -857,7 +865,9 @@ __global__ __launch_bounds__(256, OCC) void hwgrad_kernel(const HWgradArgs a)
             }
             wstage_store(ta_, ah, al);
             wstage_store(tb_, bh, bl);
-        }
+        };
+        if (p0 + WK <= pend) stage(std::true_type{});
+        else stage(std::false_type{});
         __syncthreads();
         if (p0 + WK < pend) {
             wstage_load(a.A, a.lda, M, m0, p0 + WK, pend, ra);
