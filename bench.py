@@ -521,11 +521,11 @@ def run_train(args, rank, world, dev, steps, warmup, with_cpu):
         "head_dw7_kernel": ("hbm", 4.0 * Pl * (2 * C7 + F_), PEAK_HBM_GBS, "reads dv7, u7, cat once ([512, 192] out)"),
     })
     head_traffic = {}
-    tpath = os.path.join(ROOT, "profiles", "r3_20_head_tail_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r3_80_head_tail_traffic.json")
     if (Bl, N) == (32, 7000) and os.path.exists(tpath):   # PMC passes of this shape (scripts/pmc_head_tail.sh), committed
         with open(tpath) as f:
             kk = json.load(f)["kernels"]
-        for region, pat in (("head_conv7_kernel", "hgemm_kernel<0, 1"), ("head_conv8_kernel", "hgemm_kernel<1, 1"),
+        for region, pat in (("head_conv7_kernel", "hrow_kernel<1"), ("head_conv8_kernel", "hgemm_kernel<1, 1"),
                             ("head_dz7_kernel", "hgemm_kernel<2, 2"), ("head_dcat_kernel", "hgemm_kernel<2, 0"),
                             ("head_dw8_kernel", "hwgrad_kernel<2, 1"), ("head_dw7_kernel", "hwgrad_kernel<2, 0")):
             for name, e in kk.items():
@@ -534,7 +534,7 @@ def run_train(args, rank, world, dev, steps, warmup, with_cpu):
     kernels = kernel_entries(regions, work, head_traffic)
     for e in kernels:
         if "traffic_source" in e:
-            e["traffic_source"] = "profiles/r3_20_head_tail_traffic.json (rocprofv3 --pmc passes of scripts/bench_head_tail.py at this shape, committed; not re-measured in this run)"
+            e["traffic_source"] = "profiles/r3_80_head_tail_traffic.json (rocprofv3 --pmc passes of scripts/bench_head_tail.py at this shape, committed; not re-measured in this run)"
     step_flops = 12.04e6 * Bl * N   # 12.04 MFLOP per point for the full training step
     out = {
         "metric": "DGCNN training-step points/sec (global B=%d,N=%d,k=%d)" % (Bg, N, k),
