@@ -28,8 +28,9 @@
 // with index = j mod 32, even / odd tiles: 64 classes per row); the k-th largest of the 64 class
 // maxima is attained by k distinct candidates, hence is a valid lower bound.  For C >= 16 the
 // pre-pass runs on fp16 MFMA (v_mfma_f32_32x32x16_f16, 1/16 of the fp32 cost) over mean-centred
-// features and tau0 is loosened by an a-priori error bound; for small C it is the exact fp32
-// arithmetic loosened by one ulp.  The bound only affects speed: if a row ends the exact stream
+// features and tau0 is loosened by an a-priori error bound; C <= 4 (the raw point features) takes the same fp16 path
+// with every channel as two fp16 pieces in one 16-deep slab (knn_prep_split4_kernel); for 4 < C <= 8 it is the exact
+// fp32 arithmetic loosened by one ulp.  The bound only affects speed: if a row ends the exact stream
 // with fewer than k candidates (tau0 was not a lower bound), the wave repeats its stream from
 // tau = -inf, so the result never depends on the pre-pass.
 //
