@@ -724,7 +724,10 @@ __global__ __launch_bounds__(256, 2) void hrow_kernel(const HGemmArgs a)
 static bool row_form(const HGemmArgs &a)
 {
     static const int off = getenv("DGCNN_HF_ROW") ? atoi(getenv("DGCNN_HF_ROW")) == 0 : 0;
-    return !off && a.K == RK && a.N % GN == 0;
+    // (below about one and a half row blocks per CU the walk leaves CUs with one workgroup or none, and the product with a
+    // workgroup per (row block, column block) is the faster one again: training step at B = 4, 219 row blocks: 2.134 ms
+    // against 2.146; at B = 8, 438: 3.282 against 3.254)
+    return !off && a.K == RK && a.N % GN == 0 && a.nrb >= 320;
 }
 
 // ---- weight gradient dW[M][Nn] = sum_p aeff[p][m] beff[p][n] with prologues on both operands ---------------------------
