@@ -723,7 +723,10 @@ __global__ __launch_bounds__(256, 2) void hrow_kernel(const HGemmArgs a)
 }
 static bool row_form(const HGemmArgs &a)
 {
-    static const int off = getenv("DGCNN_HF_ROW") ? atoi(getenv("DGCNN_HF_ROW")) == 0 : 0;
+    // DGCNN_HF_ROW: 0 = never, 2 = whenever the shape allows (tests of the small, ragged shapes), otherwise by size
+    static const int mode = getenv("DGCNN_HF_ROW") ? atoi(getenv("DGCNN_HF_ROW")) : 1;
+    const bool off = mode == 0;
+    if (mode == 2) return a.K == RK && a.N % GN == 0;
     // (below about one and a half row blocks per CU the walk leaves CUs with one workgroup or none, and the product with a
     // workgroup per (row block, column block) is the faster one again: training step at B = 4, 219 row blocks: 2.134 ms
     // against 2.146; at B = 8, 438: 3.282 against 3.254)

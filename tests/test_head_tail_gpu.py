@@ -217,3 +217,29 @@ def test_head_tail_randomised_configurations():
             N = max(128, 700 // B)
         run_case(B, N, rnd.random() < 0.7, rnd.choice([0.0, 0.1, 0.5, 0.8]), seed=50 + case, NC=rnd.choice([2, 3, 5, 7, 8]),
                  cat_scale=10.0 ** rnd.uniform(-2, 2), cat_shift=rnd.choice([0.0, 0.0, 3.0, -20.0]))
+
+
+def test_row_stationary_products_on_small_and_ragged_shapes():
+    """conv6 / conv7 forward as the row-stationary kernel (hrow_kernel, head_fused.hip) is chosen by size (from 320 row blocks
+    up); a child process with DGCNN_HF_ROW=2 runs it on the small shapes -- tiles that straddle batch elements, a partial last
+    tile -- through the same float64 comparisons as the tests above and the embed test of test_edgeconv_gpu.py."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = (
+        "import sys, torch\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import test_head_tail_gpu as t, test_edgeconv_gpu as e\n"
+        "for B, N in ((2, 256), (3, 160), (1, 700), (5, 129)):\n"
+        "    t.run_case(B, N, True, 0.0, seed=B)\n"
+        "for B, N in ((2, 300), (1, 128)):\n"
+        "    t.run_case(B, N, False, 0.5, seed=7)\n"
+        "dev = torch.device('cuda:0')\n"
+        "for B, N, F, C in ((2, 1030, 192, 1024), (4, 257, 192, 1024), (3, 130, 192, 128)):\n"
+        "    for train in (True, False):\n"
+        "        e.test_head_embed_max_rows(B, N, F, C, train, True, dev)\n"
+        "print('row form ok')\n" % (os.path.dirname(here), here))
+    env = dict(os.environ, DGCNN_HF_ROW="2")
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "row form ok" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
