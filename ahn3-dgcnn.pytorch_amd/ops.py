@@ -173,6 +173,9 @@ class _EdgeConv(torch.autograd.Function):
                                           ws_bytes, _lib.stream_ptr(dev)), "dgcnn_edgeconv_fwd")
         ctx.save_for_backward(x_pm, idx, y, saved, w1c, g1c, b1c, w2c, g2c, b2c, rm1, rv1, rm2, rv2)
         ctx.cfg = (training, eps, momentum, slope, tuple(w1.shape), tuple(w2.shape) if w2 is not None else None)
+        # where the gradients of the parameters are to be written, if their owner has said so (parallel.FlatGradAllReduce:
+        # slices of its flat exchange buffer -- the backward then fills the buffer itself and nothing is packed)
+        ctx.sinks = tuple((t, getattr(t, "_dgcnn_grad_sink", None)) if t is not None else (None, None) for t in (w1, g1, b1, w2, g2, b2))
         return y
 
     @staticmethod
@@ -189,13 +192,24 @@ class _EdgeConv(torch.autograd.Function):
         g = _lib.EdgeConvGrads()
         need_x = ctx.needs_input_grad[0]
         gx = torch.empty_like(x_pm) if need_x else None
-        gw1 = torch.empty_like(w1c)
-        gg1, gb1 = torch.empty_like(g1c), torch.empty_like(b1c)
+
+        def out_like(ref, owner_sink):
+            # a NEW tensor object on the sink's memory (autograd keeps a gradient it alone refers to instead of cloning it).
+            # Only while the parameter has no gradient yet: an accumulating backward must not overwrite what .grad holds
+            owner, sink = owner_sink
+            if (sink is not None and owner.grad is None and sink.numel() == ref.numel() and sink.dtype == ref.dtype
+                    and sink.device == ref.device and sink.is_contiguous()):
+                return sink.detach().view(ref.shape)
+            return torch.empty_like(ref)
+
+        s_w1, s_g1, s_b1, s_w2, s_g2, s_b2 = ctx.sinks
+        gw1 = out_like(w1c, s_w1)
+        gg1, gb1 = out_like(g1c, s_g1), out_like(b1c, s_b1)
         g.gx = gx.data_ptr() if need_x else None
         g.gw1, g.gbn1_w, g.gbn1_b = gw1.data_ptr(), gg1.data_ptr(), gb1.data_ptr()
         gw2 = gg2 = gb2 = None
         if w2c is not None:
-            gw2, gg2, gb2 = torch.empty_like(w2c), torch.empty_like(g2c), torch.empty_like(b2c)
+            gw2, gg2, gb2 = out_like(w2c, s_w2), out_like(g2c, s_g2), out_like(b2c, s_b2)
             g.gw2, g.gbn2_w, g.gbn2_b = gw2.data_ptr(), gg2.data_ptr(), gb2.data_ptr()
         ws_bytes = lib.dgcnn_edgeconv_bwd_workspace_bytes(d)
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)

@@ -131,6 +131,9 @@ class FlatGradAllReduce:
             n = p.numel()
             self.views.append(self.flat[off:off + n].view_as(p))
             p.grad = self.views[-1]
+            # ops' backward passes write a parameter's gradient straight into its slice when they find this (ops._EdgeConv):
+            # `pack` then has nothing to copy for it
+            p._dgcnn_grad_sink = self.views[-1]
             off += n
 
     @property

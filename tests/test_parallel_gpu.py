@@ -162,3 +162,43 @@ def test_exchange_behind_the_c_abi_single_rank(device):
     with pytest.raises(TypeError):
         comm.all_reduce(torch.zeros(4, dtype=torch.float64, device=device))
     comm.close()
+
+
+def test_edgeconv_gradients_land_in_the_flat_buffer(device):
+    """FlatGradAllReduce names, per parameter, the slice of its exchange buffer (`_dgcnn_grad_sink`); the EdgeConv backward
+    writes the parameter gradients there, `pack` finds nothing to copy, and an accumulating backward (zero(set_to_none=False))
+    still adds up."""
+    from ahn3_dgcnn_pytorch_amd import ops
+    from ahn3_dgcnn_pytorch_amd.parallel import FlatGradAllReduce
+    torch.manual_seed(5)
+    B, N, C, k = 2, 300, 64, 12
+    conv = torch.nn.Conv2d(2 * C, 64, 1, bias=False).to(device)
+    bn = torch.nn.BatchNorm2d(64).to(device)
+    conv2 = torch.nn.Conv2d(64, 64, 1, bias=False).to(device)
+    bn2 = torch.nn.BatchNorm2d(64).to(device)
+    params = [conv.weight, bn.weight, bn.bias, conv2.weight, bn2.weight, bn2.bias]
+    x = torch.randn(B, N, C, device=device)
+    idx = ops.knn_pm(x, k)
+    cot = torch.randn(B, N, 64, device=device)
+
+    def run():
+        y = ops.edgeconv_pm(x, idx, conv.weight, bn, conv2.weight, bn2, training=True, slope=0.2)
+        y.backward(cot)
+
+    run()                                             # no sinks yet: plain gradients
+    want = [p.grad.clone() for p in params]
+    for p in params:
+        p.grad = None
+    sync = FlatGradAllReduce(params)
+    sync.zero()
+    run()
+    for p, v, w in zip(params, sync.views, want):
+        assert p.grad.data_ptr() == v.data_ptr(), "the gradient was not written into its slice"
+        assert torch.equal(p.grad, w)
+    flat = sync.sync().clone()
+    assert torch.equal(flat, torch.cat([w.reshape(-1) for w in want]))
+    sync.zero(set_to_none=False)                      # accumulation: .grad stays (zeroed) and two backward passes add up
+    run()
+    run()
+    for p, w in zip(params, want):
+        assert torch.allclose(p.grad, 2.0 * w, rtol=1e-6, atol=0.0)
