@@ -595,6 +595,86 @@ __global__ __launch_bounds__(256) void wgrad_fast64_kernel(const float *__restri
             partial[((size_t)blockIdx.x * 128 + mt * 32 + mfma32_row(r, h)) * 64 + nt * 32 + i32] = acc[nt][r];
 }
 
+// The same product on the fp16 matrix cores (the fp32 kernel above is bound by its 256 matrix instructions of 64 cycles per
+// wave: 21.5 us at P = 56 000 against 9.4 at the fp32 MFMA peak).  The contraction runs over the POINTS, so a lane's eight
+// consecutive k of an operand are eight points of its channel: eight 4-byte loads, each a 128-byte row segment per half
+// wave.  A wave takes its 256 points in four chunks of 64: the chunk's values wait in registers (32 of A, 64 of X per
+// lane), their largest magnitudes give the chunk's two exact power-of-two scales (gradients of any size, no range check),
+// both operands are split in two fp16 halves (edge_mlp16.h) and four steps of three v_mfma_f32_32x32x16_f16 per tile go
+// to a chunk accumulator, which joins the total with 1 / (sA sB): 96 matrix instructions of 32 cycles per wave.
+__global__ __launch_bounds__(256) void wgrad_split64_kernel(const float *__restrict__ A0, const float *__restrict__ A1,
+                                                            const float *__restrict__ X, int P, float *__restrict__ partial)
+{
+    const int lane = threadIdx.x & 63, mt = threadIdx.x >> 6, h = lane >> 5, i32 = lane & 31;
+    const int pbeg = blockIdx.x * WGRAD_FAST_POINTS;
+    const int pend = pbeg + WGRAD_FAST_POINTS < P ? pbeg + WGRAD_FAST_POINTS : P;
+    const float *A = (mt < 2 ? A0 : A1) + (mt & 1) * 32;
+    f32x16 acc[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
+    for (int p0 = pbeg; p0 < pend; p0 += 64) {
+        float av[32], bv[2][32];
+        float amax = 0.0f, bmax = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {  // value q of the lane: point p0 + 16 (q / 8) + 8 h + q % 8
+            const int pp = p0 + 16 * (q >> 3) + 8 * h + (q & 7);
+            const bool pv = pp < pend;
+            const size_t ro = (size_t)(pv ? pp : pbeg) * 64 + i32;  // clamped row: unconditional loads, masked values
+            const float a0 = A[ro], b0 = X[ro], b1 = X[ro + 32];
+            av[q] = pv ? a0 : 0.0f;
+            bv[0][q] = pv ? b0 : 0.0f;
+            bv[1][q] = pv ? b1 : 0.0f;
+        }
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+            amax = fmaxf(amax, fabsf(av[q]));
+            bmax = fmaxf(bmax, fmaxf(fabsf(bv[0][q]), fabsf(bv[1][q])));
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            amax = fmaxf(amax, __shfl_xor(amax, o));
+            bmax = fmaxf(bmax, __shfl_xor(bmax, o));
+        }
+        const float sA = scale_to(amax, 15), sB = scale_to(bmax, 15);
+        f32x16 cacc[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cacc[nt][r] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            unsigned H[4], L[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) split_pair(av[8 * s + 2 * j] * sA, av[8 * s + 2 * j + 1] * sA, H[j], L[j]);
+            const half8 ahi = words_as_half8(H[0], H[1], H[2], H[3]), alo = words_as_half8(L[0], L[1], L[2], L[3]);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) split_pair(bv[nt][8 * s + 2 * j] * sB, bv[nt][8 * s + 2 * j + 1] * sB, H[j], L[j]);
+                const half8 bhi = words_as_half8(H[0], H[1], H[2], H[3]), blo = words_as_half8(L[0], L[1], L[2], L[3]);
+                cacc[nt] = mfma3(ahi, alo, bhi, blo, cacc[nt]);
+            }
+        }
+        const float un = 1.0f / (sA * sB);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = __builtin_fmaf(cacc[nt][r], un, acc[nt][r]);
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            partial[((size_t)blockIdx.x * 128 + mt * 32 + mfma32_row(r, h)) * 64 + nt * 32 + i32] = acc[nt][r];
+}
+static bool wgrad_force_f32()  // experiments / tests: the fp32-MFMA form of the first convolution's weight gradient
+{
+    static const int v = getenv("DGCNN_WGRAD1_F32") ? atoi(getenv("DGCNN_WGRAD1_F32")) : 0;
+    return v != 0;
+}
+
 // partials of launch_wgrad (the caller sizes the buffer and passes the count to launch_finish_dw1)
 int wgrad_chunks(int P, int C) { return ceil_div(P, C == 64 ? WGRAD_FAST_POINTS : WGRAD_CHUNK); }
 
@@ -604,7 +684,8 @@ void launch_wgrad(const float *A0, int M0, const float *A1, int M1, const float 
     // (M0 = M1 = 64 always: the stage widths of the model; C = 64 takes the four-wave kernel)
     const dim3 grid(wgrad_chunks(P, C)), block(64);
     if (C == 64) {
-        hipLaunchKernelGGL(wgrad_fast64_kernel, grid, dim3(256), 0, st, A0, A1, X, P, partial);
+        if (wgrad_force_f32()) hipLaunchKernelGGL(wgrad_fast64_kernel, grid, dim3(256), 0, st, A0, A1, X, P, partial);
+        else hipLaunchKernelGGL(wgrad_split64_kernel, grid, dim3(256), 0, st, A0, A1, X, P, partial);
         return;
     }
     const int mt = ceil_div(M0 + M1, 32), nt = ceil_div(C, 32);
