@@ -377,8 +377,8 @@ def run_block(args, rank, world, dev):
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32 (results); the kNN pre-filter runs on f16 MFMA and is followed by an exact f32 refine "
-                 "(indices bit-exact vs the f32 oracle); the first convolution's forward and weight gradient on f32 MFMA, "
-                 "its input gradient%s as split-f16 MFMA products (hi.hi + hi.lo + lo.hi, 2^-22 relative)" %
+                 "(indices bit-exact vs the f32 oracle); the first convolution's forward on f32 MFMA, "
+                 "its input and weight gradients%s as split-f16 MFMA products (hi.hi + hi.lo + lo.hi, 2^-22 relative)" %
                  (" and the second convolution" if args.stages == 2 else ""),
         "data": "synthetic",
         "config": {"workload": "single EdgeConv block fwd+bwd (kNN graph build + conv 128->64%s + BN(train) + "
