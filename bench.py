@@ -172,12 +172,24 @@ def sample_stride(args, steps):
 def timed_steps(step, n, every, dev):
     """EXACTLY n steps between two fences; `step(sampled)` with sampled=True on every `every`-th.  Returns the wall
     time, max over ranks."""
+    import gc
+    gc.collect()
+    gc.disable()   # (a generation-2 collection inside the region is a 10 ms host stall: twenty 0.5 ms steps then read 1.1 ms)
     fence()
     t0 = time.perf_counter()
+    marks = []
     for i in range(n):
         step(every > 0 and i % every == every // 2)   # (the middle of each stride: never the first step behind the fence)
+        if os.environ.get("DGCNN_BENCH_DEBUG"):
+            marks.append(time.perf_counter() - t0)
+    t1 = time.perf_counter() - t0
     fence()
-    return max_over_ranks(time.perf_counter() - t0, dev)
+    dt = time.perf_counter() - t0
+    gc.enable()
+    if os.environ.get("DGCNN_BENCH_DEBUG"):
+        sys.stderr.write("timed region: enqueue %.3f ms, total %.3f ms; host marks (ms): %s\n" % (
+            t1 * 1e3, dt * 1e3, " ".join("%.2f" % (m * 1e3) for m in marks)))
+    return max_over_ranks(dt, dev)
 
 
 def per_step_ms(step, n):
