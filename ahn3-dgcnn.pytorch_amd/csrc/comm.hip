@@ -38,15 +38,25 @@ int rccl_api(const RcclApi **out)
 {
     static RcclApi api;
     static int state = 0;  // 0 = not tried, 1 = ok, -1 = failed
+    static char why[256] = "";  // the FIRST failure's message (dlerror() hands its string over once), reported on every later call
     if (state == 0) {
         void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);  // the copy the process already holds (PyTorch's)
         if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
         if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
         if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
         bool ok = h != nullptr;
-        if (ok) {
+        if (!ok) {
+            const char *e = dlerror();
+            snprintf(why, sizeof(why), "%s", e ? e : "dlopen failed");
+        } else {
             api.lib = h;
-#define DG_SYM(field, name) ok = ok && ((*(void **)(&api.field) = dlsym(h, name)) != nullptr)
+#define DG_SYM(field, name)                                                                      \
+    do {                                                                                         \
+        if (ok && (*(void **)(&api.field) = dlsym(h, name)) == nullptr) {                        \
+            ok = false;                                                                          \
+            snprintf(why, sizeof(why), "symbol %s is missing", name);                            \
+        }                                                                                        \
+    } while (0)
             DG_SYM(GetUniqueId, "ncclGetUniqueId");
             DG_SYM(CommInitRank, "ncclCommInitRank");
             DG_SYM(CommDestroy, "ncclCommDestroy");
@@ -55,13 +65,14 @@ int rccl_api(const RcclApi **out)
             DG_SYM(GetErrorString, "ncclGetErrorString");
             DG_SYM(GetVersion, "ncclGetVersion");
 #undef DG_SYM
+            if (!ok) {
+                dlclose(h);
+                api.lib = nullptr;
+            }
         }
         state = ok ? 1 : -1;
     }
-    if (state != 1) {
-        const char *why = dlerror();  // (one call: it hands the message over and clears it)
-        DG_FAIL("dgcnn_comm: librccl.so.1 could not be loaded (%s)", why ? why : "a symbol is missing");
-    }
+    if (state != 1) DG_FAIL("dgcnn_comm: librccl.so.1 could not be loaded (%s)", why);
     *out = &api;
     return 0;
 }

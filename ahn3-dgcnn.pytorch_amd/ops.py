@@ -196,9 +196,14 @@ class _EdgeConv(torch.autograd.Function):
         def out_like(ref, owner_sink):
             # a NEW tensor object on the sink's memory (autograd keeps a gradient it alone refers to instead of cloning it).
             # Only while the parameter has no gradient yet: an accumulating backward must not overwrite what .grad holds
+            # and only ONCE per zero() / pack() cycle of the owner (parallel.FlatGradAllReduce clears the claim): a parameter
+            # that feeds two nodes of one backward has no .grad yet when the second node runs -- both would write the slice
+            # and autograd would add the aliased tensors
             owner, sink = owner_sink
-            if (sink is not None and owner.grad is None and sink.numel() == ref.numel() and sink.dtype == ref.dtype
+            if (sink is not None and owner.grad is None and not getattr(owner, "_dgcnn_sink_claimed", False)
+                    and owner.requires_grad and sink.numel() == ref.numel() and sink.dtype == ref.dtype
                     and sink.device == ref.device and sink.is_contiguous()):
+                owner._dgcnn_sink_claimed = True
                 return sink.detach().view(ref.shape)
             return torch.empty_like(ref)
 

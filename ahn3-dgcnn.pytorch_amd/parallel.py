@@ -143,6 +143,8 @@ class FlatGradAllReduce:
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
 
     def zero(self, set_to_none=True):
+        for p in self.params:
+            p._dgcnn_sink_claimed = False   # a new cycle: each sink may be handed out once again (ops._EdgeConv.backward)
         if set_to_none:
             for p in self.params:
                 p.grad = None
@@ -156,6 +158,7 @@ class FlatGradAllReduce:
         .grad is a view of its slice again"""
         src, dst = [], []
         for p, v in zip(self.params, self.views):
+            p._dgcnn_sink_claimed = False
             if p.grad is None:
                 v.zero_()
             elif p.grad.data_ptr() != v.data_ptr():

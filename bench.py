@@ -77,6 +77,10 @@ def parse_args():
                     help="nccl = RCCL over xGMI (the product path); gloo only to rehearse the N-rank code on a box "
                          "with fewer GPUs than ranks (together with --same-device)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--graph-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-graph-leg", action="store_true", help="block workload: skip the hipGraph replay of the step (a child process)")
+    ap.add_argument("--no-model-legs", action="store_true", help="block workload: skip the `eval_forward` (configs[2]) and `stress` (configs[4]) objects")
+    ap.add_argument("--no-stress-cpu", action="store_true", help="skip the CPU baseline of the stress leg (B=1, N=32768: tens of GB of host memory)")
     ap.add_argument("--exchange", default="torch", choices=("torch", "abi"),
                     help="the gradient all-reduce: torch.distributed's RCCL binding (default) or the library's own, behind the C "
                          "ABI (dgcnn_comm_allreduce_f32; the id is handed out over the torch.distributed group)")
@@ -171,25 +175,30 @@ def sample_stride(args, steps):
 
 def timed_steps(step, n, every, dev):
     """EXACTLY n steps between two fences; `step(sampled)` with sampled=True on every `every`-th.  Returns the wall
-    time, max over ranks."""
+    time (max over ranks) and this rank's host timeline of the region: `host_enqueue_ms` = the time the host took to
+    enqueue the n steps (when it is close to `region_total_ms` the host, not the GPU, paced the region), `region_total_ms`
+    = enqueue + the wait of the final fence."""
     import gc
     gc.collect()
     gc.disable()   # (a generation-2 collection inside the region is a 10 ms host stall: twenty 0.5 ms steps then read 1.1 ms)
-    fence()
-    t0 = time.perf_counter()
     marks = []
-    for i in range(n):
-        step(every > 0 and i % every == every // 2)   # (the middle of each stride: never the first step behind the fence)
-        if os.environ.get("DGCNN_BENCH_DEBUG"):
-            marks.append(time.perf_counter() - t0)
-    t1 = time.perf_counter() - t0
-    fence()
-    dt = time.perf_counter() - t0
-    gc.enable()
-    if os.environ.get("DGCNN_BENCH_DEBUG"):
+    debug = bool(os.environ.get("DGCNN_BENCH_DEBUG"))
+    try:
+        fence()
+        t0 = time.perf_counter()
+        for i in range(n):
+            step(every > 0 and i % every == every // 2)   # (the middle of each stride: never the first step behind the fence)
+            if debug:
+                marks.append(time.perf_counter() - t0)
+        t1 = time.perf_counter() - t0
+        fence()
+        dt = time.perf_counter() - t0
+    finally:
+        gc.enable()
+    if debug:
         sys.stderr.write("timed region: enqueue %.3f ms, total %.3f ms; host marks (ms): %s\n" % (
             t1 * 1e3, dt * 1e3, " ".join("%.2f" % (m * 1e3) for m in marks)))
-    return max_over_ranks(dt, dev)
+    return max_over_ranks(dt, dev), {"host_enqueue_ms": t1 * 1e3, "region_total_ms": dt * 1e3}
 
 
 def per_step_ms(step, n):
@@ -260,24 +269,60 @@ def make_stages(C, n_stage, device):
     return stages
 
 
-def cpu_threads():
+REF_THREADS = 8   # the reference's own default: torch.set_num_threads(8), train.py:36
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or "unknown"
+
+
+def cpu_threads(want=None):
     import torch
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     # measured on the MI355X box's host (256 hardware threads): 8 / 16 / 32 / 64 / 128 / 256 threads give
-    # 20.6 / 20.4 / 25.1 / 19.0 / 12.0 / 3.9 k points/s on the block, so the baseline runs at its best setting, 32
-    # (the reference's own default is 8, train.py:36)
-    n = min(avail, 32)
+    # 20.6 / 20.4 / 25.1 / 19.0 / 12.0 / 3.9 k points/s on the block, so the baseline's `value` is taken at its best
+    # setting, 32; the reference's own default of 8 (train.py:36) is reported beside it
+    n = min(avail, want or 32)
     torch.set_num_threads(n)
     return n, avail
 
 
-def cpu_baseline_block(B, N, k, C, n_stage, steps=4):
+def cpu_timed(step, steps):
+    step()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    return time.perf_counter() - t0
+
+
+def cpu_both_thread_counts(step, steps, units_per_step):
+    """`step` timed at the best thread count (-> value, cores) and at the reference's default of 8 threads"""
+    import torch
+    best, avail = cpu_threads()
+    dt_best = cpu_timed(step, steps)
+    ref, _ = cpu_threads(REF_THREADS)
+    dt_ref = dt_best if ref == best else cpu_timed(step, steps)
+    cpu_threads()
+    return {"value": units_per_step * steps / dt_best, "unit": "points/s", "cores": best, "kind": "port",
+            "cpu_model": cpu_model(), "hardware_threads": avail,
+            "value_at_reference_threads": units_per_step * steps / dt_ref, "reference_threads": ref,
+            "torch": torch.__version__, "seconds": dt_best + (0.0 if ref == best else dt_ref)}
+
+
+def cpu_baseline_block(B, N, k, C, n_stage, steps=2):
     """The reference's CPU path (restated op-for-op in oracle/torch_ref.py: materialised BxNxN
     distances, topk, gather/repeat/cat, Conv2d, BatchNorm2d, LeakyReLU, max) fwd+bwd on the host."""
     import torch
     from oracle import torch_ref
     from param_fill import cotangent
-    nthreads, avail = cpu_threads()
     stages = make_stages(C, n_stage, torch.device("cpu"))
     x = torch.randn(B, C, N, generator=torch.Generator().manual_seed(0))
     R = cotangent((B, 64, N), tag="bench")
@@ -287,15 +332,11 @@ def cpu_baseline_block(B, N, k, C, n_stage, steps=4):
         y = torch_ref.edgeconv_block(xr, k, stages)
         (y * R).sum().backward()
 
-    step()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    dt = time.perf_counter() - t0
-    return {"value": B * N * steps / dt, "unit": "points/s", "cores": nthreads, "kind": "port",
-            "sample": "B=%d of the workload's 8 batch elements (same N=%d, k=%d, C=%d, %d-stage block), "
-                      "%d fwd+bwd steps after 1 warm-up, %.1f s, torch %s with %d of %d hardware threads" % (
-                          B, N, k, C, n_stage, steps, dt, torch.__version__, nthreads, avail)}
+    out = cpu_both_thread_counts(step, steps, B * N)
+    out["sample"] = ("B=%d of the workload's 8 batch elements (same N=%d, k=%d, C=%d, %d-stage block), %d fwd+bwd steps after 1 "
+                     "warm-up at each thread count (%d = best measured on this host class, %d = the reference's default, "
+                     "train.py:36), %.1f s in all" % (B, N, k, C, n_stage, steps, out["cores"], out["reference_threads"], out["seconds"]))
+    return out
 
 
 def run_block(args, rank, world, dev):
@@ -337,7 +378,7 @@ def run_block(args, rank, world, dev):
         step(False)
     lib.dgcnn_profile_enable(1)  # reset the sample rings ...
     lib.dgcnn_profile_enable(0)  # ... recording is switched on for the sampled steps only
-    dt = timed_steps(step, args.steps, sample_stride(args, args.steps), dev)
+    dt, host = timed_steps(step, args.steps, sample_stride(args, args.steps), dev)
     knn_ms = sum(a.elapsed_time(b) for a, b in knn_events) / max(1, len(knn_events))
     regions = region_times(lib)
     dist_ms = per_step_ms(step, min(args.steps, 50))
@@ -385,6 +426,11 @@ def run_block(args, rank, world, dev):
         "ms_per_step": dt / args.steps * 1e3,
         "ms_per_step_median": statistics.median(dist_ms),
         "ms_per_step_p10_p90": [sorted(dist_ms)[len(dist_ms) // 10], sorted(dist_ms)[(len(dist_ms) * 9) // 10]],
+        "host_enqueue_ms": host["host_enqueue_ms"],
+        "region_total_ms": host["region_total_ms"],
+        "host_timeline_note": "rank 0's host clock over the timed region: the %d steps were enqueued in host_enqueue_ms; "
+                              "region_total_ms adds the final fence (= ms_per_step x steps on one rank).  enqueue ~ total means "
+                              "the host paced the region, enqueue << total means the GPU did" % args.steps,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -424,12 +470,11 @@ def synthetic_blocks(B, N, seed):
     return pts, lab
 
 
-def cpu_baseline_train(B, N, k, steps=2):
+def cpu_baseline_train(B, N, k, steps=1):
     """the reference's training step on the host: RefDGCNN (model.py:144-193 op for op) forward, softmax + cal_loss
     (train.py:180,197), backward, torch.optim.Adam step (train.py:118,199)"""
     import torch
     from oracle import seg_ref, torch_ref
-    nthreads, avail = cpu_threads()
     torch.manual_seed(0)
     m = torch_ref.RefDGCNN(5, 4, k, dropout=0.5)
     m.train()
@@ -443,25 +488,45 @@ def cpu_baseline_train(B, N, k, steps=2):
         loss.backward()
         opt.step()
 
-    step()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    dt = time.perf_counter() - t0
-    return {"value": B * N * steps / dt, "unit": "points/s", "cores": nthreads, "kind": "port",
-            "sample": "B=%d of the workload's 32 blocks (same N=%d, k=%d, full DGCNN training step), %d steps after 1 "
-                      "warm-up, %.1f s, torch %s with %d of %d hardware threads" % (
-                          B, N, k, steps, dt, torch.__version__, nthreads, avail)}
+    out = cpu_both_thread_counts(step, steps, B * N)
+    out["sample"] = ("B=%d of the workload's blocks (same N=%d, k=%d, full DGCNN training step), %d step(s) after 1 warm-up at each "
+                     "thread count (%d and the reference's %d), %.1f s in all" % (
+                         B, N, k, steps, out["cores"], out["reference_threads"], out["seconds"]))
+    return out
 
 
-def run_train(args, rank, world, dev, steps, warmup, with_cpu):
+def cpu_baseline_eval(B, N, k, scale_to, steps=1):
+    """the reference's inference forward on the host (RefDGCNN.eval(), model.py:144-193), on B batch elements; the
+    GPU leg runs `scale_to` of them: batch elements are independent in eval mode, so points/s carries over
+    (where the reference formulation does not fit at the full batch, time B=1 and say so)"""
+    import torch
+    from oracle import torch_ref
+    torch.manual_seed(0)
+    m = torch_ref.RefDGCNN(5, 4, k, dropout=0.5)
+    m.eval()
+    pts, _ = synthetic_blocks(B, N, 0)
+    x = pts.permute(0, 2, 1).float()
+
+    def step():
+        with torch.no_grad():
+            m(x)
+
+    out = cpu_both_thread_counts(step, steps, B * N)
+    out["sample"] = ("B=%d of the leg's %d batch elements (points/s of B=%d; x%d in batch = the same rate: eval-mode batch elements "
+                     "are independent), N=%d, k=%d, full DGCNN eval forward with the materialised B x N x N distances, %d "
+                     "forward(s) after 1 warm-up at each thread count (%d and the reference's %d), %.1f s in all" % (
+                         B, scale_to, B, scale_to // B, N, k, steps, out["cores"], out["reference_threads"], out["seconds"]))
+    return out
+
+
+def run_train(args, rank, world, dev, steps, warmup, with_cpu, global_batch=None):
     import torch
     import torch.distributed as dist
     from ahn3_dgcnn_pytorch_amd import DGCNN, _lib, blocks, ops
     from ahn3_dgcnn_pytorch_amd.optim import FlatAdam
     from ahn3_dgcnn_pytorch_amd.parallel import FlatGradAllReduce, broadcast, shard_batch
 
-    Bg, N, k = (args.batch if args.workload == "train" and args.batch else 32), args.points, args.k
+    Bg, N, k = (global_batch or (args.batch if args.workload == "train" and args.batch else 32)), args.points, args.k
     if Bg % world:
         raise SystemExit("bench.py: global batch %d is not divisible by %d ranks" % (Bg, world))
     Bl = Bg // world
@@ -501,7 +566,7 @@ def run_train(args, rank, world, dev, steps, warmup, with_cpu):
         step(False)
     lib.dgcnn_profile_enable(1)
     lib.dgcnn_profile_enable(0)
-    dt = timed_steps(step, steps, sample_stride(args, steps), dev)
+    dt, host = timed_steps(step, steps, sample_stride(args, steps), dev)
     regions = region_times(lib)
     ar_ms = sum(a.elapsed_time(b) for a, b in ar_events) / max(1, len(ar_events))
     dist_ms = per_step_ms(step, min(steps, 20))
@@ -557,6 +622,8 @@ def run_train(args, rank, world, dev, steps, warmup, with_cpu):
         "warmup": warmup,
         "ms_per_step": dt / steps * 1e3,
         "ms_per_step_median": statistics.median(dist_ms),
+        "host_enqueue_ms": host["host_enqueue_ms"],
+        "region_total_ms": host["region_total_ms"],
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
@@ -576,14 +643,205 @@ def run_train(args, rank, world, dev, steps, warmup, with_cpu):
         "kernels": kernels[1:],
     }
     if with_cpu:
-        out["cpu_baseline"] = cpu_baseline_train(args.cpu_sample_batch or 2, N, k)
+        out["cpu_baseline"] = cpu_baseline_train(args.cpu_sample_batch or 2, N, k, steps=2)
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
     return out
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+# legs "eval_forward" (BASELINE.json configs[2]) and "stress" (configs[4]): the full DGCNN on one GPU
+def model_work(B, N, k, training):
+    """algorithmic work per launch of the profiled kernel groups inside one full-model pass.  A group's launches differ
+    in shape (the kNN of block 1 searches 4 channels, blocks 2 and 3 search 64): the entry is the MEAN over the group's
+    launches of a pass, so that work / mean time = (sum of work) / (sum of time)."""
+    P, E = B * N, B * N * k
+    chans = (4, 64, 64)
+    knn_flops = sum(2.0 * B * N * N * c for c in chans) / 3
+    refine = sum(E * (4.0 * c + 12) for c in chans) / 3
+    conv2 = 2.0 * E * 64 * 64
+    full_reduce = E * 260.0 + P * 832.0
+    sums_only = E * 260.0 + P * 512.0
+    F_, C6, C7, C8 = 192, 1024, 512, 256
+    return {
+        "knn_bound16s_kernel": ("mfma", knn_flops, PEAK_F16_MFMA_TFLOPS,
+                                "threshold pre-pass of the three kNN builds (4, 64, 64 channels): mean 2 B N^2 C flops per launch"),
+        "knn_filter16_kernel": ("mfma", knn_flops, PEAK_F16_MFMA_TFLOPS,
+                                "exact fp16 filter of the three kNN builds: mean 2 B N^2 C flops per launch"),
+        "knn_refine_kernel": ("l2-gather", refine, PEAK_L2_GATHER_GBS,
+                              "exact fp32 distances of at least the k winners of every row, mean over the three builds"),
+        "edge_reduce_kernel": ("l2-gather", (2 * sums_only + full_reduce) / 3 if training else full_reduce, PEAK_L2_GATHER_GBS,
+                               "per edge one fp32 [64] row of TP and its index" + (
+                                   "; two of the three launches only take the BatchNorm sums (two-stage blocks)" if training else
+                                   " (eval: the one-stage block only)")),
+        "edge_rgather_kernel": ("l2-gather", (2 * (E * 516.0) + E * 292.0) / 3 + P * 520.0, PEAK_L2_GATHER_GBS,
+                                "reverse gather of the three blocks' backward (two dense: TQ row + dv1 row per in-edge)"),
+        "edge_mlp_fwd_kernel": ("mfma", conv2, PEAK_F16_MFMA_TFLOPS, "conv2 / conv4 per edge, 2 E 64 64 flops per launch (3 split-fp16 products executed)"),
+        "edge_mlp_bwd_kernel": ("mfma", 2 * conv2, PEAK_F16_MFMA_TFLOPS, "dgrad + wgrad of conv2 / conv4, 2 x 2 E 64 64 flops per launch"),
+        "head_conv6_kernel": ("mfma", 2.0 * P * F_ * C6, PEAK_F16_MFMA_TFLOPS, "conv6 + statistics + max over the points, 2 P 192 1024 flops; nothing stored"),
+        "head_conv7_kernel": ("hbm", 4.0 * P * (F_ + C7), PEAK_HBM_GBS, "reads cat [P, 192], writes u7 [P, 512]"),
+        "head_conv8_kernel": ("hbm", 4.0 * P * (C7 + C8), PEAK_HBM_GBS, "reads u7, writes u8 [P, 256]"),
+        "head_dz7_kernel": ("hbm", 4.0 * P * (2 * C8 + 2 * C7), PEAK_HBM_GBS, "reads dv8, u8, u7, writes dv7"),
+        "head_dcat_kernel": ("hbm", 4.0 * P * (2 * C7 + F_), PEAK_HBM_GBS, "reads dv7, u7, writes dL/dcat"),
+        "head_dw8_kernel": ("hbm", 4.0 * P * (2 * C8 + C7), PEAK_HBM_GBS, "reads dv8, u8, u7 once"),
+        "head_dw7_kernel": ("hbm", 4.0 * P * (2 * C7 + F_), PEAK_HBM_GBS, "reads dv7, u7, cat once"),
+    }
+
+
+def sampled_pass(lib, fn, n):
+    """mean wall time of fn over n calls between two fences (no events inside), then ONE more call with the per-kernel
+    events recorded"""
+    import torch
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    lib.dgcnn_profile_enable(1)
+    fn()
+    lib.dgcnn_profile_enable(0)
+    torch.cuda.synchronize()
+    return dt, region_times(lib)
+
+
+def run_model_leg(args, dev, B, N, k, which, steps, with_train, cpu_batch, with_cpu):
+    """full DGCNN on ONE GPU: eval forward (test.py:122 form: model.eval(), no_grad) and, with_train, the training step of
+    run_train's shape at batch B.  Inputs resident in HBM in the strides train.py:176 / test.py:119 hand over."""
+    import torch
+    from ahn3_dgcnn_pytorch_amd import DGCNN, _lib, blocks, ops
+    from ahn3_dgcnn_pytorch_amd.optim import FlatAdam
+    lib = _lib.load()
+    torch.manual_seed(0)
+    model = DGCNN(5, 4, k, dropout=0.5, emb_dims=1024, cuda=True)
+    pts, lab = synthetic_blocks(B, N, 0)
+    pts, lab = pts.to(dev), lab.to(dev)
+    x = blocks.to_model_input(pts)
+    model.eval()
+
+    def fwd():
+        with torch.no_grad():
+            model(x)
+
+    dt, regions = sampled_pass(lib, fwd, steps)
+    kernels = kernel_entries(regions, model_work(B, N, k, False), {})
+    out = {
+        "metric": "DGCNN eval-forward points/sec (B=%d,N=%d,k=%d)" % (B, N, k),
+        "value": B * N / dt, "unit": "points/s", "n_gpus": 1, "steps": steps, "ms_per_step": dt * 1e3,
+        "higher_is_better": True, "data": "synthetic",
+        "dtype": "f32 (results); kNN pre-filter on f16 MFMA (exact f32 refine); conv2/conv4 and the head's products as split-f16 "
+                 "MFMA products (hi.hi + hi.lo + lo.hi, 2^-22 relative) -- the fp16-MFMA edge-MLP of BASELINE.json configs[4]; a "
+                 "one-product fp16 mode (2^-11 operand error) is not offered: logits would leave the 1e-4 parity bound",
+        "config": {"workload": "full DGCNN segmentation forward, eval mode (4 EdgeConv stages in 3 blocks + emb_dims=1024 head), %s"
+                               % which, "batch": B, "points": N, "k": k, "emb_dims": 1024, "launch": "eager"},
+        "roofline": kernels[0] if kernels else None,
+        "kernels": kernels[1:],
+    }
+    if with_cpu:
+        out["cpu_baseline"] = cpu_baseline_eval(cpu_batch, N, k, B)
+        out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+    if with_train:
+        model.train()
+        opt = FlatAdam(model.parameters(), lr=1e-3, weight_decay=1e-4)
+
+        def step():
+            xx = blocks.to_model_input(pts)
+            opt.zero_grad()
+            loss, _pred = ops.seg_loss(model(xx), lab)
+            loss.backward()
+            opt.step()
+
+        dts, regions = sampled_pass(lib, step, max(3, steps // 2))
+        kt = kernel_entries(regions, model_work(B, N, k, True), {})
+        out["train_step"] = {"metric": "DGCNN training-step points/sec (B=%d,N=%d,k=%d, one GPU)" % (B, N, k),
+                             "value": B * N / dts, "unit": "points/s", "ms_per_step": dts * 1e3,
+                             "roofline": kt[0] if kt else None, "kernels": kt[1:]}
+    del model
+    torch.cuda.empty_cache()
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# graph-replay leg: the block step captured once in a FRESH process and replayed (no launch latency, no host in the loop)
+def graph_child(args):
+    """runs in a child process that has done nothing else on the GPU (PyTorch-ROCm 2.10's stream capture crashes when
+    results of eager steps are alive at capture time: DESIGN.md section 10).  Captures kNN + EdgeConv fwd + bwd of the block
+    workload once, replays it --steps times between two events and prints one JSON line."""
+    import torch
+    from ahn3_dgcnn_pytorch_amd import ops
+    from param_fill import cotangent
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    B, N, k, C = args.batch or 8, args.points, args.k, args.channels
+    stages = make_stages(C, args.stages, dev)
+    params = [p for st in stages for p in st.parameters()]
+    x_pm = torch.randn(B, N, C, generator=torch.Generator().manual_seed(1000)).to(dev).requires_grad_(True)
+    cot = cotangent((B, 64, N), tag="bench").to(dev).transpose(1, 2).contiguous()
+    w2 = stages[1][0].weight if args.stages == 2 else None
+    bn2 = stages[1][1] if args.stages == 2 else None
+
+    def step():
+        x_pm.grad = None
+        for p in params:
+            p.grad = None
+        idx = ops.knn_pm(x_pm, k)
+        y = ops.edgeconv_pm(x_pm, idx, stages[0][0].weight, stages[0][1], w2, bn2, training=True, slope=0.2)
+        y.backward(cot)
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step()
+    for _ in range(max(3, args.warmup)):
+        graph.replay()
+    torch.cuda.synchronize()
+    n = args.steps
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(n):
+        graph.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    print(json.dumps({"ms_per_step_graph": e0.elapsed_time(e1) / n, "ms_per_step_graph_wall": wall / n * 1e3, "replays": n,
+                      "note": "one hipGraph of the block step (kNN build + EdgeConv forward + backward) captured in a fresh "
+                              "process and replayed %d times between two HIP events: what the step costs without launch latency "
+                              "or a host in the loop; `value` stays the eager number" % n}), flush=True)
+
+
+def run_graph_child(args):
+    """parent side: spawn the child BEFORE this process makes its first GPU call; relay its line (None on any failure:
+    a crash of the capture must not take the bench line with it)"""
+    cmd = [sys.executable, os.path.abspath(__file__), "--graph-child", "--steps", str(max(20, args.steps)), "--warmup", str(args.warmup),
+           "--stages", str(args.stages), "--points", str(args.points), "--k", str(args.k), "--channels", str(args.channels)]
+    if args.batch:
+        cmd += ["--batch", str(args.batch)]
+    try:
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    except Exception as e:  # noqa: BLE001
+        return {"error": "graph child: %r" % (e,)}
+    for line in reversed(p.stdout.splitlines()):
+        if line.startswith("{"):
+            try:
+                return json.loads(line)
+            except ValueError:
+                break
+    return {"error": "graph child exited with %d" % p.returncode, "stderr_tail": p.stderr[-400:]}
+
+
+# ----------------------------------------------------------------------------------------------------------------------
 def main():
     args = parse_args()
+    if args.graph_child:
+        return graph_child(args)
     if "RANK" not in os.environ and args.gpus > 1:
         raise SystemExit(self_launch(args))
 
@@ -592,18 +850,42 @@ def main():
     if os.environ.get("NCCL_DEBUG", "VERSION").upper() in ("VERSION", "INFO"):
         os.environ["NCCL_DEBUG"] = "WARN"
     os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
+    single = int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus == 1
+    graph_leg = None
+    if single and args.workload == "block" and not args.no_graph_leg:
+        graph_leg = run_graph_child(args)      # before this process touches the GPU
     import torch.distributed as dist
 
     rank, world, dev = init_ranks(args)
     cpu = world == 1 and not args.no_cpu_baseline
-    if args.workload == "train":
-        out = run_train(args, rank, world, dev, args.steps, args.warmup, cpu)
-    else:
-        out = run_block(args, rank, world, dev)
-        if not args.no_train_leg:
-            leg = run_train(args, rank, world, dev, args.train_steps, 3, cpu)
-            if out is not None:
-                out["train_step"] = leg
+    try:
+        if args.workload == "train":
+            out = run_train(args, rank, world, dev, args.steps, args.warmup, cpu)
+        else:
+            out = run_block(args, rank, world, dev)
+            if out is not None and graph_leg is not None:
+                out["graph_replay"] = graph_leg
+                if "ms_per_step_graph" in graph_leg:
+                    out["ms_per_step_graph"] = graph_leg["ms_per_step_graph"]
+            if not args.no_train_leg:
+                leg = run_train(args, rank, world, dev, args.train_steps, 3, cpu)
+                if world == 1 and leg is not None:
+                    # the per-GPU share of the 8-GPU run of the same global batch, measured on this one GPU: what strong
+                    # scaling to 8 ranks can reach before the all-reduce (t(B=32) / t(B=4))
+                    b4 = run_train(args, rank, world, dev, args.train_steps, 3, False, global_batch=4)
+                    leg["per_gpu_share_of_8"] = {k_: b4[k_] for k_ in ("ms_per_step", "ms_per_step_median", "value", "host_enqueue_ms",
+                                                                         "region_total_ms")}
+                    leg["per_gpu_share_of_8"]["global_batch"] = 4
+                    leg["projected_strong_scaling_8"] = leg["ms_per_step"] / b4["ms_per_step"]
+                if out is not None:
+                    out["train_step"] = leg
+            if world == 1 and not args.no_model_legs:
+                out["eval_forward"] = run_model_leg(args, dev, 8, args.points, args.k, "BASELINE.json configs[2]", 20, False, 1, cpu)
+                out["stress"] = run_model_leg(args, dev, 8, 32768, 64, "BASELINE.json configs[4] (large-tile stress)", 6, True, 1,
+                                              cpu and not args.no_stress_cpu)
+    finally:
+        if _COMM is not None:
+            _COMM.close()      # ncclCommDestroy now, not from __del__ at interpreter shutdown
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist.is_initialized():

@@ -104,7 +104,16 @@ def run_case(B, N, training, p_drop, seed=0, NC=5, cat_scale=1.0, cat_shift=0.0,
     err = (y.detach().cpu().double() - want.detach()).abs().max().item()
     assert err < tol, "logits differ by %g" % err
 
-    def close(got, ref, name, floor=0.0):
+    # not strict: the near-ties (|pre-activation| < NEAR in the float64 evaluation) are counted and priced.  One flipped
+    # derivative changes ONE element of dv by at most 0.8 of itself: a row of dL/dcat sums 512 such elements, a weight-gradient
+    # entry sums P of them, so n flips move a gradient tensor by at most ~ sqrt(n / (P * 256)) in relative L2 (256 = the
+    # narrowest layer); at B = 8, N = 7000 with ~100 near-ties that is 2.6e-3, not the 0.9 a 1 / sqrt(P) PER NEAR-TIE rule gives
+    l2_tol = tol + (near / (P * 256.0)) ** 0.5
+    clean = None
+    if not strict:
+        clean = ((v7.detach().abs() < NEAR).sum(1) + (v8.detach().abs() < NEAR).sum(1)) == 0   # rows without a near-tie
+
+    def close(got, ref, name, floor=0.0, rows=False):
         ref = ref.detach()
         diff = got.detach().cpu().double() - ref
         if strict:
@@ -112,8 +121,13 @@ def run_case(B, N, training, p_drop, seed=0, NC=5, cat_scale=1.0, cat_shift=0.0,
             assert e < tol, "%s: relative error %g" % (name, e)
         else:
             e = diff.norm().item() / max(ref.norm().item(), floor, 1e-30)
-            assert e < tol + 2.0 * (1 + near) / P ** 0.5, "%s: relative L2 error %g (%d near-ties)" % (name, e, near)
-    close(dcat.grad, rcat.grad, "dcat")
+            assert e < l2_tol, "%s: relative L2 error %g > %g (%d near-ties)" % (name, e, l2_tol, near)
+            if rows:
+                # per-row gradients: the rows WITHOUT a near-tie are held to the strict max-norm bound (in training mode a
+                # flip elsewhere reaches them only through the BatchNorm sums: <= 0.2 / P of an entry per flip)
+                e = diff[clean].abs().max().item() / max(ref.abs().max().item(), 1e-30)
+                assert e < tol + 0.2 * near / P, "%s, %d near-tie-free rows: relative error %g" % (name, int(clean.sum()), e)
+    close(dcat.grad, rcat.grad, "dcat", rows=True)
     # (B = 1 in training mode: the true gradient of the added row is zero -- the BatchNorm input gradients of a column sum
     # to zero -- so the error is measured against the magnitude of what is summed)
     close(dadd.grad, radd.grad, "dadd7", floor=1e-3 * u7.grad.abs().sum(0).max().item())
@@ -203,6 +217,13 @@ def test_head_tail_is_bit_stable():
 
 def test_head_tail_at_the_benchmark_size():
     run_case(8, 7000, True, 0.5, seed=13, strict=False)
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_head_tail_many_batch_elements_and_row_blocks(training):
+    # B = 32 batch-element slots and P = 67200 > 65536 rows (525 row blocks: more than the classifier's 512-block cap, the
+    # grid-stride tiles of its backward, two-level finalizers): the shape class of the B = 32, N = 7000 training step
+    run_case(32, 2100, training, 0.5, seed=17, strict=False)
 
 
 def test_head_tail_randomised_configurations():

@@ -202,3 +202,38 @@ def test_edgeconv_gradients_land_in_the_flat_buffer(device):
     run()
     for p, w in zip(params, want):
         assert torch.allclose(p.grad, 2.0 * w, rtol=1e-6, atol=0.0)
+
+
+def test_shared_weight_claims_its_sink_once(device):
+    """One convolution / BatchNorm used by TWO EdgeConv nodes of the same backward: when the second node runs the
+    parameter has no .grad yet (AccumulateGrad has not fired), so a sink decided by `.grad is None` alone would be handed
+    out twice and autograd would add a tensor to itself.  The sink is claimed once per zero() / pack() cycle; the sum of
+    the two contributions must come out."""
+    from ahn3_dgcnn_pytorch_amd import ops
+    from ahn3_dgcnn_pytorch_amd.parallel import FlatGradAllReduce
+    torch.manual_seed(6)
+    B, N, C, k = 2, 300, 64, 12
+    conv = torch.nn.Conv2d(2 * C, 64, 1, bias=False).to(device)
+    bn = torch.nn.BatchNorm2d(64).to(device)
+    params = [conv.weight, bn.weight, bn.bias]
+    x = torch.randn(B, N, C, device=device)
+    idx = ops.knn_pm(x, k)
+    cot = torch.randn(B, N, 64, device=device)
+
+    def run():
+        y1 = ops.edgeconv_pm(x, idx, conv.weight, bn, None, None, training=True, slope=0.2)
+        y2 = ops.edgeconv_pm(y1, idx, conv.weight, bn, None, None, training=True, slope=0.2)   # the same weights again
+        y2.backward(cot)
+
+    run()
+    want = [p.grad.clone() for p in params]
+    for p in params:
+        p.grad = None
+    sync = FlatGradAllReduce(params)
+    for _ in range(2):                                # two cycles: the claim is released by zero() / pack()
+        sync.zero()
+        run()
+        flat = sync.sync()
+        for p, w in zip(params, want):
+            assert torch.allclose(p.grad, w, rtol=1e-5, atol=1e-6 * float(w.abs().max()))
+        assert torch.allclose(flat, torch.cat([w.reshape(-1) for w in want]), rtol=1e-5, atol=1e-6 * float(flat.abs().max()))
