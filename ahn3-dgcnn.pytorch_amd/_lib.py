@@ -57,6 +57,23 @@ class HeadTailGrads(ctypes.Structure):
 
 _c_ht_p = ctypes.POINTER(HeadTailDesc)
 
+
+class ModelDesc(ctypes.Structure):
+    """mirror of `dgcnn_model_desc` (include/dgcnn_hip.h)"""
+    _fields_ = [("B", ctypes.c_int32), ("N", ctypes.c_int32), ("F", ctypes.c_int32), ("k", ctypes.c_int32),
+                ("num_classes", ctypes.c_int32), ("emb", ctypes.c_int32), ("c7", ctypes.c_int32), ("c8", ctypes.c_int32),
+                ("training", ctypes.c_int32), ("idx_given", ctypes.c_int32),
+                ("slope", _c_f), ("p_drop", _c_f), ("seed", ctypes.c_uint64),
+                ("w", _c_vp * 9), ("bn", BnParams * 8), ("eps", _c_f * 8), ("momentum", _c_f * 8), ("idx", _c_vp * 3)]
+
+
+class ModelGrads(ctypes.Structure):
+    """mirror of `dgcnn_model_grads` (include/dgcnn_hip.h)"""
+    _fields_ = [("gw", _c_vp * 9), ("gbn_w", _c_vp * 8), ("gbn_b", _c_vp * 8)]
+
+
+_c_md_p = ctypes.POINTER(ModelDesc)
+
 # name -> (restype, argtypes); must list every symbol of include/dgcnn_hip.h
 SIGNATURES = {
     "dgcnn_last_error": (ctypes.c_char_p, []),
@@ -114,6 +131,12 @@ SIGNATURES = {
     "dgcnn_head_tail_fwd": (_c_int, [_c_ht_p, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp]),
     "dgcnn_head_tail_bwd": (_c_int, [_c_ht_p, _c_vp, _c_vp, _c_vp, _c_vp, ctypes.POINTER(HeadTailGrads), _c_vp, _c_sz, _c_vp]),
     "dgcnn_dropout_mask": (_c_int, [ctypes.c_uint64, _c_int, _c_int, _c_f, _c_vp, _c_vp]),
+    "dgcnn_model_saved_bytes": (_c_sz, [_c_md_p]),
+    "dgcnn_model_fwd_workspace_bytes": (_c_sz, [_c_md_p]),
+    "dgcnn_model_bwd_workspace_bytes": (_c_sz, [_c_md_p]),
+    "dgcnn_model_fwd": (_c_int, [_c_md_p, _c_vp, _c_i64, _c_i64, _c_i64, _c_vp, _c_i64, _c_i64, _c_i64, _c_vp, _c_vp, _c_sz, _c_vp]),
+    "dgcnn_model_bwd": (_c_int, [_c_md_p, _c_vp, _c_i64, _c_i64, _c_i64, _c_vp, _c_i64, _c_i64, _c_i64, _c_vp,
+                                 ctypes.POINTER(ModelGrads), _c_vp, _c_sz, _c_vp]),
     "dgcnn_comm_rccl_version": (_c_int, []),
     "dgcnn_comm_unique_id": (_c_int, [_c_vp]),
     "dgcnn_comm_init": (_c_int, [ctypes.POINTER(_c_vp), _c_vp, _c_int, _c_int]),

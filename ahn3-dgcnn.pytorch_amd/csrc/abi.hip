@@ -49,7 +49,7 @@ __global__ void from_point_major_kernel(const float *__restrict__ src, int C, in
 using namespace dgcnn;
 
 extern "C" const char *dgcnn_last_error(void) { return g_err; }
-extern "C" int dgcnn_abi_version(void) { return 5; }  // 5: dgcnn_head_tail_*, dgcnn_dropout_mask (4: dgcnn_bn_params.num_batches_tracked)
+extern "C" int dgcnn_abi_version(void) { return 6; }  // 6: dgcnn_model_* (5: dgcnn_head_tail_*, dgcnn_dropout_mask; 4: dgcnn_bn_params.num_batches_tracked)
 
 extern "C" int dgcnn_to_point_major(const float *src, int B, int C, int N, int64_t sb, int64_t sc, int64_t sn,
                                     float *dst, void *stream)

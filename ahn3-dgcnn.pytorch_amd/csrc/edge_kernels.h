@@ -20,18 +20,69 @@ struct FwdSide {
     dgcnn_bn_params bn[2];
     float *stats[2];
 };
-void launch_rowgemm_fwd(const float *x, int C, const float *w1, float *TP, float *TQ, const FwdSide &sd, int P, hipStream_t st);
+// row strides (in floats) of the operands that may be column slices of a wider row (the model's [P][192] concatenation of
+// the block outputs): A0's rows, Y0's rows, and whether Y0 is added to instead of overwritten (the second gradient that flows
+// into a block's output)
+struct RowLd {
+    int a0, y0, y0_acc;
+};
+// ldx: row stride of x (0 = dense, C)
+void launch_rowgemm_fwd(const float *x, int C, const float *w1, float *TP, float *TQ, const FwdSide &sd, int P, hipStream_t st,
+                        int ldx = 0);
 // Y(p, n) = sum_k A(p, k) W[k][n];  A = [A0 | A1] (K0 + K1 columns), Y = [Y0 | Y1] (NO0 + rest)
+// ldy0: row stride of Y0 (0 = dense, NO0); y0_accumulate: Y0 += instead of =
 void launch_rowgemm(const float *A0, int K0, const float *A1, int K1, const float *W, int NO, float *Y0, int NO0,
-                    float *Y1, int P, hipStream_t st);
+                    float *Y1, int P, hipStream_t st, int ldy0 = 0, int y0_accumulate = 0);
 // partial[chunk][m][n] = sum_{p in chunk} A(p, m) X[p][n];  A = [A0 | A1] (M0 + M1 <= 128 columns)
 int wgrad_chunks(int P, int C);
 void launch_wgrad(const float *A0, int M0, const float *A1, int M1, const float *X, int C, int P, float *partial,
-                  hipStream_t st);
+                  hipStream_t st, int ldx = 0);
 // G [128][C] = sum of the partials, then gw1[o][c]:  c < C: G[o][c] - G[64 + o][c];  c >= C: G[64 + o][c - C]
 void launch_finish_dw1(const float *partial, int nchunk, int C, float *gw1, hipStream_t st);
+// that fold as extra workgroups of the input-gradient product's launch
+struct Dw1Rider {
+    const float *partial;
+    int nchunk, C;
+    float *gw1;
+    int main_blocks;
+};
+void launch_dgrad_and_dw1(const float *dR, const float *dD, const float *wcat, int C, float *gx, int ldgx, int gx_acc, int P,
+                          const float *partial, int nchunk, float *gw1, hipStream_t st);
 // out[e] = sum_chunk partial[chunk][e]   (fixed order: deterministic)
 void launch_sum_partials(const float *partial, int nchunk, int n, float *out, hipStream_t st);
+
+// ---- edgeconv.hip : the block with row strides (0 = dense) -- what dgcnn_edgeconv_fwd / _bwd run with all strides dense.
+// x, y, gy, gx: row strides in floats of the block's input, output, output gradient and input gradient when those are
+// column slices of wider rows; gx_acc: the input gradient is added to its slice instead of overwriting it.  The second
+// convolution's backward takes gy == y == 64 or 192 only.
+struct EdgeLd {
+    int x, y, gy, gx, gx_acc;
+};
+int edgeconv_fwd_ld(const dgcnn_edgeconv_desc *d, const EdgeLd &ld, const float *x, const int32_t *idx, float *y, void *saved,
+                    void *workspace, size_t workspace_bytes, void *stream);
+// counters of a backward call that must be zero when its kernels start (zeroed by the first kernel of the call -- the counting
+// pass of the reverse lists -- or, with RevPrebuilt, by launch_rev_build_merged)
+enum {
+    Z_FOLD_A = 0,
+    Z_FOLD_B = FOLD_CTR_WORDS,
+    Z_FOLD_C = 2 * FOLD_CTR_WORDS,   // the fp32 fallback of edge_mlp_bwd16_kernel
+    Z_ALLOC = 3 * FOLD_CTR_WORDS,    // [0] reverse-list space, [1] extra (point, segment) pairs
+    Z_GMAX = Z_ALLOC + 2,            // bits of max |dL/dy . LReLU'| (bwd_point -> edge_mlp_bwd16)
+    Z_GUARD = Z_ALLOC + 3,           // raised by edge_mlp_bwd16_kernel when an operand leaves the fp16 range
+    Z_WORDS = 3 * FOLD_CTR_WORDS + 16
+};
+// reverse lists built outside the call (the model builds those of its three blocks in one go): the call's Z_WORDS counters
+// (zeroed, the list allocation at Z_ALLOC filled in) and the arrays of THIS graph
+struct RevPrebuilt {
+    int *zero, *indeg, *rowptr, *segbase, *pcnt, *rev, *extra;
+};
+int edgeconv_bwd_ld(const dgcnn_edgeconv_desc *d, const EdgeLd &ld, const float *x, const int32_t *idx, const float *y,
+                    const float *gy, const void *saved, const dgcnn_edgeconv_grads *g, void *workspace, size_t workspace_bytes,
+                    void *stream, const RevPrebuilt *pre = nullptr);
+
+// ---- knn.hip : dgcnn_knn over rows with a stride (ldx = 0: dense) -------------------------------------------------
+int knn_ld(const float *x, int ldx, int B, int N, int C, int k, int32_t *idx, void *workspace, size_t workspace_bytes,
+           void *stream);
 
 // ---- edge_stream.hip : gather / reduce passes over the edges (no MFMA) -------------------------
 int edge_grid(int P);
@@ -42,13 +93,13 @@ int edge_grid(int P);
 void launch_edge_reduce(const float *TP, const float *TQ, const int32_t *idx, int N, int k, int P, const float *gamma,
                         float *usel, float *usum, uint8_t *hitj, const FoldSet &fs, const BnBatchStats *fin, hipStream_t st);
 // y = LeakyReLU(sc * usel + sh)
-void launch_edge_out(const float *usel, const float *stats, float slope, int P, float *y, hipStream_t st);
+void launch_edge_out(const float *usel, const float *stats, float slope, int P, float *y, hipStream_t st, int ldy = 0);
 // last-stage BN backward sums from per-point quantities, finished in the same launch: gbn_w, gbn_b and cc = [c1 | c2]
 // gmax_bits (zero at launch): receives the bits of max |gy . LReLU'| (an atomic max: order-independent)
 struct RevSlotsArgs;
 void launch_bwd_point(const float *gy, const float *usel, const float *stats, float slope, int P, double count,
                       int training, const FoldSet &fs, float *gbn_w, float *gbn_b, float *cc, unsigned *gmax_bits,
-                      const struct RevSlotsArgs *slots, hipStream_t st);
+                      const struct RevSlotsArgs *slots, hipStream_t st, int ldgy = 0);
 // Reverse adjacency of the neighbour graph (depends on idx only), every list sorted by edge id.  Scratch: cnt
 // [B * rev_chunks][N]; results: rowptr [P] (list start), indeg [P], segbase [P], pcnt [P] (zeroed), rev [E], alloc [2]
 // (alloc[1] = number of extra (point, segment) pairs), extra [2 (E / REV_SEG + 1)] ints.  The first kernel also zeroes
@@ -62,6 +113,9 @@ struct RevSlotsArgs {
     int N, chunks, P;
     int *cnt, *rowptr, *indeg, *segbase, *pcnt, *alloc;
     int2 *extra;
+    // a merged build of nblk graphs of Pblk points each (launch_rev_build_merged): alloc / extra of graph g at
+    // alloc + g alloc_stride ints, extra + g extra_stride pairs; one graph: nblk = 1, Pblk = P
+    int nblk, Pblk, alloc_stride, extra_stride;
 };
 RevSlotsArgs rev_slots_args(int B, int N, int k, int *cnt, int *indeg, int *rowptr, int *segbase, int *pcnt, int *alloc,
                             int *extra);
@@ -74,7 +128,11 @@ struct RevPlaceArgs {
     int N, k, chunks, rows_per, nblocks;  // nblocks = B * chunks
     const int *cnt;
     int32_t *rev;
+    int Bblk, Eblk;  // merged build: batch elements per graph and list entries per graph (one graph: Bblk = B, Eblk = 0)
 };
+int launch_rev_build_merged(const int32_t *idx, int nblk, int B, int N, int k, int *cnt, int *indeg, int *rowptr, int *segbase,
+                            int *pcnt, int32_t *rev, int *extra, int extra_stride, int *zero_words, int zero_stride, int alloc_off,
+                            hipStream_t st);
 
 // stage-1 backward as a gather over the reverse lists (see edge_stream.hip): dR and dD are overwritten.
 // dv == NULL: sparse dv from (gy, y, hitj) -- hits [E] x 32 bytes and G [P][64] are scratch; else dense dv [E][64] with
@@ -84,7 +142,7 @@ int launch_edge_bwd(const float *TP, const float *TQ, int B, int N, int k, const
                     const float *gy, const float *y, const uint8_t *hitj, const float *usum, const float *dv,
                     const float *dvsum, const int *rowptr, const int *indeg, const int *segbase, int *pcnt,
                     const int32_t *rev, const int *alloc, const int *extra, void *hits, float *G, float *part0,
-                    float *partx, float *dR, float *dD, hipStream_t st);
+                    float *partx, float *dR, float *dD, hipStream_t st, int ldgy = 0, int ldy = 0);
 void launch_graph_feature_fwd(const float *x, const int32_t *idx, int B, int N, int C, int k, float *out,
                               hipStream_t st);
 void launch_graph_feature_bwd(const float *gout, const int *rowptr, const int *indeg, const int32_t *rev, int B, int N,
@@ -104,10 +162,10 @@ void launch_edge_mlp_fwd(const float *TP, const float *TQ, const int32_t *idx, i
 // backward sums (sum dv1, sum dv1 * uhat1) are finished in the same launch (fold.h) -> fin1
 // gmax_bits: bits of max |dL/dy . LReLU'| (launch_bwd_point); guard: one int, zero at launch -- raised when an operand
 // leaves the fp16 range, in which case the fp32 form of the pass (fold counters fs_fallback) redoes it in the same call
-void launch_edge_mlp_bwd(const float *TP, const float *TQ, const int32_t *idx, int N, int k, int P,
+int launch_edge_mlp_bwd(const float *TP, const float *TQ, const int32_t *idx, int N, int k, int P,
                          const float *stats1, const float *stats2, const float *cc2, const float *w2, float slope,
                          int training, const float *gy, const float *y, const uint8_t *hit2, const unsigned *gmax_bits,
                          float *dv1, float *dvsum, float *partial_dw2, const FoldSet &fs, const FoldSet &fs_fallback,
-                         const BnBackwardSums &fin1, int *guard, hipStream_t st);
+                         const BnBackwardSums &fin1, int *guard, hipStream_t st, int ldgy = 0, int ldy = 0);
 
 }  // namespace dgcnn

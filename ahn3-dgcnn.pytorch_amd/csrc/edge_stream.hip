@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
 }
 
 __global__ void edge_out_kernel(const float *__restrict__ usel, const float *__restrict__ stats, float slope,
-                                size_t n4, float *__restrict__ y)
+                                size_t n4, float *__restrict__ y, int ldy)
 {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n4) return;
@@ -156,7 +156,7 @@ __global__ void edge_out_kernel(const float *__restrict__ usel, const float *__r
     o.y = lrelu(__builtin_fmaf(u.y, sc.y, sh.y), slope);
     o.z = lrelu(__builtin_fmaf(u.z, sc.z, sh.z), slope);
     o.w = lrelu(__builtin_fmaf(u.w, sc.w, sh.w), slope);
-    reinterpret_cast<float4 *>(y)[t] = o;
+    *reinterpret_cast<float4 *>(y + (t >> 4) * (size_t)ldy + c) = o;  // (ldy: y may be a 64-column slice of a wider row)
 }
 
 // alloc[0]: list space handed out so far, alloc[1]: number of extra (point, segment) pairs (both zeroed by
@@ -166,14 +166,19 @@ __global__ void edge_out_kernel(const float *__restrict__ usel, const float *__r
 // chip idle on their own -- as the workgroups behind that kernel's own; `block` = index among the pass's workgroups.)
 __device__ __forceinline__ void rev_slots_pass(const RevSlotsArgs &a, int block)
 {
-    const int N = a.N, chunks = a.chunks, P = a.P;
+    // a merged build (nblk graphs of Pblk points each, side by side: the three blocks of the model in one launch): a workgroup
+    // stays inside ONE graph, which has its own list space (alloc, rev) and its own extra-pair list; the per-point arrays and
+    // the count table are indexed by the merged point number
+    const int N = a.N, chunks = a.chunks;
+    const int wgs = (a.Pblk + 255) / 256, blk = block / wgs, gl = (block - blk * wgs) * 256 + (int)threadIdx.x;
+    const bool live = gl < a.Pblk;
     int *__restrict__ cnt = a.cnt, *__restrict__ rowptr = a.rowptr, *__restrict__ indeg = a.indeg;
-    int *__restrict__ segbase = a.segbase, *__restrict__ pcnt = a.pcnt, *__restrict__ alloc = a.alloc;
-    int2 *__restrict__ extra = a.extra;
-    const int g = block * 256 + threadIdx.x;
+    int *__restrict__ segbase = a.segbase, *__restrict__ pcnt = a.pcnt, *__restrict__ alloc = a.alloc + (size_t)blk * a.alloc_stride;
+    int2 *__restrict__ extra = a.extra + (size_t)blk * a.extra_stride;
+    const int g = blk * a.Pblk + gl;
     int deg = 0;
     int *cb = nullptr;
-    if (g < P) {
+    if (live) {
         const int b = g / N, m = g - b * N;
         cb = cnt + (size_t)b * chunks * N + m;
         int c = 0;
@@ -220,7 +225,7 @@ __device__ __forceinline__ void rev_slots_pass(const RevSlotsArgs &a, int block)
         }
     }
     __syncthreads();
-    if (g < P) {
+    if (live) {
         int slot = wbase[wave][0] + inc_d - deg;
         const int sb = wbase[wave][1] + inc_s - nseg;
         rowptr[g] = slot;
@@ -243,7 +248,7 @@ __device__ __forceinline__ void rev_slots_pass(const RevSlotsArgs &a, int block)
             cb[(size_t)c * N] = slot;
             slot += n;
         }
-        for (int sg = 0; sg < nseg; ++sg) extra[sb + sg] = int2{g, sg + 1};
+        for (int sg = 0; sg < nseg; ++sg) extra[sb + sg] = int2{gl, sg + 1};  // (the point's number inside its graph)
     }
 }
 
@@ -253,7 +258,7 @@ __device__ __forceinline__ void rev_slots_pass(const RevSlotsArgs &a, int block)
 // carries gradient through max-over-k, so  sum dv  and  sum dv * uhat  over all edges reduce to
 // sums over points of quantities at the selected extreme.  The pass finishes
 // the sums itself (fold.h): gbn_b, gbn_w and the two mean terms cc.
-__global__ __launch_bounds__(256) void bwd_point_kernel(const float *__restrict__ gy, const float *__restrict__ usel,
+__global__ __launch_bounds__(256) void bwd_point_kernel(const float *__restrict__ gy, int ldgy, const float *__restrict__ usel,
                                                         const float *__restrict__ stats, float slope, int P,
                                                         FoldSet fs, BnBackwardSums fin, unsigned *__restrict__ gmax_bits,
                                                         int nbp, RevSlotsArgs slots)
@@ -279,7 +284,7 @@ __global__ __launch_bounds__(256) void bwd_point_kernel(const float *__restrict_
         for (int u = 0; u < INF; ++u) {
             const int p = pt + u * stride < P ? pt + u * stride : pt;  // clamped: the load is unconditional, the value masked
             us[u] = usel[(size_t)p * EC + lane];
-            g4[u] = gy[(size_t)p * EC + lane];
+            g4[u] = gy[(size_t)p * ldgy + lane];
         }
 #pragma unroll
         for (int u = 0; u < INF; ++u) {
@@ -413,7 +418,6 @@ __device__ __forceinline__ void rev_place_pass(const RevPlaceArgs &a, int block,
     const int32_t *__restrict__ idx = a.idx;
     const int N = a.N, k = a.k, chunks = a.chunks, rows_per = a.rows_per;
     const int *__restrict__ cnt = a.cnt;
-    int32_t *__restrict__ rev = a.rev;
     const int lane = threadIdx.x & 63;
     // workgroups are dealt round-robin over the 8 XCDs: batch element = block % B keeps all writers of a batch
     // element's lists (scattered 4-byte stores into one region of `rev`) behind ONE L2, where they merge into whole lines
@@ -423,6 +427,10 @@ __device__ __forceinline__ void rev_place_pass(const RevPlaceArgs &a, int block,
     const int r0 = chunk * rows_per, r1 = r0 + rows_per < N ? r0 + rows_per : N;
     if (r0 >= r1) return;
     const int32_t *ib = idx + (size_t)b * N * k;
+    // (a merged build: batch element b belongs to graph b / Bblk, whose lists live in their own E-entry range of rev and hold
+    // edge ids local to the graph)
+    const int blk = b / a.Bblk, bl = b - blk * a.Bblk;
+    int32_t *__restrict__ rev = a.rev + (size_t)blk * a.Eblk;
     RevRows<K2> ra, rb;
     rev_load_rows<K2>(ib, k, r0, r1, lane, ra);
     for (int m0 = 0; m0 < N; m0 += 64 * 16) {  // 16 loads in flight, then 16 LDS writes
@@ -436,7 +444,7 @@ __device__ __forceinline__ void rev_place_pass(const RevPlaceArgs &a, int block,
     auto place = [&](const RevRows<K2> &v, int r) {
 #pragma unroll
         for (int u = 0; u < REV_ROWS; ++u) {
-            const int e = (b * N + r + u) * k + lane;  // edge id = (global source point) * k + slot
+            const int e = (bl * N + r + u) * k + lane;  // edge id = (source point within its graph) * k + slot
             if (v.n0[u] >= 0) rev[atomicAdd(&table[v.n0[u]], 1)] = e;
             if (K2 && v.n1[u] >= 0) rev[atomicAdd(&table[v.n1[u]], 1)] = e + 64;
         }
@@ -475,7 +483,8 @@ int rev_chunks(int B, int N, int k)
 RevSlotsArgs rev_slots_args(int B, int N, int k, int *cnt, int *indeg, int *rowptr, int *segbase, int *pcnt, int *alloc,
                             int *extra)
 {
-    return RevSlotsArgs{N, rev_chunks(B, N, k), B * N, cnt, rowptr, indeg, segbase, pcnt, alloc, reinterpret_cast<int2 *>(extra)};
+    return RevSlotsArgs{N, rev_chunks(B, N, k), B * N, cnt, rowptr, indeg, segbase, pcnt, alloc, reinterpret_cast<int2 *>(extra), 1, B * N,
+                        0, 0};
 }
 __global__ __launch_bounds__(256) void rev_slots_kernel(RevSlotsArgs a) { rev_slots_pass(a, (int)blockIdx.x); }
 
@@ -514,11 +523,45 @@ int launch_rev_build(const int32_t *idx, int B, int N, int k, int *cnt, int *ind
     return launch_rev_place(idx, B, N, k, cnt, rev, st);
 }
 
+// The reverse adjacencies of nblk graphs over the same B x N points (idx [nblk][B][N][k], contiguous) in three launches: the
+// graphs ride side by side as nblk B batch elements.  Graph g gets its own list space rev + g E, its own allocation counters at
+// zero_words + g zero_stride + alloc_off (the first kernel zeroes all nblk zero_stride words) and its own extra-pair list at
+// extra + g extra_stride ints; the per-point arrays are [nblk][P].
+int launch_rev_build_merged(const int32_t *idx, int nblk, int B, int N, int k, int *cnt, int *indeg, int *rowptr, int *segbase,
+                            int *pcnt, int32_t *rev, int *extra, int extra_stride, int *zero_words, int zero_stride, int alloc_off,
+                            hipStream_t st)
+{
+    DG_REQUIRE(N <= REV_MAX_N, "dgcnn: N=%d > %d unsupported in the backward", N, REV_MAX_N);
+    DG_REQUIRE(k <= 64, "dgcnn: merged reverse lists take k <= 64");
+    const int Bm = nblk * B, chunks = rev_chunks(Bm, N, k), rows_per = ceil_div(N, chunks);
+    const size_t lds = (size_t)N * sizeof(int);
+    if (lds > 64 * 1024) {
+        static bool attr_done[64] = {};
+        int dev = 0;
+        DG_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64, "dgcnn: no current HIP device");
+        if (!attr_done[dev]) {
+            const void *fns[2] = {(const void *)rev_count_kernel<false>, (const void *)rev_place_kernel<false>};
+            for (const void *fn : fns)
+                DG_REQUIRE(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, REV_MAX_N * 4) == hipSuccess,
+                           "dgcnn: cannot reserve %d bytes of dynamic LDS for the reverse-list kernels", REV_MAX_N * 4);
+            attr_done[dev] = true;
+        }
+    }
+    hipLaunchKernelGGL((rev_count_kernel<false>), dim3(Bm * chunks), dim3(64), lds, st, idx, N, k, chunks, rows_per, cnt, zero_words,
+                       nblk * zero_stride);
+    const RevSlotsArgs sa{N, chunks, Bm * N, cnt, rowptr, indeg, segbase, pcnt, zero_words + alloc_off, reinterpret_cast<int2 *>(extra),
+                          nblk, B * N, zero_stride, extra_stride / 2};
+    hipLaunchKernelGGL(rev_slots_kernel, dim3(nblk * ceil_div(B * N, 256)), dim3(256), 0, st, sa);
+    const RevPlaceArgs pa{idx, N, k, chunks, rows_per, Bm * chunks, cnt, rev, B, B * N * k};
+    hipLaunchKernelGGL((rev_place_kernel<false>), dim3(Bm * chunks), dim3(64), lds, st, pa);
+    return 0;
+}
+
 int launch_rev_place(const int32_t *idx, int B, int N, int k, const int *cnt, int32_t *rev, hipStream_t st)
 {
     const int chunks = rev_chunks(B, N, k), rows_per = ceil_div(N, chunks);
     const size_t lds = (size_t)N * sizeof(int);
-    const RevPlaceArgs a{idx, N, k, chunks, rows_per, B * chunks, cnt, rev};
+    const RevPlaceArgs a{idx, N, k, chunks, rows_per, B * chunks, cnt, rev, B, 0};
     if (k > 64) hipLaunchKernelGGL((rev_place_kernel<true>), dim3(B * chunks), dim3(64), lds, st, a);
     else hipLaunchKernelGGL((rev_place_kernel<false>), dim3(B * chunks), dim3(64), lds, st, a);
     return 0;
@@ -544,7 +587,8 @@ template <bool DENSE>
 __global__ __launch_bounds__(256) void edge_point_bwd_kernel(const float *__restrict__ TQ, int k, int P,
                                                              const float *__restrict__ stats,
                                                              const float *__restrict__ cc, float slope,
-                                                             const float *__restrict__ gy, const float *__restrict__ y,
+                                                             const float *__restrict__ gy, int ldgy,
+                                                             const float *__restrict__ y, int ldy,
                                                              const uint8_t *__restrict__ hitj,
                                                              const float *__restrict__ usum,
                                                              const float *__restrict__ dv, HitRec *__restrict__ hits,
@@ -566,8 +610,8 @@ __global__ __launch_bounds__(256) void edge_point_bwd_kernel(const float *__rest
         if (DENSE) {
             dsum = sc * dv[o];
         } else {
-            const float yv = y[o];
-            dsum = sc * gy[o] * (yv > 0.0f ? 1.0f : slope);
+            const float yv = y[(size_t)pt * ldy + lane];
+            dsum = sc * gy[(size_t)pt * ldgy + lane] * (yv > 0.0f ? 1.0f : slope);
             G[o] = dsum;
             const int hj = hitj[o];
             sm[lane] = 0;
@@ -859,19 +903,21 @@ int launch_edge_bwd(const float *TP, const float *TQ, int B, int N, int k, const
                     const float *gy, const float *y, const uint8_t *hitj, const float *usum, const float *dv,
                     const float *dvsum, const int *rowptr, const int *indeg, const int *segbase, int *pcnt,
                     const int32_t *rev, const int *alloc, const int *extra, void *hits, float *G, float *part0,
-                    float *partx, float *dR, float *dD, hipStream_t st)
+                    float *partx, float *dR, float *dD, hipStream_t st, int ldgy, int ldy)
 {
     const int P = B * N;
+    if (ldgy <= 0) ldgy = EC;
+    if (ldy <= 0) ldy = EC;
     DG_REQUIRE((size_t)P * EC * 4 < ((size_t)1 << 32), "edge backward: B * N = %d points exceed the 4 GB row-offset range of the TQ gather", P);
     const dim3 grid(stream_grid(P)), block(256);
     // (measured: the placement pass of the reverse adjacency as extra workgroups of this launch -- as the list-space
     // pass rides with bwd_point -- gains nothing: 47.9 us against 28.0 + 17.3; its N-int LDS table is then reserved by
     // every workgroup of the launch and thins out the point pass)
     if (dv)
-        hipLaunchKernelGGL((edge_point_bwd_kernel<true>), grid, block, 0, st, TQ, k, P, stats, cc, slope, gy, y, hitj, usum,
+        hipLaunchKernelGGL((edge_point_bwd_kernel<true>), grid, block, 0, st, TQ, k, P, stats, cc, slope, gy, ldgy, y, ldy, hitj, usum,
                            dvsum, (HitRec *)hits, G, dD);
     else
-        hipLaunchKernelGGL((edge_point_bwd_kernel<false>), grid, block, 0, st, TQ, k, P, stats, cc, slope, gy, y, hitj, usum,
+        hipLaunchKernelGGL((edge_point_bwd_kernel<false>), grid, block, 0, st, TQ, k, P, stats, cc, slope, gy, ldgy, y, ldy, hitj, usum,
                            nullptr, (HitRec *)hits, G, dD);
     prof_begin(PROF_EDGE_RGATHER, st);
     // one launch: the point workgroups and, behind them, workgroups for the extra segments of the long lists
@@ -948,24 +994,25 @@ void launch_edge_reduce(const float *TP, const float *TQ, const int32_t *idx, in
     prof_end(PROF_EDGE_REDUCE, st);
 }
 
-void launch_edge_out(const float *usel, const float *stats, float slope, int P, float *y, hipStream_t st)
+void launch_edge_out(const float *usel, const float *stats, float slope, int P, float *y, hipStream_t st, int ldy)
 {
     const size_t n4 = (size_t)P * EC / 4;
-    hipLaunchKernelGGL(edge_out_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, usel, stats, slope, n4, y);
+    hipLaunchKernelGGL(edge_out_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, usel, stats, slope, n4, y,
+                       ldy > 0 ? ldy : EC);
 }
 
 void launch_bwd_point(const float *gy, const float *usel, const float *stats, float slope, int P, double count,
                       int training, const FoldSet &fs, float *gbn_w, float *gbn_b, float *cc, unsigned *gmax_bits,
-                      const RevSlotsArgs *slots, hipStream_t st)
+                      const RevSlotsArgs *slots, hipStream_t st, int ldgy)
 {
     int grid = ceil_div(P, EDGE_WAVES * 8);
     if (grid > 512) grid = 512;
     const BnBackwardSums fin{count, training, gbn_w, gbn_b, cc};
     // (slots: the list-space pass of the reverse adjacency rides behind this pass's workgroups, see rev_slots_pass)
-    const RevSlotsArgs none{0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    const int extra_wgs = slots ? ceil_div(slots->P, 256) : 0;
-    hipLaunchKernelGGL(bwd_point_kernel, dim3(grid + extra_wgs), dim3(256), 0, st, gy, usel, stats, slope, P, fs, fin, gmax_bits,
-                       grid, slots ? *slots : none);
+    const RevSlotsArgs none{0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0, 0, 0};
+    const int extra_wgs = slots ? slots->nblk * ceil_div(slots->Pblk, 256) : 0;
+    hipLaunchKernelGGL(bwd_point_kernel, dim3(grid + extra_wgs), dim3(256), 0, st, gy, ldgy > 0 ? ldgy : EC, usel, stats, slope, P,
+                       fs, fin, gmax_bits, grid, slots ? *slots : none);
 }
 
 void launch_graph_feature_fwd(const float *x, const int32_t *idx, int B, int N, int C, int k, float *out,

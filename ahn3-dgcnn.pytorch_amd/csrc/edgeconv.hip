@@ -62,17 +62,6 @@ static SavedLayout saved_layout(const dgcnn_edgeconv_desc *d, void *p)
     return s;
 }
 
-// counters that must be zero when the kernels using them start (zeroed by the first kernel of each call)
-enum {
-    Z_FOLD_A = 0,
-    Z_FOLD_B = FOLD_CTR_WORDS,
-    Z_FOLD_C = 2 * FOLD_CTR_WORDS,   // the fp32 fallback of edge_mlp_bwd16_kernel
-    Z_ALLOC = 3 * FOLD_CTR_WORDS,    // [0] reverse-list space, [1] extra (point, segment) pairs
-    Z_GMAX = Z_ALLOC + 2,            // bits of max |dL/dy . LReLU'| (bwd_point -> edge_mlp_bwd16)
-    Z_GUARD = Z_ALLOC + 3,           // raised by edge_mlp_bwd16_kernel when an operand leaves the fp16 range
-    Z_WORDS = 3 * FOLD_CTR_WORDS + 16
-};
-
 struct FoldBufs {
     double *rec, *folded;
 };
@@ -202,7 +191,16 @@ extern "C" size_t dgcnn_edgeconv_bwd_workspace_bytes(const dgcnn_edgeconv_desc *
 extern "C" int dgcnn_edgeconv_fwd(const dgcnn_edgeconv_desc *d, const float *x, const int32_t *idx, float *y,
                                   void *saved, void *workspace, size_t workspace_bytes, void *stream)
 {
+    return edgeconv_fwd_ld(d, EdgeLd{0, 0, 0, 0, 0}, x, idx, y, saved, workspace, workspace_bytes, stream);
+}
+
+// the forward with row strides: x and y may be 64-column slices of wider rows (model.hip: the [P][192] concatenation of the
+// block outputs, which the blocks then write and read in place -- the torch.cat of model.py:167 disappears)
+int dgcnn::edgeconv_fwd_ld(const dgcnn_edgeconv_desc *d, const EdgeLd &ld, const float *x, const int32_t *idx, float *y,
+                           void *saved, void *workspace, size_t workspace_bytes, void *stream)
+{
     if (check_desc(d, "dgcnn_edgeconv_fwd")) return 1;
+    DG_REQUIRE((ld.x == 0 || ld.x >= d->C) && (ld.y == 0 || ld.y >= EC) && (ld.y & 3) == 0, "dgcnn_edgeconv_fwd: bad row strides");
     DG_REQUIRE(x && idx && y && saved && workspace, "dgcnn_edgeconv_fwd: null pointer");
     const FwdWs w = fwd_ws(d, workspace);
     DG_REQUIRE(workspace_bytes >= w.bytes, "dgcnn_edgeconv_fwd: workspace too small (%zu < %zu)", workspace_bytes,
@@ -219,19 +217,19 @@ extern "C" int dgcnn_edgeconv_fwd(const dgcnn_edgeconv_desc *d, const float *x, 
         sd.bn[0] = d->bn1, sd.stats[0] = s.stats1;
         sd.bn[1] = d->bn2, sd.stats[1] = s.stats2;
     }
-    launch_rowgemm_fwd(x, C, d->w1, s.TP, s.TQ, sd, P, st);
+    launch_rowgemm_fwd(x, C, d->w1, s.TP, s.TQ, sd, P, st, ld.x);
     const FoldSet fs1{w.f1.rec, w.f1.folded, w.zero + Z_FOLD_A}, fs2{w.f2.rec, w.f2.folded, w.zero + Z_FOLD_B};
     const BnBatchStats fin1{d->bn1, E, d->eps, d->momentum, s.stats1}, fin2{d->bn2, E, d->eps, d->momentum, s.stats2};
     if (d->n_stage == 1) {
         launch_edge_reduce(s.TP, s.TQ, idx, N, k, P, d->bn1.weight, s.usel, s.usum, s.hitj, fs1, d->training ? &fin1 : nullptr,
                            st);
-        launch_edge_out(s.usel, s.stats1, d->slope, P, y, st);
+        launch_edge_out(s.usel, s.stats1, d->slope, P, y, st, ld.y);
     } else {
         if (d->training) launch_edge_reduce(s.TP, s.TQ, idx, N, k, P, d->bn1.weight, nullptr, s.usum, nullptr, fs1, &fin1, st);
         const FoldSet fs3{w.f2.rec, w.f2.folded, w.zero + Z_FOLD_C};
         launch_edge_mlp_fwd(s.TP, s.TQ, idx, N, k, P, s.stats1, d->w2, d->bn2.weight, d->slope, s.usel, s.hitj, fs2, fs3,
                             d->training ? &fin2 : nullptr, w.zero + Z_GUARD, st);
-        launch_edge_out(s.usel, s.stats2, d->slope, P, y, st);
+        launch_edge_out(s.usel, s.stats2, d->slope, P, y, st, ld.y);
     }
     DG_CHECK_LAUNCH("dgcnn_edgeconv_fwd");
     return 0;
@@ -241,52 +239,70 @@ extern "C" int dgcnn_edgeconv_bwd(const dgcnn_edgeconv_desc *d, const float *x, 
                                   const float *gy, const void *saved, const dgcnn_edgeconv_grads *g, void *workspace,
                                   size_t workspace_bytes, void *stream)
 {
+    return edgeconv_bwd_ld(d, EdgeLd{0, 0, 0, 0, 0}, x, idx, y, gy, saved, g, workspace, workspace_bytes, stream, nullptr);
+}
+
+// the backward with row strides (x, y, gy, gx as 64-column slices of wider rows) and, with ld.gx_acc, gx ADDED to what the
+// slice holds: the second gradient that reaches a block's output (model.py:167 / :180 feed x1, x2 to the head as well)
+int dgcnn::edgeconv_bwd_ld(const dgcnn_edgeconv_desc *d, const EdgeLd &ld, const float *x, const int32_t *idx, const float *y,
+                           const float *gy, const void *saved, const dgcnn_edgeconv_grads *g, void *workspace,
+                           size_t workspace_bytes, void *stream, const RevPrebuilt *pre)
+{
     if (check_desc(d, "dgcnn_edgeconv_bwd", true)) return 1;
+    DG_REQUIRE((ld.x == 0 || ld.x >= d->C) && (ld.y == 0 || ld.y >= EC) && (ld.gy == 0 || ld.gy >= EC) && (ld.gx == 0 || ld.gx >= d->C),
+               "dgcnn_edgeconv_bwd: bad row strides");
     DG_REQUIRE(x && idx && y && gy && saved && g && workspace, "dgcnn_edgeconv_bwd: null pointer");
     DG_REQUIRE(g->gw1 && g->gbn1_w && g->gbn1_b, "dgcnn_edgeconv_bwd: stage-1 gradient outputs missing");
     if (d->n_stage == 2) DG_REQUIRE(g->gw2 && g->gbn2_w && g->gbn2_b, "dgcnn_edgeconv_bwd: stage-2 gradient outputs missing");
-    const BwdWs w = bwd_ws(d, workspace);
+    BwdWs w = bwd_ws(d, workspace);
     DG_REQUIRE(workspace_bytes >= w.bytes, "dgcnn_edgeconv_bwd: workspace too small (%zu < %zu)", workspace_bytes,
                w.bytes);
     const SavedLayout s = saved_layout(d, const_cast<void *>(saved));
     hipStream_t st = (hipStream_t)stream;
     const int P = d->B * d->N, N = d->N, C = d->C, k = d->k;
     const double E = (double)P * k;
+    if (pre) {  // the lists exist (launch_rev_build_merged, which has also zeroed the call's counters)
+        w.zero = pre->zero, w.indeg = pre->indeg, w.rowptr = pre->rowptr, w.segbase = pre->segbase, w.pcnt = pre->pcnt;
+        w.rev = pre->rev, w.extra = pre->extra;
+    }
 
     // (measured: building the lists on a side stream, concurrently with the BatchNorm-backward sums and the
     // per-point pass, costs more in cross-stream barriers than it hides: 0.776 ms against 0.725 ms per step)
     // The reverse adjacency: its counting pass first (it also zeroes the call's counters), its list-space pass inside the
     // launch of bwd_point (two short passes that leave most of the chip idle on their own), then the placement.
-    if (launch_rev_build(idx, d->B, N, k, w.cnt, w.indeg, w.rowptr, w.segbase, w.pcnt, w.rev, w.zero + Z_ALLOC, w.extra,
-                         w.zero, Z_WORDS, false, false, st))
+    if (!pre && launch_rev_build(idx, d->B, N, k, w.cnt, w.indeg, w.rowptr, w.segbase, w.pcnt, w.rev, w.zero + Z_ALLOC, w.extra,
+                                 w.zero, Z_WORDS, false, false, st))
         return 1;
-    const RevSlotsArgs slots = rev_slots_args(d->B, N, k, w.cnt, w.indeg, w.rowptr, w.segbase, w.pcnt, w.zero + Z_ALLOC, w.extra);
+    const RevSlotsArgs slots_ = rev_slots_args(d->B, N, k, w.cnt, w.indeg, w.rowptr, w.segbase, w.pcnt, w.zero + Z_ALLOC, w.extra);
+    const RevSlotsArgs *slots = pre ? nullptr : &slots_;
     const FoldSet fsa{w.fa.rec, w.fa.folded, w.zero + Z_FOLD_A}, fsb{w.fb.rec, w.fb.folded, w.zero + Z_FOLD_B};
     if (d->n_stage == 1) {
-        launch_bwd_point(gy, s.usel, s.stats1, d->slope, P, E, d->training, fsa, g->gbn1_w, g->gbn1_b, w.cc1, nullptr, &slots, st);
-        if (launch_rev_place(idx, d->B, N, k, w.cnt, w.rev, st)) return 1;
+        launch_bwd_point(gy, s.usel, s.stats1, d->slope, P, E, d->training, fsa, g->gbn1_w, g->gbn1_b, w.cc1, nullptr, slots, st,
+                         ld.gy);
+        if (!pre && launch_rev_place(idx, d->B, N, k, w.cnt, w.rev, st)) return 1;
         if (launch_edge_bwd(s.TP, s.TQ, d->B, N, k, s.stats1, w.cc1, d->slope, gy, y, s.hitj, s.usum, nullptr, nullptr,
                             w.rowptr, w.indeg, w.segbase, w.pcnt, w.rev, w.zero + Z_ALLOC, w.extra, w.hits, w.G, w.part0,
-                            w.partx, w.dR, w.dD, st))
+                            w.partx, w.dR, w.dD, st, ld.gy, ld.y))
             return 1;
     } else {
         launch_bwd_point(gy, s.usel, s.stats2, d->slope, P, E, d->training, fsa, g->gbn2_w, g->gbn2_b, w.cc2,
-                         reinterpret_cast<unsigned *>(w.zero + Z_GMAX), &slots, st);
-        if (launch_rev_place(idx, d->B, N, k, w.cnt, w.rev, st)) return 1;
+                         reinterpret_cast<unsigned *>(w.zero + Z_GMAX), slots, st, ld.gy);
+        if (!pre && launch_rev_place(idx, d->B, N, k, w.cnt, w.rev, st)) return 1;
         const BnBackwardSums fin1{E, d->training, g->gbn1_w, g->gbn1_b, w.cc1};
         const FoldSet fsc{w.fb.rec, w.fb.folded, w.zero + Z_FOLD_C};
-        launch_edge_mlp_bwd(s.TP, s.TQ, idx, N, k, P, s.stats1, s.stats2, w.cc2, d->w2, d->slope, d->training, gy, y,
-                            s.hitj, reinterpret_cast<const unsigned *>(w.zero + Z_GMAX), w.dv1, w.dvsum, w.dw2_partial, fsb,
-                            fsc, fin1, w.zero + Z_GUARD, st);
+        if (launch_edge_mlp_bwd(s.TP, s.TQ, idx, N, k, P, s.stats1, s.stats2, w.cc2, d->w2, d->slope, d->training, gy, y,
+                                s.hitj, reinterpret_cast<const unsigned *>(w.zero + Z_GMAX), w.dv1, w.dvsum, w.dw2_partial, fsb,
+                                fsc, fin1, w.zero + Z_GUARD, st, ld.gy, ld.y))
+            return 1;
         launch_sum_partials(w.dw2_partial, mlp_grid(P), EC * EC, g->gw2, st);
         if (launch_edge_bwd(s.TP, s.TQ, d->B, N, k, s.stats1, w.cc1, d->slope, gy, y, nullptr, s.usum, w.dv1, w.dvsum,
                             w.rowptr, w.indeg, w.segbase, w.pcnt, w.rev, w.zero + Z_ALLOC, w.extra, nullptr, nullptr,
                             w.part0, w.partx, w.dR, w.dD, st))
             return 1;
     }
-    launch_wgrad(w.dR, EC, w.dD, EC, x, C, P, w.wg_partial, st);
-    launch_finish_dw1(w.wg_partial, wgrad_chunks(P, C), C, g->gw1, st);
-    if (g->gx) launch_rowgemm(w.dR, EC, w.dD, EC, s.wcat, C, g->gx, C, nullptr, P, st);
+    launch_wgrad(w.dR, EC, w.dD, EC, x, C, P, w.wg_partial, st, ld.x);
+    if (g->gx) launch_dgrad_and_dw1(w.dR, w.dD, s.wcat, C, g->gx, ld.gx, ld.gx_acc, P, w.wg_partial, wgrad_chunks(P, C), g->gw1, st);
+    else launch_finish_dw1(w.wg_partial, wgrad_chunks(P, C), C, g->gw1, st);
     DG_CHECK_LAUNCH("dgcnn_edgeconv_bwd");
     return 0;
 }

@@ -363,11 +363,66 @@ __global__ void colmax_bwd_apply_kernel(const float *__restrict__ x, const int32
 // u = cat . W^T, so the two 1024-wide products of the backward collapse to 192-wide ones (ops.py: _EmbedMax):
 //   dcat = 1 (A W)^T + cat (W^T diag(B) W) + [winners]      dW = A (sum cat)^T + diag(B) W (cat^T cat) + [winners]
 // This kernel turns the winners' pre-activations uwin [B][C] and dL/dg into gbias, gweight, A, B and s = sc dv.
-__global__ void embed_bwd_coef_kernel(const float *__restrict__ uwin, const float *__restrict__ gg,
+// Workgroups behind the channel workgroups (sorted != NULL): workgroup ncb + b sorts the (winning point, channel) keys of batch
+// element b ONCE for embed_bwd_sorted_scatter_kernel (the order depends on arg alone; sorting inside every scatter workgroup
+// -- 32 per batch element -- was 45 us of the backward at any batch size).
+__global__ __launch_bounds__(256) void embed_bwd_coef_kernel(const float *__restrict__ uwin, const float *__restrict__ gg,
                                       const float *__restrict__ stats, int B, int N, int C, int training, float slope,
                                       float *__restrict__ gweight, float *__restrict__ gbias, float *__restrict__ coefA,
-                                      float *__restrict__ coefB, float *__restrict__ s)
+                                      float *__restrict__ coefB, float *__restrict__ s, const int32_t *__restrict__ arg,
+                                      int C2, unsigned long long *__restrict__ sorted)
 {
+    extern __shared__ unsigned long long skeys[];  // [C2] (sort workgroups only)
+    const int ncb = (C + 255) / 256;
+    if ((int)blockIdx.x >= ncb) {
+        const int b = (int)blockIdx.x - ncb;
+        for (int i = threadIdx.x; i < C2; i += 256)
+            skeys[i] = i < C ? ((unsigned long long)(unsigned)arg[(size_t)b * C + i] << 32) | (unsigned)i : ~0ull;
+        __syncthreads();
+        if (C2 <= 2048) {
+            // rank sort: the keys are distinct (the channel is their low word), so the number of smaller keys IS the position;
+            // every thread ranks its <= 8 keys against all of them with broadcast LDS reads -- no barrier between the steps of
+            // a sorting network (the bitonic sort below takes 55 barrier-separated steps for 1024 keys: 30 us)
+            unsigned long long mine[8];
+            int rank[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = threadIdx.x + 256 * u;
+                mine[u] = i < C2 ? skeys[i] : ~0ull;
+                rank[u] = 0;
+            }
+            for (int j = 0; j < C2; ++j) {
+                const unsigned long long kj = skeys[j];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) rank[u] += kj < mine[u] ? 1 : 0;
+            }
+            // (the padding keys ~0 are equal: they take the positions behind the C real keys in any order)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = threadIdx.x + 256 * u;
+                if (i < C) sorted[(size_t)b * C2 + rank[u]] = mine[u];
+                else if (i < C2) sorted[(size_t)b * C2 + i] = ~0ull;
+            }
+            return;
+        }
+        for (int k = 2; k <= C2; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = threadIdx.x; i < C2; i += 256) {
+                    const int l = i ^ j;
+                    if (l > i) {
+                        const unsigned long long a = skeys[i], c = skeys[l];
+                        const bool up = (i & k) == 0;
+                        if ((a > c) == up) {
+                            skeys[i] = c;
+                            skeys[l] = a;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        for (int i = threadIdx.x; i < C2; i += 256) sorted[(size_t)b * C2 + i] = skeys[i];
+        return;
+    }
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     const float mean = stats[c], rstd = stats[(size_t)C + c], sc = stats[2 * (size_t)C + c], sh = stats[3 * (size_t)C + c];
@@ -387,13 +442,57 @@ __global__ void embed_bwd_coef_kernel(const float *__restrict__ uwin, const floa
     coefA[c] = training ? (float)(-(double)sc * (sb / P) - Bc * (double)mean) : 0.0f;
 }
 
+// The scatter over keys sorted beforehand (embed_bwd_coef_kernel): workgroup (share, b) takes a contiguous share of the sorted
+// list of batch element b, moved to the next point boundary at both ends, one thread per column f; the additions of one
+// (point, column) happen in list order inside ONE thread: race-free, fixed order.
+constexpr int EMB_SORTED_SHARES = 128;
+__global__ __launch_bounds__(256) void embed_bwd_sorted_scatter_kernel(const unsigned long long *__restrict__ sorted, int C2,
+                                                                       const float *__restrict__ s, const float *__restrict__ W,
+                                                                       int N, int C, int F, float *__restrict__ dcat, int ldd)
+{
+    const int b = blockIdx.y;
+    const unsigned long long *keys = sorted + (size_t)b * C2;
+    const int per = (C + EMB_SORTED_SHARES - 1) / EMB_SORTED_SHARES;
+    int i0 = blockIdx.x * per, i1 = i0 + per < C ? i0 + per : C;
+    if (i0 >= C) return;
+    // a point's run belongs to the share it starts in
+    while (i0 > 0 && i0 < C && (keys[i0] >> 32) == (keys[i0 - 1] >> 32)) ++i0;
+    while (i1 > 0 && i1 < C && (keys[i1] >> 32) == (keys[i1 - 1] >> 32)) ++i1;
+    for (int f = threadIdx.x; f < F; f += 256) {
+        float acc = 0.0f;
+        for (int i = i0; i < i1; i += 4) {
+            float sv[4], wv[4];
+            int nn[4], nx[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned long long key = keys[i + u < i1 ? i + u : i1 - 1];
+                const int c = (int)(unsigned)key;
+                nn[u] = (int)(key >> 32);
+                nx[u] = i + u + 1 < i1 ? (int)(keys[i + u + 1] >> 32) : -1;
+                sv[u] = s[(size_t)b * C + c];
+                wv[u] = W[(size_t)c * F + f];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (i + u < i1) {
+                    acc = __builtin_fmaf(sv[u], wv[u], acc);
+                    if (nx[u] != nn[u]) {
+                        dcat[((size_t)b * N + nn[u]) * ldd + f] += acc;
+                        acc = 0.0f;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // dcat[b N + arg[b][c]][f] += s[b][c] W[c][f] over the C winners of batch element b, race-free and in a fixed order:
 // every workgroup sorts the (point, channel) keys of its batch element in LDS, takes a contiguous share of the sorted
 // list moved to the next point boundary at both ends, and walks it with one thread per column f.
 constexpr int EMB_SHARES = 32;  // (8 shares: 91 us -- each workgroup walks its entries one dependent load at a time)
 __global__ __launch_bounds__(256) void embed_bwd_scatter_kernel(const int32_t *__restrict__ arg, const float *__restrict__ s,
                                                                 const float *__restrict__ W, int N, int C, int F, int C2,
-                                                                float *__restrict__ dcat)
+                                                                float *__restrict__ dcat, int ldd)
 {
     extern __shared__ unsigned long long keys[];  // C2 = C rounded up to a power of two
     const int b = blockIdx.y;
@@ -440,7 +539,7 @@ __global__ __launch_bounds__(256) void embed_bwd_scatter_kernel(const int32_t *_
                     acc = __builtin_fmaf(sv[u], wv[u], acc);
                     const int nxt = i + u + 1 < i1 ? (int)(keys[i + u + 1] >> 32) : -1;
                     if (nxt != nn[u]) {
-                        dcat[((size_t)b * N + nn[u]) * F + f] += acc;
+                        dcat[((size_t)b * N + nn[u]) * ldd + f] += acc;
                         acc = 0.0f;
                     }
                 }
@@ -731,18 +830,35 @@ void launch_colmax_finish(const unsigned long long *keys, const float *stats, in
     hipLaunchKernelGGL(colmax_finish_kernel, dim3(ceil_div(B * C, 256)), dim3(256), 0, st, keys, stats, B, C, slope, g, arg, uwin);
 }
 void launch_embed_bwd_coef(const float *uwin, const float *gg, const float *stats, int B, int N, int C, int training, float slope,
-                           float *gweight, float *gbias, float *coef_a, float *coef_b, float *s, hipStream_t st)
-{
-    hipLaunchKernelGGL(embed_bwd_coef_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, uwin, gg, stats, B, N, C, training, slope,
-                       gweight, gbias, coef_a, coef_b, s);
-}
-void launch_embed_bwd_scatter(const int32_t *arg, const float *s, const float *w, int B, int N, int C, int F, float *dcat,
-                              hipStream_t st)
+                           float *gweight, float *gbias, float *coef_a, float *coef_b, float *s, hipStream_t st, const int32_t *arg,
+                           unsigned long long *sorted)
 {
     int C2 = 1;
     while (C2 < C) C2 <<= 1;
+    hipLaunchKernelGGL(embed_bwd_coef_kernel, dim3(ceil_div(C, 256) + (sorted ? B : 0)), dim3(256),
+                       sorted ? (size_t)C2 * sizeof(unsigned long long) : 0, st, uwin, gg, stats, B, N, C, training, slope, gweight, gbias,
+                       coef_a, coef_b, s, arg, C2, sorted);
+}
+int embed_sorted_len(int C)
+{
+    int C2 = 1;
+    while (C2 < C) C2 <<= 1;
+    return C2;
+}
+void launch_embed_bwd_sorted_scatter(const unsigned long long *sorted, const float *s, const float *w, int B, int N, int C, int F,
+                                     float *dcat, hipStream_t st, int ldd)
+{
+    hipLaunchKernelGGL(embed_bwd_sorted_scatter_kernel, dim3(EMB_SORTED_SHARES, B), dim3(256), 0, st, sorted, embed_sorted_len(C), s, w,
+                       N, C, F, dcat, ldd > 0 ? ldd : F);
+}
+void launch_embed_bwd_scatter(const int32_t *arg, const float *s, const float *w, int B, int N, int C, int F, float *dcat,
+                              hipStream_t st, int ldd)
+{
+    if (ldd <= 0) ldd = F;
+    int C2 = 1;
+    while (C2 < C) C2 <<= 1;
     hipLaunchKernelGGL(embed_bwd_scatter_kernel, dim3(EMB_SHARES, B), dim3(256), (size_t)C2 * sizeof(unsigned long long), st, arg,
-                       s, w, N, C, F, C2, dcat);
+                       s, w, N, C, F, C2, dcat, ldd);
 }
 }  // namespace dgcnn
 
@@ -805,8 +921,8 @@ extern "C" int dgcnn_embed_max_bwd_prepare(const float *uwin, const float *gg, c
 {
     DG_REQUIRE(uwin && gg && stats && gweight && gbias && coef_a && coef_b && s, "dgcnn_embed_max_bwd_prepare: null pointer");
     DG_REQUIRE(B > 0 && N > 0 && C > 0, "dgcnn_embed_max_bwd_prepare: bad shape B=%d N=%d C=%d", B, N, C);
-    hipLaunchKernelGGL(embed_bwd_coef_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, (hipStream_t)stream, uwin, gg, stats, B, N,
-                       C, training, slope, gweight, gbias, coef_a, coef_b, s);
+    hipLaunchKernelGGL(embed_bwd_coef_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, uwin, gg, stats, B, N,
+                       C, training, slope, gweight, gbias, coef_a, coef_b, s, (const int32_t *)nullptr, 0, (unsigned long long *)nullptr);
     DG_CHECK_LAUNCH("dgcnn_embed_max_bwd_prepare");
     return 0;
 }
@@ -820,7 +936,7 @@ extern "C" int dgcnn_embed_max_bwd_scatter(const int32_t *arg, const float *s, c
     int C2 = 1;
     while (C2 < C) C2 <<= 1;
     hipLaunchKernelGGL(embed_bwd_scatter_kernel, dim3(EMB_SHARES, B), dim3(256), (size_t)C2 * sizeof(unsigned long long),
-                       (hipStream_t)stream, arg, s, w, N, C, F, C2, dcat);
+                       (hipStream_t)stream, arg, s, w, N, C, F, C2, dcat, F);
     DG_CHECK_LAUNCH("dgcnn_embed_max_bwd_scatter");
     return 0;
 }

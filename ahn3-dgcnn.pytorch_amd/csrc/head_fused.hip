@@ -26,6 +26,10 @@
 
 namespace dgcnn {
 void launch_sum_partials(const float *partial, int nchunk, int n, float *out, hipStream_t st);  // pointgemm.hip
+int embed_bwd_ld(const float *cat, int ldc, const uint32_t *amax_cat, const float *catsum, const float *w, int ldw,
+                 const int32_t *arg, const float *uwin, const float *stats, const float *gg, int B, int N, int F, int C,
+                 int training, float slope, float *dcat, int lddcat, int dcat_acc, float *dw, float *gbn_w, float *gbn_b,
+                 void *workspace, size_t workspace_bytes, void *stream);  // (model_parts.h)
 
 namespace hf {
 
@@ -43,10 +47,14 @@ struct WPrepArgs {
     WPrepJob job[WPREP_MAX];
     int first_row[WPREP_MAX + 1];
     int njobs;
+    unsigned long long *zero;  // side job (or NULL): nzero 64-bit words the NEXT kernel of the call takes maxima into
+    size_t nzero;              // (a hipMemsetAsync of their own was a 4.8 us launch)
 };
 
 __global__ __launch_bounds__(256) void wprep_kernel(WPrepArgs a)
 {
+    if (a.zero)
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.nzero; i += (size_t)gridDim.x * 256) a.zero[i] = 0ull;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int gr = blockIdx.x * 4 + wave;
     if (gr >= a.first_row[a.njobs]) return;
@@ -93,6 +101,7 @@ struct HGemmArgs {
     int rows_per_batch;
     float *Y;
     int ldy;
+    int yacc;        // E_PLAIN: Y += (the product is the second gradient that reaches Y) instead of Y =
     double *psum;    // E_STATS: [nrb][2][N] sum, sum of squares (or NULL: extrema only)
     float *pext;     // E_STATS: [nrb][2][N] min, max
     unsigned *zero;  // E_STATS: one word zeroed by workgroup 0 (the finalize kernel behind this launch takes a maximum into it)
@@ -388,7 +397,15 @@ __global__ __launch_bounds__(256, OCC) void hgemm_kernel(const HGemmArgs a)
                     }
                 }
             }
-            if (EMODE != E_COLRED && on) *reinterpret_cast<float4 *>(a.Y + (size_t)row * a.ldy + cbase) = float4{o[0], o[1], o[2], o[3]};
+            if (EMODE != E_COLRED && on) {
+                float4 *yp = reinterpret_cast<float4 *>(a.Y + (size_t)row * a.ldy + cbase);
+                if (EMODE == E_PLAIN && a.yacc) {
+                    const float4 y0 = *yp;
+                    *yp = float4{y0.x + o[0], y0.y + o[1], y0.z + o[2], y0.w + o[3]};
+                } else {
+                    *yp = float4{o[0], o[1], o[2], o[3]};
+                }
+            }
         }
         // fold the four row groups of the wave (lanes lr = 0 .. 3 of a column group): lanes with lr == 0 end up with the sums
 #pragma unroll
@@ -1526,7 +1543,7 @@ __global__ __launch_bounds__(256) void embed_dw_kernel(const float *__restrict__
 // (a wave every fourth row, a lane four adjacent columns) and leaves one fp64 record; colsum_fold_kernel adds the records
 // in order.  cols a multiple of 4, cols <= 256.
 __global__ __launch_bounds__(256) void rows_stats_kernel(const float *__restrict__ x, int ld, int rows, int cols,
-                                                         unsigned *__restrict__ amax, double *__restrict__ partial)
+                                                         float *__restrict__ pmax, double *__restrict__ partial)
 {
     __shared__ double red[4][256];
     __shared__ float rmax[4];
@@ -1562,13 +1579,29 @@ __global__ __launch_bounds__(256) void rows_stats_kernel(const float *__restrict
     __syncthreads();
     if ((int)threadIdx.x < cols) partial[(size_t)blockIdx.x * cols + threadIdx.x] =
         (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-    if (threadIdx.x == 0) atomicMax(amax, __float_as_uint(fmaxf(fmaxf(rmax[0], rmax[1]), fmaxf(rmax[2], rmax[3]))));
+    // (the workgroup's maximum goes to a record of its own: colsum_fold_kernel folds them -- no word to zero before the pass)
+    if (threadIdx.x == 0) pmax[blockIdx.x] = fmaxf(fmaxf(rmax[0], rmax[1]), fmaxf(rmax[2], rmax[3]));
 }
 __global__ __launch_bounds__(64 * FW) void colsum_fold_kernel(const double *__restrict__ partial, int nrec, int cols,
-                                                              float *__restrict__ colsum)
+                                                              float *__restrict__ colsum, const float *__restrict__ pmax,
+                                                              unsigned *__restrict__ amax)
 {
     __shared__ double red[FW][64];
+    __shared__ float mred[FW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (blockIdx.x == 0 && amax) {  // max |x| = the maximum of the workgroups' records (a maximum has no order)
+        float m = 0.0f;
+        for (int g = threadIdx.x; g < nrec; g += 64 * FW) m = fmaxf(m, pmax[g]);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if (lane == 0) mred[wave] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float t = mred[0];
+            for (int w = 1; w < FW; ++w) t = fmaxf(t, mred[w]);
+            *amax = __float_as_uint(t);
+        }
+    }
     const int c = blockIdx.x * 64 + lane;
     double a = 0.0;
     if (c < cols)
@@ -1995,9 +2028,13 @@ void launch_colstats_finalize(const double *partial, int nchunk, int P, int C, i
 void launch_colmax_finish(const unsigned long long *keys, const float *stats, int B, int C, float slope, float *g, int32_t *arg,
                           float *uwin, hipStream_t st);
 void launch_embed_bwd_coef(const float *uwin, const float *gg, const float *stats, int B, int N, int C, int training, float slope,
-                           float *gweight, float *gbias, float *coef_a, float *coef_b, float *s, hipStream_t st);
+                           float *gweight, float *gbias, float *coef_a, float *coef_b, float *s, hipStream_t st, const int32_t *arg,
+                           unsigned long long *sorted);
+int embed_sorted_len(int C);
+void launch_embed_bwd_sorted_scatter(const unsigned long long *sorted, const float *s, const float *w, int B, int N, int C, int F,
+                                     float *dcat, hipStream_t st, int ldd);
 void launch_embed_bwd_scatter(const int32_t *arg, const float *s, const float *w, int B, int N, int C, int F, float *dcat,
-                              hipStream_t st);
+                              hipStream_t st, int ldd);
 namespace hf {
 struct EmbedFwdWs {
     double *psum, *fpsum;
@@ -2018,6 +2055,7 @@ static EmbedFwdWs embed_fwd_ws(int B, int N, int F, int C, void *p)
 }
 struct EmbedBwdWs {
     float *coef_a, *coef_b, *s, *M, *v, *G, *wpart, *mvpart;
+    unsigned long long *sorted;  // [B][C2]: (winning point, channel) keys of every batch element, ascending
     Planes m;
     size_t bytes;
 };
@@ -2028,6 +2066,7 @@ static EmbedBwdWs embed_bwd_ws(int B, int N, int F, int C, void *p)
     w.coef_a = c.take<float>(C);
     w.coef_b = c.take<float>(C);
     w.s = c.take<float>((size_t)B * C);
+    w.sorted = c.take<unsigned long long>((size_t)B * embed_sorted_len(C));
     w.M = c.take<float>((size_t)F * F + F);  // M [F][F], then v [F]: one fold of the channel chunks' shares
     w.v = w.M + (size_t)F * F;
     w.mvpart = c.take<float>((size_t)ceil_div(C, MV_CH) * ((size_t)F * F + F));
@@ -2050,7 +2089,7 @@ static int embed_shape_ok(int B, int N, int F, int C, int ldc, int ldw, const ch
 
 extern "C" size_t dgcnn_rows_stats_workspace_bytes(int rows, int cols)
 {
-    return rows > 0 && cols > 0 ? align_up((size_t)ceil_div(rows, 256) * cols * sizeof(double), 256) : 0;
+    return rows > 0 && cols > 0 ? align_up((size_t)ceil_div(rows, 256) * cols * sizeof(double), 256) + align_up((size_t)ceil_div(rows, 256) * sizeof(float), 256) : 0;
 }
 extern "C" int dgcnn_rows_stats(const float *x, int ld, int rows, int cols, uint32_t *amax, float *colsum, void *workspace,
                                 size_t workspace_bytes, void *stream)
@@ -2060,10 +2099,11 @@ extern "C" int dgcnn_rows_stats(const float *x, int ld, int rows, int cols, uint
                "dgcnn_rows_stats: cols a multiple of 4 (<= 256), 16-byte aligned rows (rows=%d cols=%d ld=%d)", rows, cols, ld);
     DG_REQUIRE(workspace_bytes >= dgcnn_rows_stats_workspace_bytes(rows, cols), "dgcnn_rows_stats: workspace too small");
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(amax, 0, 4, st) != hipSuccess) DG_FAIL("dgcnn_rows_stats: hipMemsetAsync failed");
     const int nrec = ceil_div(rows, 256);
-    hipLaunchKernelGGL(rows_stats_kernel, dim3(nrec), dim3(256), 0, st, x, ld, rows, cols, amax, (double *)workspace);
-    hipLaunchKernelGGL(colsum_fold_kernel, dim3(ceil_div(cols, 64)), dim3(64 * FW), 0, st, (const double *)workspace, nrec, cols, colsum);
+    float *pmax = (float *)((char *)workspace + align_up((size_t)nrec * cols * sizeof(double), 256));
+    hipLaunchKernelGGL(rows_stats_kernel, dim3(nrec), dim3(256), 0, st, x, ld, rows, cols, pmax, (double *)workspace);
+    hipLaunchKernelGGL(colsum_fold_kernel, dim3(ceil_div(cols, 64)), dim3(64 * FW), 0, st, (const double *)workspace, nrec, cols, colsum,
+                       (const float *)pmax, amax);
     DG_CHECK_LAUNCH("dgcnn_rows_stats");
     return 0;
 }
@@ -2086,13 +2126,13 @@ extern "C" int dgcnn_embed_fwd(const float *cat, int ldc, const float *w, int ld
     DG_REQUIRE(workspace_bytes >= ws.bytes, "dgcnn_embed_fwd: workspace too small (%zu < %zu)", workspace_bytes, ws.bytes);
     hipStream_t st = (hipStream_t)stream;
     const int P = B * N, nrb = ceil_div(P, GM);
-    if (hipMemsetAsync(ws.keys, 0, (size_t)B * C * sizeof(unsigned long long), st) != hipSuccess) DG_FAIL("dgcnn_embed_fwd: memset failed");
     {
         WPrepArgs a{};
         a.job[0] = WPrepJob{w, ldw, C, F, 0, ws.w.hi, ws.w.lo, ws.w.scale};
         a.njobs = 1;
         a.first_row[0] = 0;
         a.first_row[1] = C;
+        a.zero = ws.keys, a.nzero = (size_t)B * C;  // the winners' keys start at zero (atomic maxima of the product's tiles)
         hipLaunchKernelGGL(wprep_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, a);
     }
     {
@@ -2125,16 +2165,28 @@ extern "C" int dgcnn_embed_bwd(const float *cat, int ldc, const uint32_t *amax_c
                                int training, float slope, float *dcat, int lddcat, float *dw, float *gbn_w, float *gbn_b,
                                void *workspace, size_t workspace_bytes, void *stream)
 {
+    DG_REQUIRE(lddcat == F, "dgcnn_embed_bwd: dcat must be contiguous (lddcat = F)");
+    return embed_bwd_ld(cat, ldc, amax_cat, catsum, w, ldw, arg, uwin, stats, gg, B, N, F, C, training, slope, dcat, lddcat, 0, dw,
+                        gbn_w, gbn_b, workspace, workspace_bytes, stream);
+}
+
+// dgcnn_embed_bwd with a row stride of dcat and, with dcat_acc, dL/dcat ADDED to what dcat holds (model.hip: the head's tail
+// has left its share of dL/dcat there -- model.py:167 and :180 both read the concatenation)
+int dgcnn::embed_bwd_ld(const float *cat, int ldc, const uint32_t *amax_cat, const float *catsum, const float *w, int ldw,
+                        const int32_t *arg, const float *uwin, const float *stats, const float *gg, int B, int N, int F, int C,
+                        int training, float slope, float *dcat, int lddcat, int dcat_acc, float *dw, float *gbn_w, float *gbn_b,
+                        void *workspace, size_t workspace_bytes, void *stream)
+{
     DG_REQUIRE(cat && amax_cat && w && arg && uwin && stats && gg && dcat && dw && gbn_w && gbn_b && workspace, "dgcnn_embed_bwd: null pointer");
     DG_REQUIRE(!training || catsum, "dgcnn_embed_bwd: training mode needs the column sums of cat");
     if (embed_shape_ok(B, N, F, C, ldc, ldw, "dgcnn_embed_bwd")) return 1;
-    DG_REQUIRE(lddcat == F && ldw == F, "dgcnn_embed_bwd: dcat and w must be contiguous (lddcat = ldw = F)");
+    DG_REQUIRE(lddcat >= F && (lddcat & 3) == 0 && ldw == F, "dgcnn_embed_bwd: lddcat >= F (a multiple of 4), w contiguous (ldw = F)");
     DG_REQUIRE(((uintptr_t)cat & 15) == 0 && ((uintptr_t)dcat & 15) == 0, "dgcnn_embed_bwd: rows must be 16-byte aligned");
     const EmbedBwdWs ws = embed_bwd_ws(B, N, F, C, workspace);
     DG_REQUIRE(workspace_bytes >= ws.bytes, "dgcnn_embed_bwd: workspace too small (%zu < %zu)", workspace_bytes, ws.bytes);
     hipStream_t st = (hipStream_t)stream;
     const int P = B * N, nrb = ceil_div(P, GM);
-    launch_embed_bwd_coef(uwin, gg, stats, B, N, C, training, slope, gbn_w, gbn_b, ws.coef_a, ws.coef_b, ws.s, st);
+    launch_embed_bwd_coef(uwin, gg, stats, B, N, C, training, slope, gbn_w, gbn_b, ws.coef_a, ws.coef_b, ws.s, st, arg, ws.sorted);
     if (training) {
         {
             const int ncs = ceil_div(C, MV_CH);
@@ -2157,7 +2209,7 @@ extern "C" int dgcnn_embed_bwd(const float *cat, int ldc, const uint32_t *amax_c
             a.xmax = amax_cat;
             a.slope = slope;
             a.add = ws.v, a.rows_per_batch = P;
-            a.Y = dcat, a.ldy = lddcat;
+            a.Y = dcat, a.ldy = lddcat, a.yacc = dcat_acc;
             a.ncb = ceil_div(F, GN), a.nrb = nrb;
             hipLaunchKernelGGL((hgemm_kernel<X_RAW, E_PLAIN, 3>), dim3((unsigned)align_up((size_t)a.ncb * nrb, 8)), dim3(256), 0, st, a);
         }
@@ -2176,12 +2228,13 @@ extern "C" int dgcnn_embed_bwd(const float *cat, int ldc, const uint32_t *amax_c
             hipLaunchKernelGGL((hwgrad_kernel<A_RAW, B_RAW, 3>), grid, dim3(256), 0, st, a);
             launch_sum_partials(ws.wpart, nch, F * F, ws.G, st);
         }
-    } else {
-        if (hipMemsetAsync(dcat, 0, (size_t)P * F * sizeof(float), st) != hipSuccess) DG_FAIL("dgcnn_embed_bwd: memset failed");
+    } else if (!dcat_acc) {   // eval mode: only the winners' rows are non-zero
+        if (hipMemset2DAsync(dcat, (size_t)lddcat * sizeof(float), 0, (size_t)F * sizeof(float), (size_t)P, st) != hipSuccess)
+            DG_FAIL("dgcnn_embed_bwd: memset failed");
     }
     hipLaunchKernelGGL(embed_dw_kernel, dim3(ceil_div(C, DW_CH)), dim3(256), 0, st, cat, ldc, w, ldw, arg, ws.s, ws.coef_a, ws.coef_b,
                        ws.G, catsum, B, N, C, F, training, dw);
-    launch_embed_bwd_scatter(arg, ws.s, w, B, N, C, F, dcat, st);
+    launch_embed_bwd_sorted_scatter(ws.sorted, ws.s, w, B, N, C, F, dcat, st, lddcat);
     DG_CHECK_LAUNCH("dgcnn_embed_bwd");
     return 0;
 }

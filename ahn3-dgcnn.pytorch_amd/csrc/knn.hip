@@ -50,6 +50,11 @@
 #include "prof.h"
 
 namespace dgcnn {
+int knn_ld(const float *x, int ldx, int B, int N, int C, int k, int32_t *idx, void *workspace, size_t workspace_bytes,
+           void *stream);  // (declared for the other translation units in edge_kernels.h)
+}  // namespace dgcnn
+
+namespace dgcnn {
 
 constexpr int KNN_ROWPAD = 128;  // query/candidate rows are padded to a multiple of this
 
@@ -58,14 +63,14 @@ typedef unsigned long long u64;
 // ------------------------------------------------------------------------------------
 // prep 1: squared norms with the oracle's chain order; +inf for padding rows, which makes
 // pd = -inf: a padded candidate can never enter a list.
-__global__ void knn_norm_kernel(const float *__restrict__ x, int N, int C, int Npad, float *__restrict__ xx)
+__global__ void knn_norm_kernel(const float *__restrict__ x, int ldx, int N, int C, int Npad, float *__restrict__ xx)
 {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     const int b = blockIdx.y;
     if (n >= Npad) return;
     float acc = __builtin_inff();
     if (n < N) {
-        const float *src = x + ((size_t)b * N + n) * C;
+        const float *src = x + ((size_t)b * N + n) * ldx;
         acc = 0.0f;
         for (int c = 0; c < C; ++c) acc = __builtin_fmaf(src[c], src[c], acc);
     }
@@ -77,7 +82,7 @@ __global__ void knn_norm_kernel(const float *__restrict__ x, int N, int C, int N
 //   xt[tile][g][lane][e] = x[tile * 32 + (lane & 31)][2 * (g * VEC + e) + (lane >> 5)]
 // (VEC = min(4, CP / 2) floats per lane and load; zero beyond N or C).  One thread per vector.
 template <int VEC>
-__global__ void knn_tile_kernel(const float *__restrict__ x, int N, int C, int Npad, int CP,
+__global__ void knn_tile_kernel(const float *__restrict__ x, int ldx, int N, int C, int Npad, int CP,
                                 float *__restrict__ xt)
 {
     const int G = (CP / 2) / VEC;
@@ -93,7 +98,7 @@ __global__ void knn_tile_kernel(const float *__restrict__ x, int N, int C, int N
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
         const int c = 2 * (g * VEC + e) + h;
-        out[e] = (n < N && c < C) ? x[((size_t)b * N + n) * C + c] : 0.0f;
+        out[e] = (n < N && c < C) ? x[((size_t)b * N + n) * ldx + c] : 0.0f;
     }
     float *dst = xt + (size_t)b * Npad * CP + v * VEC;
 #pragma unroll
@@ -246,7 +251,7 @@ __device__ __forceinline__ Half3 knn_split3(float v)
 // approximate centre of one batch element (any vector works: distances are translation invariant; centring only
 // tightens the fp16 error bound): the mean of the first <= 64 points, computed by every workgroup of knn_prep16_kernel
 // itself in the same fixed order (16 KB of L2-resident reads instead of a launch of its own)
-__device__ __forceinline__ void knn_centre(const float *__restrict__ x, int b, int N, int C, float *red /* [256] */,
+__device__ __forceinline__ void knn_centre(const float *__restrict__ x, int ldx, int b, int N, int C, float *red /* [256] */,
                                            float *ms /* [128] */)
 {
     const int G = 256 / C > 0 ? 256 / C : 1;  // C <= 128
@@ -254,7 +259,7 @@ __device__ __forceinline__ void knn_centre(const float *__restrict__ x, int b, i
     const int n1 = N < 64 ? N : 64;
     float s = 0.0f;
     if (g < G)
-        for (int n = g; n < n1; n += G) s += x[((size_t)b * N + n) * C + c];
+        for (int n = g; n < n1; n += G) s += x[((size_t)b * N + n) * ldx + c];
     red[threadIdx.x] = (g < G) ? s : 0.0f;
     __syncthreads();
     if ((int)threadIdx.x < C) {
@@ -292,7 +297,7 @@ __device__ __forceinline__ float batch_max(const unsigned *__restrict__ tmax, in
 //   rbflag[b][tile] = 0: the fallback flag of the row block, set later by the filter / refine kernels
 // CC: the channel count when it is known at compile time (64: the index arithmetic is shifts; 0: C and CP at run time)
 template <int CC>
-__global__ __launch_bounds__(256) void knn_prep16_kernel(const float *__restrict__ x,
+__global__ __launch_bounds__(256) void knn_prep16_kernel(const float *__restrict__ x, int ldx,
                                                          int N, int C_, int Npad, int CP_, float *__restrict__ xx,
                                                          float *__restrict__ xxc, half8 *__restrict__ xh,
                                                          float *__restrict__ xt, unsigned *__restrict__ bmax,
@@ -310,9 +315,9 @@ __global__ __launch_bounds__(256) void knn_prep16_kernel(const float *__restrict
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
         const int i = tid + 256 * u;
-        trow[u] = (i < 32 * C && q0 + i / C < N) ? x[((size_t)b * N + q0) * C + i] : 0.0f;
+        trow[u] = (i < 32 * C && q0 + i / C < N) ? x[((size_t)b * N + q0 + i / C) * ldx + i % C] : 0.0f;
     }
-    knn_centre(x, b, N, C, cred, ms);
+    knn_centre(x, ldx, b, N, C, cred, ms);
     if (tid == 0) rbflag[(size_t)b * (Npad / 32) + tile] = 0;  // fallback flag of this row block (set by filter / refine)
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
@@ -396,7 +401,7 @@ __global__ __launch_bounds__(256) void knn_prep16_kernel(const float *__restrict
 // 0.49 ms of a training step at B = 32, N = 7000).  One wave = one 32-point tile (a workgroup takes four); everything
 // knn_prep16_kernel leaves is left here too: xx, xxc, xh (data slab + augmented slab), xt (the layout of
 // knn_tile_kernel<2>, CP = 4), bmax, rbflag.
-__global__ __launch_bounds__(256) void knn_prep_split4_kernel(const float *__restrict__ x, int N, int C, int Npad,
+__global__ __launch_bounds__(256) void knn_prep_split4_kernel(const float *__restrict__ x, int ldx, int N, int C, int Npad,
                                                               float *__restrict__ xx, float *__restrict__ xxc,
                                                               half8 *__restrict__ xh, float *__restrict__ xt,
                                                               unsigned *__restrict__ bmax, int *__restrict__ rbflag)
@@ -409,8 +414,8 @@ __global__ __launch_bounds__(256) void knn_prep_split4_kernel(const float *__res
     const bool real = n < N;
     float v[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) v[c] = (real && c < C) ? x[((size_t)b * N + n) * C + c] : 0.0f;
-    knn_centre(x, b, N, C, cred, ms);
+    for (int c = 0; c < 4; ++c) v[c] = (real && c < C) ? x[((size_t)b * N + n) * ldx + c] : 0.0f;
+    knn_centre(x, ldx, b, N, C, cred, ms);
     __syncthreads();
     if (lane == 0) rbflag[(size_t)b * ntiles + tile] = 0;
     float raw = 0.0f, cen = 0.0f, d[4];
@@ -1028,25 +1033,33 @@ __global__ __launch_bounds__(64) void knn_bound_merge_kernel(const unsigned *__r
     }
 }
 
+// LDS of the exact all-pairs pass over one 32-row block
+template <int CAP>
+struct KnnExactLds {
+    u64 keys[32][CAP];
+    int cnts[32];
+    float taus[32];
+};
+
+// The exact fp32 all-pairs kNN of ONE 32-row block (b, rb) by one wave: the whole of knn_kernel below, and -- called from
+// knn_refine_kernel for the row blocks the fp16 filter path has flagged (features outside the fp16 range, a survivor list
+// that overflowed, a row that ended with fewer than k candidates) -- the fallback of that path, without a launch of its own
+// (behind every kNN build it was an idle 4.7 us launch on unflagged inputs).
 template <int CP, int CAP>
-__global__ __launch_bounds__(64, 2) void knn_kernel(const float *__restrict__ xt, const float *__restrict__ xx,
-                                                    const float *__restrict__ tau0, const int *__restrict__ rbflag,
-                                                    int B, int N, int Npad, int k, int32_t *__restrict__ idx)
+__device__ __forceinline__ void knn_exact_block(KnnExactLds<CAP> &L, const float *__restrict__ xt, const float *__restrict__ xx,
+                                                const float *__restrict__ tau0, int b, int rb, int N, int Npad, int k,
+                                                int32_t *__restrict__ idx)
 {
     constexpr int CH = CP / 2;
     constexpr int VEC = CH >= 4 ? 4 : CH;
     constexpr int G = CH / VEC;
     typedef float vecf __attribute__((ext_vector_type(VEC)));
 
-    __shared__ u64 keys[32][CAP];
-    __shared__ int cnts[32];
-    __shared__ float taus[32];
+    auto &keys = L.keys;
+    auto &cnts = L.cnts;
+    auto &taus = L.taus;
 
     const int lane = threadIdx.x, h = lane >> 5, j32 = lane & 31;
-    // blocks are dealt round-robin over the XCDs: with B a multiple of 8 all waves of batch
-    // element b run on one XCD and share its L2 copy of xt[b] (speed only)
-    const int b = blockIdx.x % B, rb = blockIdx.x / B;
-    if (rbflag && !rbflag[b * (Npad / 32) + rb]) return;  // row block already done by the fp16 filter + refine path
     const int q0 = rb * 32;
     const float *xtb = xt + (size_t)b * Npad * CP;
     const float *xxb = xx + (size_t)b * Npad;
@@ -1228,6 +1241,19 @@ __global__ __launch_bounds__(64, 2) void knn_kernel(const float *__restrict__ xt
             }
         }
     }
+}
+
+template <int CP, int CAP>
+__global__ __launch_bounds__(64, 2) void knn_kernel(const float *__restrict__ xt, const float *__restrict__ xx,
+                                                    const float *__restrict__ tau0, const int *__restrict__ rbflag,
+                                                    int B, int N, int Npad, int k, int32_t *__restrict__ idx)
+{
+    __shared__ KnnExactLds<CAP> L;
+    // blocks are dealt round-robin over the XCDs: with B a multiple of 8 all waves of batch
+    // element b run on one XCD and share its L2 copy of xt[b] (speed only)
+    const int b = blockIdx.x % B, rb = blockIdx.x / B;
+    if (rbflag && !rbflag[b * (Npad / 32) + rb]) return;  // row block already done by the fp16 filter + refine path
+    knn_exact_block<CP, CAP>(L, xt, xx, tau0, b, rb, N, Npad, k, idx);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1625,11 +1651,12 @@ __global__ __launch_bounds__(256) void knn_filter32_kernel(const float *__restri
 // the list entries of its 16 rows -- the other half's entries are inert lanes of a batch -- bring seven to a CU:
 // knn_refine<64, 128> 1.99 -> 1.52 ms, <4, 128> 0.76 -> 0.52 ms at B = 8, N = 32768, k = 64): exact pd of every listed survivor, selection, output.
 template <int CP, int CAP, int HALVES_ = (CAP == 64 ? 1 : 2)>
-__global__ __launch_bounds__(64) void knn_refine_kernel(const float *__restrict__ x, const float *__restrict__ xx,
+__global__ __launch_bounds__(64, 2) void knn_refine_kernel(const float *__restrict__ x, int ldx, const float *__restrict__ xx,
                                                         const unsigned *__restrict__ lists,
                                                         const int *__restrict__ lcount, int *__restrict__ rbflag,
                                                         int B, int N, int C, int Npad, int k, int parts,
-                                                        int32_t *__restrict__ idx)
+                                                        int32_t *__restrict__ idx, const float *__restrict__ xt,
+                                                        const float *__restrict__ tau0)
 {
     constexpr int XS = CP + 1;  // LDS row stride of the raw query rows (odd: conflict-free column reads)
     // key storage per row: 48 entries for k <= 32 (the filter leaves ~42 survivors per row; a fuller row is
@@ -1638,23 +1665,42 @@ __global__ __launch_bounds__(64) void knn_refine_kernel(const float *__restrict_
     constexpr int STORE = CAP == 64 ? 48 : CAP;
     constexpr int HALVES = HALVES_, ROWS = 32 / HALVES;  // rows of this wave
     constexpr unsigned INERT = 0xffffffffu;                        // a lane without an entry of this wave's rows
-    __shared__ u64 keys[ROWS][STORE];
-    __shared__ int cnts[ROWS];
-    __shared__ u64 tkeys[ROWS];  // key of the k-th best of a compacted row: later offers must beat it as KEYS (the list
-                                 // is not index-ordered inside a chunk of four tiles, so an equal pd with a lower
-                                 // index can arrive after the compaction and must still win)
-    __shared__ float xq[ROWS][XS];
-    __shared__ float xxq[ROWS];
+    // EXACT_INLINE (k <= 32: one wave per row block): a flagged row block is recomputed here by the exact all-pairs pass
+    // (knn_exact_block) instead of by a kernel launched behind this one; its LDS shares the refine's (a union: 16.6 KB
+    // inside the refine's 21 KB at C = 64).  k > 32 keeps the separate launch: 33 KB of keys there would halve the residency.
+    constexpr bool EXACT_INLINE = CAP == 64;
+    struct RefineLds {
+        u64 keys[ROWS][STORE];
+        int cnts[ROWS];
+        u64 tkeys[ROWS];  // key of the k-th best of a compacted row: later offers must beat it as KEYS (the list
+                          // is not index-ordered inside a chunk of four tiles, so an equal pd with a lower
+                          // index can arrive after the compaction and must still win)
+        float xq[ROWS][XS];
+        float xxq[ROWS];
+    };
+    union LdsU {
+        RefineLds r;
+        KnnExactLds<EXACT_INLINE ? CAP : 1> e;
+    };
+    __shared__ LdsU L;
+    auto &keys = L.r.keys;
+    auto &cnts = L.r.cnts;
+    auto &tkeys = L.r.tkeys;
+    auto &xq = L.r.xq;
+    auto &xxq = L.r.xxq;
 
     const int lane = threadIdx.x;
     const int half = HALVES == 2 ? (int)blockIdx.x & 1 : 0, bid = (int)blockIdx.x / HALVES;
     const int b = bid % B, rb = bid / B;
     const int ntiles = Npad / 32;
     const int wid = b * ntiles + rb;
-    if (rbflag[wid]) return;  // the exact fp32 kernel recomputes this row block
+    if (rbflag[wid]) {  // flagged by the prep / filter kernels: the exact fp32 pass recomputes this row block
+        if constexpr (EXACT_INLINE) knn_exact_block<CP, CAP>(L.e, xt, xx, tau0, b, rb, N, Npad, k, idx);
+        return;            // (k > 32: knn_kernel, launched behind this kernel)
+    }
     const int q0 = rb * 32 + half * ROWS;  // first row of this wave
     const float *xxb = xx + (size_t)b * Npad;
-    const float *xraw = x + (size_t)b * N * C;
+    const float *xraw = x + (size_t)b * N * ldx;
     // the survivor list comes in `parts` segments (one per candidate part of the filter)
     const unsigned *list = lists + (size_t)wid * KNN_MAXPARTS * KNN_LISTCAP;
     // (entry e of the concatenation lives in segment p at list[p * listcap + e - (entries before segment p)])
@@ -1667,7 +1713,7 @@ __global__ __launch_bounds__(64) void knn_refine_kernel(const float *__restrict_
 
     for (int e = lane; e < ROWS * CP; e += 64) {
         const int r = e / CP, c = e % CP;
-        xq[r][c] = (q0 + r < N && c < C) ? xraw[(size_t)(q0 + r) * C + c] : 0.0f;
+        xq[r][c] = (q0 + r < N && c < C) ? xraw[(size_t)(q0 + r) * ldx + c] : 0.0f;
     }
     if (lane < ROWS) {
         xxq[lane] = xxb[q0 + lane];
@@ -1693,12 +1739,12 @@ __global__ __launch_bounds__(64) void knn_refine_kernel(const float *__restrict_
     };
     auto fetch = [&](unsigned qe_, float4(&v)[NV], float &yy) {
         const unsigned qe = qe_ == INERT ? 0u : qe_;  // inert lanes read candidate 0 (one address for all of them)
-        const float *xl = xraw + (size_t)(qe & 0x7ffffffu) * C;
+        const float *xl = xraw + (size_t)(qe & 0x7ffffffu) * ldx;
         yy = xxb[qe & 0x7ffffffu];
 #pragma unroll
         for (int i = 0; i < NV; ++i) v[i] = (4 * i < C) ? *reinterpret_cast<const float4 *>(xl + 4 * i) : float4{0, 0, 0, 0};
     };
-    const bool vec = (C & 3) == 0;
+    const bool vec = (C & 3) == 0 && (ldx & 3) == 0;
     unsigned qe_c = entry(0), qe_n = entry(64);
     float4 vc[NV], vn[NV];
     float yc = 0.0f, yn = 0.0f;
@@ -1724,7 +1770,7 @@ __global__ __launch_bounds__(64) void knn_refine_kernel(const float *__restrict_
 #pragma unroll
             for (int i = 0; i < NV; ++i) vc[i] = vn[i];
         } else {
-            const float *xl = xraw + (size_t)cand * C;
+            const float *xl = xraw + (size_t)cand * ldx;
             ycand = xxb[cand];
             for (int c = 0; c < C; ++c) dot = __builtin_fmaf(xq[row][c], xl[c], dot);
         }
@@ -1763,6 +1809,7 @@ __global__ __launch_bounds__(64) void knn_refine_kernel(const float *__restrict_
     const bool bad = lane < ROWS && q0 + lane < N && cnts[lane] < need;
     if (__ballot(bad)) {
         if (lane == 0) rbflag[wid] = 1;
+        if constexpr (EXACT_INLINE) knn_exact_block<CP, CAP>(L.e, xt, xx, tau0, b, rb, N, Npad, k, idx);
         return;
     }
     if constexpr (CAP == 64) {
@@ -1901,7 +1948,7 @@ static KnnWs knn_ws(int B, int C, int N, void *base)
 }
 
 template <int CP>
-static void knn_f16_launch(int cap, int parts, const KnnWs &w, const float *x, int B, int N, int C, int Npad, int k,
+static void knn_f16_launch(int cap, int parts, const KnnWs &w, const float *x, int ldx, int B, int N, int C, int Npad, int k,
                            int32_t *idx, hipStream_t st)
 {
     const dim3 grid(B * (Npad / 32)), block(64);
@@ -1913,11 +1960,11 @@ static void knn_f16_launch(int cap, int parts, const KnnWs &w, const float *x, i
     // (two waves per block for k <= 32 as well -- knn_refine_kernel<CP, 64, 2> -- measured: 125 us against 80 at B = 8,
     // N = 7000: at 21 KB per wave that variant is not short of resident waves, and half-inert batches double its work)
     if (cap == 64)
-        hipLaunchKernelGGL((knn_refine_kernel<CP, 64>), grid, block, 0, st, x, w.xx, w.lists, w.lcount, w.rbflag, B, N, C,
-                           Npad, k, parts, idx);
+        hipLaunchKernelGGL((knn_refine_kernel<CP, 64>), grid, block, 0, st, x, ldx, w.xx, w.lists, w.lcount, w.rbflag, B, N, C,
+                           Npad, k, parts, idx, w.xt, w.tau0);
     else  // (two waves per row block: knn_refine_kernel)
-        hipLaunchKernelGGL((knn_refine_kernel<CP, 128>), dim3(2 * grid.x), block, 0, st, x, w.xx, w.lists, w.lcount, w.rbflag, B,
-                           N, C, Npad, k, parts, idx);
+        hipLaunchKernelGGL((knn_refine_kernel<CP, 128>), dim3(2 * grid.x), block, 0, st, x, ldx, w.xx, w.lists, w.lcount, w.rbflag, B,
+                           N, C, Npad, k, parts, idx, w.xt, w.tau0);
     prof_end(PROF_KNN_REFINE, st);
 }
 
@@ -1935,7 +1982,17 @@ extern "C" size_t dgcnn_knn_workspace_bytes(int B, int C, int N, int k)
 extern "C" int dgcnn_knn(const float *x, int B, int N, int C, int k, int32_t *idx, void *workspace,
                          size_t workspace_bytes, void *stream)
 {
+    return knn_ld(x, 0, B, N, C, k, idx, workspace, workspace_bytes, stream);
+}
+
+// the search over rows with a stride: x [B N][ldx] with the C features of a point in its first C columns (model.hip: a
+// 64-column slice of the [P][192] concatenation of the block outputs); ldx = 0: dense
+int dgcnn::knn_ld(const float *x, int ldx, int B, int N, int C, int k, int32_t *idx, void *workspace, size_t workspace_bytes,
+                  void *stream)
+{
     DG_REQUIRE(x && idx && workspace, "dgcnn_knn: null pointer");
+    if (ldx <= 0) ldx = C;
+    DG_REQUIRE(ldx >= C, "dgcnn_knn: row stride %d < C = %d", ldx, C);
     DG_REQUIRE(B > 0 && N > 0 && C > 0, "dgcnn_knn: bad shape B=%d N=%d C=%d", B, N, C);
     DG_REQUIRE(C <= 128, "dgcnn_knn: C=%d > 128 unsupported", C);
     // the reference raises from topk when k > N (model.py:39)
@@ -1961,24 +2018,24 @@ extern "C" int dgcnn_knn(const float *x, int B, int N, int C, int k, int32_t *id
     static const bool split4_off = getenv("DGCNN_KNN_NO_SPLIT4") != nullptr;
     const bool split4 = prepass && C <= 4 && !f16_off && !split4_off && (k <= 40 || parts == 2);
     if (split4) {
-        hipLaunchKernelGGL(knn_prep_split4_kernel, dim3(Npad / 128, B), dim3(256), 0, st, x, N, C, Npad, xx, w.xxc, w.xh, xt, w.bmax,
+        hipLaunchKernelGGL(knn_prep_split4_kernel, dim3(Npad / 128, B), dim3(256), 0, st, x, ldx, N, C, Npad, xx, w.xxc, w.xh, xt, w.bmax,
                            w.rbflag);
     } else if (prepass && CP >= 16) {
         // one pass over x: norms, fp16 and fp32 operand tiles, norm maxima (after the centre of each batch element)
         if (C == 64 && CP == 64)
-            hipLaunchKernelGGL(knn_prep16_kernel<64>, dim3(Npad / 32, B), dim3(256), 0, st, x, N, C, Npad, CP, xx, w.xxc, w.xh,
+            hipLaunchKernelGGL(knn_prep16_kernel<64>, dim3(Npad / 32, B), dim3(256), 0, st, x, ldx, N, C, Npad, CP, xx, w.xxc, w.xh,
                                xt, w.bmax, w.rbflag);
         else
-            hipLaunchKernelGGL(knn_prep16_kernel<0>, dim3(Npad / 32, B), dim3(256), 0, st, x, N, C, Npad, CP, xx, w.xxc, w.xh,
+            hipLaunchKernelGGL(knn_prep16_kernel<0>, dim3(Npad / 32, B), dim3(256), 0, st, x, ldx, N, C, Npad, CP, xx, w.xxc, w.xh,
                                xt, w.bmax, w.rbflag);
     } else {
-        hipLaunchKernelGGL(knn_norm_kernel, dim3(ceil_div(Npad, 256), B), dim3(256), 0, st, x, N, C, Npad, xx);
+        hipLaunchKernelGGL(knn_norm_kernel, dim3(ceil_div(Npad, 256), B), dim3(256), 0, st, x, ldx, N, C, Npad, xx);
         const size_t nvec = (size_t)Npad * CP / (CP >= 8 ? 4 : 2);
         const dim3 tgrid((unsigned)((nvec + 255) / 256), B);
         if (CP >= 8)
-            hipLaunchKernelGGL((knn_tile_kernel<4>), tgrid, dim3(256), 0, st, x, N, C, Npad, CP, xt);
+            hipLaunchKernelGGL((knn_tile_kernel<4>), tgrid, dim3(256), 0, st, x, ldx, N, C, Npad, CP, xt);
         else
-            hipLaunchKernelGGL((knn_tile_kernel<2>), tgrid, dim3(256), 0, st, x, N, C, Npad, CP, xt);
+            hipLaunchKernelGGL((knn_tile_kernel<2>), tgrid, dim3(256), 0, st, x, ldx, N, C, Npad, CP, xt);
     }
     DG_CHECK_LAUNCH("knn prep kernels");
 
@@ -2033,11 +2090,11 @@ extern "C" int dgcnn_knn(const float *x, int B, int N, int C, int k, int32_t *id
         prof_begin(PROF_KNN_REFINE, st);
         const dim3 rgrid(B * (Npad / 32));
         if (cap == 64)
-            hipLaunchKernelGGL((knn_refine_kernel<4, 64>), rgrid, dim3(64), 0, st, x, w.xx, w.lists, w.lcount, w.rbflag, B, N, C, Npad,
-                               k, fparts, idx);
+            hipLaunchKernelGGL((knn_refine_kernel<4, 64>), rgrid, dim3(64), 0, st, x, ldx, w.xx, w.lists, w.lcount, w.rbflag, B, N, C, Npad,
+                               k, fparts, idx, xt, w.tau0);
         else
-            hipLaunchKernelGGL((knn_refine_kernel<4, 128>), dim3(2 * rgrid.x), dim3(64), 0, st, x, w.xx, w.lists, w.lcount, w.rbflag,
-                               B, N, C, Npad, k, fparts, idx);
+            hipLaunchKernelGGL((knn_refine_kernel<4, 128>), dim3(2 * rgrid.x), dim3(64), 0, st, x, ldx, w.xx, w.lists, w.lcount, w.rbflag,
+                               B, N, C, Npad, k, fparts, idx, xt, w.tau0);
         prof_end(PROF_KNN_REFINE, st);
         DG_CHECK_LAUNCH("knn_filter16_kernel<16, split> / knn_refine_kernel");
     } else if (prepass && CP < 16 && !f32filter_off) {
@@ -2056,8 +2113,8 @@ extern "C" int dgcnn_knn(const float *x, int B, int N, int C, int k, int32_t *id
         prof_end(PROF_KNN_FILTER, st);
         prof_begin(PROF_KNN_REFINE, st);
 #define DG_REFINE(CP_, CAP_)                                                                                          \
-    hipLaunchKernelGGL((knn_refine_kernel<CP_, CAP_>), dim3(rgrid.x * (CAP_ == 64 ? 1 : 2)), dim3(64), 0, st, x, w.xx, w.lists, \
-                       w.lcount, w.rbflag, B, N, C, Npad, k, fparts, idx)
+    hipLaunchKernelGGL((knn_refine_kernel<CP_, CAP_>), dim3(rgrid.x * (CAP_ == 64 ? 1 : 2)), dim3(64), 0, st, x, ldx, w.xx, w.lists, \
+                       w.lcount, w.rbflag, B, N, C, Npad, k, fparts, idx, xt, w.tau0)
         if (CP == 4) {
             if (cap == 64) DG_REFINE(4, 64);
             else DG_REFINE(4, 128);
@@ -2074,14 +2131,18 @@ extern "C" int dgcnn_knn(const float *x, int B, int N, int C, int k, int32_t *id
         // kernels flagged (it returns at once for the others)
         rbflag = w.rbflag;
         switch (CP) {
-            case 16: knn_f16_launch<16>(cap, fparts, w, x, B, N, C, Npad, k, idx, st); break;
-            case 32: knn_f16_launch<32>(cap, fparts, w, x, B, N, C, Npad, k, idx, st); break;
-            case 64: knn_f16_launch<64>(cap, fparts, w, x, B, N, C, Npad, k, idx, st); break;
-            default: knn_f16_launch<128>(cap, fparts, w, x, B, N, C, Npad, k, idx, st); break;
+            case 16: knn_f16_launch<16>(cap, fparts, w, x, ldx, B, N, C, Npad, k, idx, st); break;
+            case 32: knn_f16_launch<32>(cap, fparts, w, x, ldx, B, N, C, Npad, k, idx, st); break;
+            case 64: knn_f16_launch<64>(cap, fparts, w, x, ldx, B, N, C, Npad, k, idx, st); break;
+            default: knn_f16_launch<128>(cap, fparts, w, x, ldx, B, N, C, Npad, k, idx, st); break;
         }
         DG_CHECK_LAUNCH("knn_filter16_kernel / knn_refine_kernel");
     }
 
+    // the exact fp32 all-pairs kernel: the whole search where no filter path ran (rbflag == NULL); behind a filter path the
+    // fallback for the row blocks it flagged -- for k <= 32 the refine kernel has already recomputed those itself
+    // (knn_exact_block inside knn_refine_kernel), so nothing is launched here
+    if (rbflag && cap == 64) return 0;
     switch (CP) {
         case 4: knn_launch_cp<4>(cap, B, st, xt, xx, tau0, rbflag, N, Npad, k, idx); break;
         case 8: knn_launch_cp<8>(cap, B, st, xt, xx, tau0, rbflag, N, Npad, k, idx); break;

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(const float *__restrict__ 
                                                       const float *__restrict__ A1, int K1,
                                                       const float *__restrict__ W, int NO,
                                                       float *__restrict__ Y0, int NO0, float *__restrict__ Y1,
-                                                      int P, const FwdSide sd)
+                                                      int P, const FwdSide sd, const RowLd ld)
 {
     // the weights are read by every wave at every step: stage them in LDS (the kernel was bound by the
     // latency of those loads: 73 % of its wave cycles in s_waitcnt)
@@ -86,16 +86,16 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(const float *__restrict__ 
     // this lane's K values: k = h * KH + s, s < KH (zero beyond K or beyond P)
     auto a_at = [&](int kk) -> float {
         if (!rv || kk >= K) return 0.0f;
-        return (kk < K0) ? A0[(size_t)row * K0 + kk] : A1[(size_t)row * K1 + (kk - K0)];
+        return (kk < K0) ? A0[(size_t)row * ld.a0 + kk] : A1[(size_t)row * K1 + (kk - K0)];
     };
     for (int s0 = 0; s0 < KH; s0 += 8) {
         float a[8];
         const int kb = h * KH + s0;
         // fast path: 8 contiguous, 16-byte aligned values inside one source array
-        const bool in0 = kb + 8 <= K0 && (K0 & 3) == 0 && (kb & 3) == 0;
+        const bool in0 = kb + 8 <= K0 && (ld.a0 & 3) == 0 && (kb & 3) == 0;
         const bool in1 = kb >= K0 && kb + 8 <= K && (K1 & 3) == 0 && ((kb - K0) & 3) == 0;
         if (s0 + 8 <= KH && rv && (in0 || in1)) {
-            const float *src = in0 ? A0 + (size_t)row * K0 + kb : A1 + (size_t)row * K1 + (kb - K0);
+            const float *src = in0 ? A0 + (size_t)row * ld.a0 + kb : A1 + (size_t)row * K1 + (kb - K0);
             const float4 v0 = *reinterpret_cast<const float4 *>(src), v1 = *reinterpret_cast<const float4 *>(src + 4);
             a[0] = v0.x, a[1] = v0.y, a[2] = v0.z, a[3] = v0.w, a[4] = v1.x, a[5] = v1.y, a[6] = v1.z, a[7] = v1.w;
         } else {
@@ -124,9 +124,10 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(const float *__restrict__ 
             for (int r = 0; r < 16; ++r) {
                 const int pr = p0 + mfma32_row(r, h);
                 if (pr < P) {
-                    if (n < NO0)
-                        Y0[(size_t)pr * NO0 + n] = acc[nt][r];
-                    else
+                    if (n < NO0) {
+                        float *o0 = Y0 + (size_t)pr * ld.y0 + n;
+                        *o0 = ld.y0_acc ? *o0 + acc[nt][r] : acc[nt][r];
+                    } else
                         Y1[(size_t)pr * NO1 + (n - NO0)] = acc[nt][r];
                 }
             }
@@ -143,7 +144,7 @@ template <int KH, int NT, bool FROM_W1>
 __global__ __launch_bounds__(256) void rowgemm_fast_kernel(const float *__restrict__ A0, int K0,
                                                            const float *__restrict__ A1, int K1,
                                                            const float *__restrict__ W, float *__restrict__ Y0, int NO0,
-                                                           float *__restrict__ Y1, int P, const FwdSide sd)
+                                                           float *__restrict__ Y1, int P, const FwdSide sd, const RowLd ld)
 {
     constexpr int K = 2 * KH, NO = 32 * NT;
     __shared__ float wl[K * NO];
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(256) void rowgemm_fast_kernel(const float *__restri
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, i32 = lane & 31;
     const int p0 = (blockIdx.x * 4 + wave) * 32;
     const int row = p0 + i32 < P ? p0 + i32 : P - 1;  // clamped: loads are unconditional, stores guarded
-    const float *src = (K1 == 0 || h == 0) ? A0 + (size_t)row * K0 + h * (K1 == 0 ? KH : 0) : A1 + (size_t)row * K1;
+    const float *src = (K1 == 0 || h == 0) ? A0 + (size_t)row * ld.a0 + h * (K1 == 0 ? KH : 0) : A1 + (size_t)row * K1;
     float4 av[KH / 4];
 #pragma unroll
     for (int i = 0; i < KH / 4; ++i) av[i] = reinterpret_cast<const float4 *>(src)[i];
@@ -198,13 +199,72 @@ __global__ __launch_bounds__(256) void rowgemm_fast_kernel(const float *__restri
     for (int nt = 0; nt < NT; ++nt) {
         const int n = nt * 32 + i32;
         float *dst = n < NO0 ? Y0 + n : Y1 + (n - NO0);
-        const int ld = n < NO0 ? NO0 : NO1;
+        const int ldo = n < NO0 ? ld.y0 : NO1;
+        const bool add = n < NO0 && ld.y0_acc;  // (wave-uniform: NO0 is a multiple of 32)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int pr = p0 + mfma32_row(r, h);
-            if (full || pr < P) dst[(size_t)pr * ld] = acc[nt][r];
+            if (full || pr < P) dst[(size_t)pr * ldo] = add ? dst[(size_t)pr * ldo] + acc[nt][r] : acc[nt][r];
         }
     }
+}
+
+// gw1 [64][2C] of the block's first convolution from the per-chunk partial products G = [dR ; dD]^T x ([128][C]):
+// W = [Wa | Wb] acts as Wa x_j + (Wb - Wa) x_i, so gWa = G_R - G_D (c < C: G[o][c] - G[64 + o][c]) and gWb = G_D
+// (c >= C: G[64 + o][c - C]).  NW waves take consecutive shares of the chunks (eight chunks in flight, added in chunk
+// order), the NW sums are added in wave order, then one subtraction: a fixed association.  Workgroup `block` finishes 64
+// elements.  The body of finish_dw1_kernel (NW = 16) and of the workgroups that ride behind the input-gradient product
+// (NW = 4, rowgemm_split_kernel: the two kernels read the same [dR | dD] and neither needs the other's result).
+template <int NW>
+__device__ __forceinline__ void finish_dw1_body(const float *__restrict__ partial, int nchunk, int C, float *__restrict__ gw1, int block)
+{
+    __shared__ float red[NW][2][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int t = block * 64 + lane, n = 128 * C;
+    const int q = (nchunk + NW - 1) / NW;
+    const int c0 = w * q, c1 = c0 + q < nchunk ? c0 + q : nchunk;
+    float sr = 0.0f, sd = 0.0f;
+    const bool live = t < EC * 2 * C;
+    const int o = live ? t / (2 * C) : 0, c = live ? t % (2 * C) : 0;
+    const bool first = c < C;  // a gWa column: both sources
+    const int er = o * C + (first ? c : 0), ed = (EC + o) * C + (first ? c : c - C);
+    if (live) {
+        int ch = c0;
+        for (; ch + 8 <= c1; ch += 8) {
+            float vr[8], vd[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                vd[u] = partial[(size_t)(ch + u) * n + ed];
+                vr[u] = first ? partial[(size_t)(ch + u) * n + er] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                sd += vd[u];
+                sr += vr[u];
+            }
+        }
+        for (; ch < c1; ++ch) {
+            sd += partial[(size_t)ch * n + ed];
+            sr += first ? partial[(size_t)ch * n + er] : 0.0f;
+        }
+    }
+    red[w][0][lane] = sr;
+    red[w][1][lane] = sd;
+    __syncthreads();
+    if (w == 0 && live) {
+        float tr = red[0][0][lane], td = red[0][1][lane];
+#pragma unroll
+        for (int i = 1; i < NW; ++i) {
+            tr += red[i][0][lane];
+            td += red[i][1][lane];
+        }
+        gw1[t] = first ? tr - td : td;
+    }
+}
+__global__ __launch_bounds__(1024) void finish_dw1_kernel(const float *__restrict__ partial, int nchunk, int C,
+                                                          float *__restrict__ gw1)
+{
+    finish_dw1_body<16>(partial, nchunk, C, gw1, (int)blockIdx.x);
 }
 
 // The same two products on the fp16 matrix cores: both operands scaled by an exact power of two and split in two fp16
@@ -219,8 +279,14 @@ template <int KH, int NT, bool FROM_W1>
 __global__ __launch_bounds__(256) void rowgemm_split_kernel(const float *__restrict__ A0, int K0,
                                                             const float *__restrict__ A1, int K1,
                                                             const float *__restrict__ W, float *__restrict__ Y0, int NO0,
-                                                            float *__restrict__ Y1, int P, const FwdSide sd)
+                                                            float *__restrict__ Y1, int P, const FwdSide sd, const RowLd ld,
+                                                            const Dw1Rider rd)
 {
+    // workgroups rd.main_blocks .. : the weight gradient's fold (finish_dw1_body), riding in this launch
+    if (!FROM_W1 && rd.gw1 && (int)blockIdx.x >= rd.main_blocks) {
+        finish_dw1_body<4>(rd.partial, rd.nchunk, rd.C, rd.gw1, (int)blockIdx.x - rd.main_blocks);
+        return;
+    }
     constexpr int K = 2 * KH, NO = 32 * NT, ROWB = K * 2, PLANE = NO * ROWB;
     static_assert(K * NO == 8192 && (K == 64 || K == 128), "the two shapes of the 64-channel blocks");
     __shared__ __attribute__((aligned(16))) unsigned char wp[2 * PLANE];
@@ -228,7 +294,7 @@ __global__ __launch_bounds__(256) void rowgemm_split_kernel(const float *__restr
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), h = lane >> 5, i32 = lane & 31;
     const int p0 = (blockIdx.x * 4 + wave) * 32;
     const int row = p0 + i32 < P ? p0 + i32 : P - 1;  // clamped: loads are unconditional, stores guarded
-    const float *src = (K1 == 0 || h == 0) ? A0 + (size_t)row * K0 + h * (K1 == 0 ? KH : 0) : A1 + (size_t)row * K1;
+    const float *src = (K1 == 0 || h == 0) ? A0 + (size_t)row * ld.a0 + h * (K1 == 0 ? KH : 0) : A1 + (size_t)row * K1;
     float4 av[KH / 4];
 #pragma unroll
     for (int i = 0; i < KH / 4; ++i) av[i] = reinterpret_cast<const float4 *>(src)[i];
@@ -290,11 +356,30 @@ __global__ __launch_bounds__(256) void rowgemm_split_kernel(const float *__restr
     }
     __syncthreads();
     if (p0 >= P) return;
+    const bool full = p0 + 32 <= P;
+    const float un = 1.0f / (sA * sW);
     f32x16 acc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
+    // y0_acc (the product is the SECOND gradient that reaches Y0): what Y0 holds is fetched here, ahead of the matrix
+    // instructions, and joins the result as the accumulators' starting value (in the product's scale) -- read behind the
+    // product it was a dependent load in front of every store: 22 us against 8 at P = 28 000
+    if (ld.y0_acc) {
+        const float iun = sA * sW;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = nt * 32 + i32;
+            if (n < NO0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int pr = p0 + mfma32_row(r, h);
+                    acc[nt][r] = (full || pr < P) ? Y0[(size_t)pr * ld.y0 + n] * iun : 0.0f;
+                }
+            }
+        }
+    }
     // step s of lane half h covers k = h KH + 8 s .. + 7: chunk h KH / 8 + s of the image rows
 #pragma unroll
     for (int s = 0; s < KH / 8; ++s) {
@@ -310,18 +395,16 @@ __global__ __launch_bounds__(256) void rowgemm_split_kernel(const float *__restr
             acc[nt] = mfma3(ahi, alo, bhi, blo, acc[nt]);
         }
     }
-    const float un = 1.0f / (sA * sW);
-    const bool full = p0 + 32 <= P;
     const int NO1 = NO - NO0;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int n = nt * 32 + i32;
         float *dst = n < NO0 ? Y0 + n : Y1 + (n - NO0);
-        const int ld = n < NO0 ? NO0 : NO1;
+        const int ldo = n < NO0 ? ld.y0 : NO1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int pr = p0 + mfma32_row(r, h);
-            if (full || pr < P) dst[(size_t)pr * ld] = acc[nt][r] * un;
+            if (full || pr < P) dst[(size_t)pr * ldo] = acc[nt][r] * un;
         }
     }
 }
@@ -332,7 +415,7 @@ constexpr int WGRAD_CHUNK = 64;  // points per wave (875 waves at P = 56 000)
 template <int MT, int NT>
 __global__ __launch_bounds__(64) void wgrad_kernel(const float *__restrict__ A0, int M0,
                                                    const float *__restrict__ A1, int M1,
-                                                   const float *__restrict__ X, int C, int P,
+                                                   const float *__restrict__ X, int ldx, int C, int P,
                                                    float *__restrict__ partial)
 {
     const int lane = threadIdx.x, h = lane >> 5, i32 = lane & 31;
@@ -368,7 +451,7 @@ __global__ __launch_bounds__(64) void wgrad_kernel(const float *__restrict__ A0,
             for (int nt = 0; nt < NT; ++nt) {
                 const int n = nt * 32 + i32;
                 float v = 0.0f;
-                if (n < C) v = X[(size_t)pc * C + n];
+                if (n < C) v = X[(size_t)pc * ldx + n];
                 b[u][nt] = pv ? v : 0.0f;
             }
         }
@@ -427,59 +510,6 @@ __global__ __launch_bounds__(1024) void sum_partials_kernel(const float *__restr
     }
 }
 
-// gw1 [64][2C] of the block's first convolution from the per-chunk partial products G = [dR ; dD]^T x ([128][C]):
-// W = [Wa | Wb] acts as Wa x_j + (Wb - Wa) x_i, so gWa = G_R - G_D (c < C: G[o][c] - G[64 + o][c]) and gWb = G_D
-// (c >= C: G[64 + o][c - C]).  Same summation order as sum_partials_kernel (sixteen waves take consecutive shares of
-// the chunks, eight chunks in flight) for both sources of an output element, then one subtraction: one launch instead
-// of a sum followed by a combine kernel.
-__global__ __launch_bounds__(1024) void finish_dw1_kernel(const float *__restrict__ partial, int nchunk, int C,
-                                                          float *__restrict__ gw1)
-{
-    __shared__ float red[SUM_WAVES][2][64];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int t = blockIdx.x * 64 + lane, n = 128 * C;
-    const int q = (nchunk + SUM_WAVES - 1) / SUM_WAVES;
-    const int c0 = w * q, c1 = c0 + q < nchunk ? c0 + q : nchunk;
-    float sr = 0.0f, sd = 0.0f;
-    const bool live = t < EC * 2 * C;
-    const int o = live ? t / (2 * C) : 0, c = live ? t % (2 * C) : 0;
-    const bool first = c < C;  // a gWa column: both sources
-    const int er = o * C + (first ? c : 0), ed = (EC + o) * C + (first ? c : c - C);
-    if (live) {
-        int ch = c0;
-        for (; ch + 8 <= c1; ch += 8) {
-            float vr[8], vd[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                vd[u] = partial[(size_t)(ch + u) * n + ed];
-                vr[u] = first ? partial[(size_t)(ch + u) * n + er] : 0.0f;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                sd += vd[u];
-                sr += vr[u];
-            }
-        }
-        for (; ch < c1; ++ch) {
-            sd += partial[(size_t)ch * n + ed];
-            sr += first ? partial[(size_t)ch * n + er] : 0.0f;
-        }
-    }
-    red[w][0][lane] = sr;
-    red[w][1][lane] = sd;
-    __syncthreads();
-    if (w == 0 && live) {
-        float tr = red[0][0][lane], td = red[0][1][lane];
-#pragma unroll
-        for (int i = 1; i < SUM_WAVES; ++i) {
-            tr += red[i][0][lane];
-            td += red[i][1][lane];
-        }
-        gw1[t] = first ? tr - td : td;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 static bool rowgemm_force_f32()  // experiments / tests: the fp32-MFMA form of the backward products
 {
     static const int v = getenv("DGCNN_ROWGEMM_F32") ? atoi(getenv("DGCNN_ROWGEMM_F32")) : 0;
@@ -495,51 +525,54 @@ static bool rowgemm_split_fwd()
     return v != 0;
 }
 
-void launch_rowgemm_fwd(const float *x, int C, const float *w1, float *TP, float *TQ, const FwdSide &sd, int P, hipStream_t st)
+void launch_rowgemm_fwd(const float *x, int C, const float *w1, float *TP, float *TQ, const FwdSide &sd, int P, hipStream_t st,
+                        int ldx)
 {
     const dim3 grid(ceil_div(ceil_div(P, 32), 4)), block(256);
+    const RowLd ld{ldx > 0 ? ldx : C, EC, 0};
     if (C == 64 && rowgemm_split_fwd())
-        hipLaunchKernelGGL((rowgemm_split_kernel<32, 4, true>), grid, block, 0, st, x, C, nullptr, 0, w1, TP, EC, TQ, P, sd);
+        hipLaunchKernelGGL((rowgemm_split_kernel<32, 4, true>), grid, block, 0, st, x, C, nullptr, 0, w1, TP, EC, TQ, P, sd, ld, Dw1Rider{});
     else if (C == 64)
-        hipLaunchKernelGGL((rowgemm_fast_kernel<32, 4, true>), grid, block, 0, st, x, C, nullptr, 0, w1, TP, EC, TQ, P, sd);
+        hipLaunchKernelGGL((rowgemm_fast_kernel<32, 4, true>), grid, block, 0, st, x, C, nullptr, 0, w1, TP, EC, TQ, P, sd, ld);
     else
-        hipLaunchKernelGGL((rowgemm_kernel<4, true>), grid, block, 0, st, x, C, nullptr, 0, w1, 128, TP, EC, TQ, P, sd);
+        hipLaunchKernelGGL((rowgemm_kernel<4, true>), grid, block, 0, st, x, C, nullptr, 0, w1, 128, TP, EC, TQ, P, sd, ld);
 }
 
 void launch_rowgemm(const float *A0, int K0, const float *A1, int K1, const float *W, int NO, float *Y0, int NO0,
-                    float *Y1, int P, hipStream_t st)
+                    float *Y1, int P, hipStream_t st, int ldy0, int y0_accumulate)
 {
     const dim3 grid(ceil_div(ceil_div(P, 32), 4)), block(256);
     const int nt = ceil_div(NO, 32);
     const int K = K0 + K1, NO1 = NO - NO0;
+    const RowLd ld{K0, ldy0 > 0 ? ldy0 : NO0, y0_accumulate};
     const bool runs_ok = (K1 == 0 || K0 == K / 2) && (K0 & 3) == 0 && (K1 & 3) == 0;
     if (runs_ok && NO0 % 32 == 0 && NO1 % 32 == 0 && (NO1 == 0 || Y1)) {
         if (!rowgemm_force_f32() && ((K == 64 && NO == 128) || (K == 128 && NO == 64))) {
             if (K == 64)
                 hipLaunchKernelGGL((rowgemm_split_kernel<32, 4, false>), grid, block, 0, st, A0, K0, A1, K1, W, Y0, NO0, Y1, P,
-                                   FwdSide{});
+                                   FwdSide{}, ld, Dw1Rider{});
             else
                 hipLaunchKernelGGL((rowgemm_split_kernel<64, 2, false>), grid, block, 0, st, A0, K0, A1, K1, W, Y0, NO0, Y1, P,
-                                   FwdSide{});
+                                   FwdSide{}, ld, Dw1Rider{});
             return;
         }
         if (K == 64 && NO == 128) {
             hipLaunchKernelGGL((rowgemm_fast_kernel<32, 4, false>), grid, block, 0, st, A0, K0, A1, K1, W, Y0, NO0, Y1, P,
-                               FwdSide{});
+                               FwdSide{}, ld);
             return;
         }
         if (K == 128 && NO == 64) {
             hipLaunchKernelGGL((rowgemm_fast_kernel<64, 2, false>), grid, block, 0, st, A0, K0, A1, K1, W, Y0, NO0, Y1, P,
-                               FwdSide{});
+                               FwdSide{}, ld);
             return;
         }
     }
     if (nt <= 1)
-        hipLaunchKernelGGL((rowgemm_kernel<1, false>), grid, block, 0, st, A0, K0, A1, K1, W, NO, Y0, NO0, Y1, P, FwdSide{});
+        hipLaunchKernelGGL((rowgemm_kernel<1, false>), grid, block, 0, st, A0, K0, A1, K1, W, NO, Y0, NO0, Y1, P, FwdSide{}, ld);
     else if (nt == 2)
-        hipLaunchKernelGGL((rowgemm_kernel<2, false>), grid, block, 0, st, A0, K0, A1, K1, W, NO, Y0, NO0, Y1, P, FwdSide{});
+        hipLaunchKernelGGL((rowgemm_kernel<2, false>), grid, block, 0, st, A0, K0, A1, K1, W, NO, Y0, NO0, Y1, P, FwdSide{}, ld);
     else
-        hipLaunchKernelGGL((rowgemm_kernel<4, false>), grid, block, 0, st, A0, K0, A1, K1, W, NO, Y0, NO0, Y1, P, FwdSide{});
+        hipLaunchKernelGGL((rowgemm_kernel<4, false>), grid, block, 0, st, A0, K0, A1, K1, W, NO, Y0, NO0, Y1, P, FwdSide{}, ld);
 }
 
 // wgrad_kernel for M0 = M1 = 64, C = 64 (the 64-channel blocks): a workgroup of FOUR waves takes 256 points, wave w
@@ -548,7 +581,7 @@ void launch_rowgemm(const float *A0, int K0, const float *A1, int K1, const floa
 // product reads -- and finish_dw1_kernel read them back: 27 + 11 us.)
 constexpr int WGRAD_FAST_POINTS = 256;
 __global__ __launch_bounds__(256) void wgrad_fast64_kernel(const float *__restrict__ A0, const float *__restrict__ A1,
-                                                           const float *__restrict__ X, int P, float *__restrict__ partial)
+                                                           const float *__restrict__ X, int ldx, int P, float *__restrict__ partial)
 {
     constexpr int UN = 4, DEPTH = 4;  // point pairs per step; steps in the register ring (three steps of 8 MFMAs ahead: 22 us;
                                       // a ring of two steps of 16 measured 32 - 38 us)
@@ -568,7 +601,8 @@ __global__ __launch_bounds__(256) void wgrad_fast64_kernel(const float *__restri
             const int pp = p + 2 * u + h;
             const bool pv = pp < pend;
             const size_t ro = (size_t)(pv ? pp : pbeg) * 64 + i32;  // clamped row: unconditional loads, masked values
-            const float a0 = A[ro], b0 = X[ro], b1 = X[ro + 32];
+            const size_t rx = (size_t)(pv ? pp : pbeg) * (size_t)ldx + i32;
+            const float a0 = A[ro], b0 = X[rx], b1 = X[rx + 32];
             fa[u] = pv ? a0 : 0.0f;
             fb[u][0] = pv ? b0 : 0.0f;
             fb[u][1] = pv ? b1 : 0.0f;
@@ -603,7 +637,7 @@ __global__ __launch_bounds__(256) void wgrad_fast64_kernel(const float *__restri
 // both operands are split in two fp16 halves (edge_mlp16.h) and four steps of three v_mfma_f32_32x32x16_f16 per tile go
 // to a chunk accumulator, which joins the total with 1 / (sA sB): 96 matrix instructions of 32 cycles per wave.
 __global__ __launch_bounds__(256) void wgrad_split64_kernel(const float *__restrict__ A0, const float *__restrict__ A1,
-                                                            const float *__restrict__ X, int P, float *__restrict__ partial)
+                                                            const float *__restrict__ X, int ldx, int P, float *__restrict__ partial)
 {
     const int lane = threadIdx.x & 63, mt = threadIdx.x >> 6, h = lane >> 5, i32 = lane & 31;
     const int pbeg = blockIdx.x * WGRAD_FAST_POINTS;
@@ -622,7 +656,8 @@ __global__ __launch_bounds__(256) void wgrad_split64_kernel(const float *__restr
             const int pp = p0 + 16 * (q >> 3) + 8 * h + (q & 7);
             const bool pv = pp < pend;
             const size_t ro = (size_t)(pv ? pp : pbeg) * 64 + i32;  // clamped row: unconditional loads, masked values
-            const float a0 = A[ro], b0 = X[ro], b1 = X[ro + 32];
+            const size_t rx = (size_t)(pv ? pp : pbeg) * (size_t)ldx + i32;
+            const float a0 = A[ro], b0 = X[rx], b1 = X[rx + 32];
             av[q] = pv ? a0 : 0.0f;
             bv[0][q] = pv ? b0 : 0.0f;
             bv[1][q] = pv ? b1 : 0.0f;
@@ -679,18 +714,19 @@ static bool wgrad_force_f32()  // experiments / tests: the fp32-MFMA form of the
 int wgrad_chunks(int P, int C) { return ceil_div(P, C == 64 ? WGRAD_FAST_POINTS : WGRAD_CHUNK); }
 
 void launch_wgrad(const float *A0, int M0, const float *A1, int M1, const float *X, int C, int P, float *partial,
-                  hipStream_t st)
+                  hipStream_t st, int ldx)
 {
     // (M0 = M1 = 64 always: the stage widths of the model; C = 64 takes the four-wave kernel)
     const dim3 grid(wgrad_chunks(P, C)), block(64);
+    if (ldx <= 0) ldx = C;
     if (C == 64) {
-        if (wgrad_force_f32()) hipLaunchKernelGGL(wgrad_fast64_kernel, grid, dim3(256), 0, st, A0, A1, X, P, partial);
-        else hipLaunchKernelGGL(wgrad_split64_kernel, grid, dim3(256), 0, st, A0, A1, X, P, partial);
+        if (wgrad_force_f32()) hipLaunchKernelGGL(wgrad_fast64_kernel, grid, dim3(256), 0, st, A0, A1, X, ldx, P, partial);
+        else hipLaunchKernelGGL(wgrad_split64_kernel, grid, dim3(256), 0, st, A0, A1, X, ldx, P, partial);
         return;
     }
     const int mt = ceil_div(M0 + M1, 32), nt = ceil_div(C, 32);
 #define DG_WG(MT_, NT_) \
-    hipLaunchKernelGGL((wgrad_kernel<MT_, NT_>), grid, block, 0, st, A0, M0, A1, M1, X, C, P, partial)
+    hipLaunchKernelGGL((wgrad_kernel<MT_, NT_>), grid, block, 0, st, A0, M0, A1, M1, X, ldx, C, P, partial)
     // C <= 64 is enforced by the callers (NT <= 2)
     if (mt <= 2) {
         if (nt <= 1) DG_WG(2, 1);
@@ -700,6 +736,24 @@ void launch_wgrad(const float *A0, int M0, const float *A1, int M1, const float 
         else DG_WG(4, 2);
     }
 #undef DG_WG
+}
+
+// the input gradient of a block's first convolution, gx = [dR | dD] . Wcat (launch_rowgemm), and the fold of its weight
+// gradient (launch_finish_dw1) in ONE launch where the shapes allow (the 64-channel blocks): the fold's 128 workgroups ride
+// behind the product's
+void launch_dgrad_and_dw1(const float *dR, const float *dD, const float *wcat, int C, float *gx, int ldgx, int gx_acc, int P,
+                          const float *partial, int nchunk, float *gw1, hipStream_t st)
+{
+    if (C == 64 && !rowgemm_force_f32()) {
+        const int main_blocks = ceil_div(ceil_div(P, 32), 4);
+        const Dw1Rider rd{partial, nchunk, C, gw1, main_blocks};
+        const RowLd ld{EC, ldgx > 0 ? ldgx : C, gx_acc};
+        hipLaunchKernelGGL((rowgemm_split_kernel<64, 2, false>), dim3(main_blocks + ceil_div(EC * 2 * C, 64)), dim3(256), 0, st, dR, EC,
+                           dD, EC, wcat, gx, C, nullptr, P, FwdSide{}, ld, rd);
+        return;
+    }
+    launch_finish_dw1(partial, nchunk, C, gw1, st);
+    launch_rowgemm(dR, EC, dD, EC, wcat, C, gx, C, nullptr, P, st, ldgx, gx_acc);
 }
 
 void launch_finish_dw1(const float *partial, int nchunk, int C, float *gw1, hipStream_t st)

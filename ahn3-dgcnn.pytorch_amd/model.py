@@ -17,6 +17,8 @@ Deliberate differences from the reference:
   --  neighbour ties are broken by the lower index (the reference's topk order among equal
       distances is arbitrary), distances follow the fixed fp32 order of oracle/knn_exact.c.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -118,10 +120,31 @@ class DGCNN(nn.Module):
         with ops.batch_counters():  # the eight `num_batches_tracked += 1` as one multi-tensor add
             return self._forward(x, depth, idx, return_idx)
 
+    def _full_path(self, xd, depth):
+        """depth 10 on a supported shape: the whole network as ONE forward and ONE backward call behind the C ABI
+        (ops.dgcnn_full -> dgcnn_model_fwd / _bwd); otherwise the per-layer operators below (the same kernels)"""
+        if depth != 10 or xd.requires_grad or os.environ.get("DGCNN_PER_LAYER"):
+            return False
+        B, F_, N = xd.shape
+        w6, w7, w8 = (getattr(self, "conv%d" % i)[0].weight for i in (6, 7, 8))
+        w9 = self.conv9.weight
+        if w7.shape[1] != w6.shape[0] + 192 or w8.shape[1] != w7.shape[0] or w9.shape[1] != w8.shape[0]:
+            return False
+        bns = [getattr(self, "bn%d" % i) for i in range(1, 9)]
+        return (ops.model_full_supported(B, F_, N, self.k, w6.shape[0], w7.shape[0], w8.shape[0], w9.shape[0])
+                and ops.model_full_ready(bns, self.training) and all(p.is_cuda for p in self.parameters()))
+
     def _forward(self, x, depth, idx, return_idx):
         in_dev = x.device
         xd = _to_device(x)
         B, _, N = xd.shape
+        if self._full_path(xd, depth):
+            convs = [getattr(self, "conv%d" % i)[0].weight for i in range(1, 9)] + [self.conv9.weight]
+            bns = [getattr(self, "bn%d" % i) for i in range(1, 9)]
+            out, used = ops.dgcnn_full(xd, convs, bns, self.k, self.training, NEG_SLOPE, self.dp1.p, idx)
+            if out.device != in_dev:
+                out = out.to(in_dev)
+            return (out, used) if return_idx else out
         feats, used = [], []
         cur = ops.to_point_major_autograd(xd)                         # [B, N, F]
         out = None

@@ -804,6 +804,131 @@ def dropout_mask(seed, P, K, p_drop, device):
 
 
 # ------------------------------------------------------------------------------------------------
+# The whole network at depth 10 as one forward and one backward call (dgcnn_model_fwd / _bwd, model.hip)
+def _model_desc(mods, B, N, F_, k, training, slope, p_drop, seed, idx, idx_given, params, counters=True):
+    """params: the 25 tensors in the order conv1..conv9 weights, bn1..bn8 weights, bn1..bn8 biases (detached, contiguous)"""
+    d = _lib.ModelDesc()
+    d.B, d.N, d.F, d.k = B, N, F_, k
+    w = params[:9]
+    d.num_classes, d.emb, d.c7, d.c8 = w[8].shape[0], w[5].shape[0], w[6].shape[0], w[7].shape[0]
+    d.training, d.idx_given = (1 if training else 0), (1 if idx_given else 0)
+    d.slope, d.p_drop, d.seed = slope, p_drop, seed
+    for i in range(9):
+        d.w[i] = w[i].data_ptr()
+    for i, bn in enumerate(mods):
+        nbt = bn.num_batches_tracked if (counters and training) else None
+        d.bn[i] = _bn_struct(params[9 + i], params[17 + i], bn.running_mean, bn.running_var, nbt)
+        d.eps[i] = float(bn.eps)
+        d.momentum[i] = float(bn.momentum if bn.momentum is not None else 0.1)
+    for b in range(3):
+        d.idx[b] = idx[b].data_ptr()
+    return d
+
+
+class _DGCNNFull(torch.autograd.Function):
+    """DGCNN.forward(x, depth=10) (model.py:144-193) through dgcnn_model_fwd / dgcnn_model_bwd: one C-ABI call each way.
+    x gets no gradient (the reference's loops never ask for one)."""
+
+    @staticmethod
+    def forward(ctx, x, mods, k, training, slope, p_drop, seed, idx, idx_given, *params):
+        # idx: three int32 [B, N, k] tensors on the device -- the graphs to use (idx_given) or the buffers the forward fills
+        B, F_, N = x.shape
+        lib = _lib.load()
+        dev = x.device
+        pd = [p.detach().contiguous() for p in params]
+        pd = [t.reshape(t.shape[0], -1) if t.dim() > 1 else t for t in pd]
+        d = _model_desc(mods, B, N, F_, k, training, slope, p_drop, seed, idx, idx_given, pd)
+        nc = pd[8].shape[0]
+        logits = torch.empty((B, nc, N), dtype=torch.float32, device=dev)
+        nsaved = lib.dgcnn_model_saved_bytes(d)
+        ws_bytes = lib.dgcnn_model_fwd_workspace_bytes(d)
+        if nsaved == 0 or ws_bytes == 0:
+            _lib.check(1, "dgcnn_model_fwd (shape)")
+        saved = torch.empty((nsaved,), dtype=torch.uint8, device=dev)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        _lib.check(lib.dgcnn_model_fwd(d, _lib.ptr(x), x.stride(0), x.stride(1), x.stride(2), _lib.ptr(logits), logits.stride(0),
+                                       logits.stride(1), logits.stride(2), _lib.ptr(saved), _lib.ptr(ws), ws_bytes,
+                                       _lib.stream_ptr(dev)), "dgcnn_model_fwd")
+        ctx.save_for_backward(x, saved, *idx, *pd)
+        ctx.cfg = (mods, k, training, slope, p_drop, seed, [tuple(p.shape) for p in params])
+        ctx.sinks = tuple((p, getattr(p, "_dgcnn_grad_sink", None)) for p in params)
+        return logits
+
+    @staticmethod
+    def backward(ctx, gl):
+        x, saved, i0, i1, i2, *pd = ctx.saved_tensors
+        mods, k, training, slope, p_drop, seed, shapes = ctx.cfg
+        B, F_, N = x.shape
+        lib = _lib.load()
+        dev = x.device
+        if gl.dtype != torch.float32:
+            gl = gl.float()
+        d = _model_desc(mods, B, N, F_, k, training, slope, p_drop, seed, (i0, i1, i2), True, pd, counters=False)
+        outs = []
+        for (owner, sink), ref in zip(ctx.sinks, pd):
+            # a parameter's slice of the flat exchange buffer, if its owner has named one and nothing has claimed it in this
+            # cycle (see _EdgeConv.backward)
+            if (sink is not None and owner.grad is None and not getattr(owner, "_dgcnn_sink_claimed", False) and owner.requires_grad
+                    and sink.numel() == ref.numel() and sink.dtype == ref.dtype and sink.device == ref.device and sink.is_contiguous()):
+                owner._dgcnn_sink_claimed = True
+                outs.append(sink.detach().view(ref.shape))
+            else:
+                outs.append(torch.empty_like(ref))
+        g = _lib.ModelGrads()
+        for i in range(9):
+            g.gw[i] = outs[i].data_ptr()
+        for i in range(8):
+            g.gbn_w[i] = outs[9 + i].data_ptr()
+            g.gbn_b[i] = outs[17 + i].data_ptr()
+        ws_bytes = lib.dgcnn_model_bwd_workspace_bytes(d)
+        if ws_bytes == 0:
+            _lib.check(1, "dgcnn_model_bwd (shape)")
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        _lib.check(lib.dgcnn_model_bwd(d, _lib.ptr(x), x.stride(0), x.stride(1), x.stride(2), _lib.ptr(gl), gl.stride(0), gl.stride(1),
+                                       gl.stride(2), _lib.ptr(saved), ctypes.byref(g), _lib.ptr(ws), ws_bytes, _lib.stream_ptr(dev)),
+                   "dgcnn_model_bwd")
+        return (None,) * 9 + tuple(o.view(sh) for o, sh in zip(outs, shapes))
+
+
+def model_full_supported(B, F_, N, k, emb, c7, c8, nc):
+    """shapes dgcnn_model_fwd / _bwd take (include/dgcnn_hip.h); others go through the per-layer operators"""
+    return (1 <= B <= 64 and N >= 128 and 1 <= F_ <= 64 and 1 <= k <= min(64, N) and B * N < (1 << 23) and emb % 32 == 0
+            and 32 <= emb <= 8192 and c7 % 32 == 0 and c8 % 32 == 0 and 32 <= c7 <= 1024 and 32 <= c8 <= 1024 and 1 <= nc <= 8
+            and N <= 40000)
+
+
+def dgcnn_full(x, convs, bns, k, training, slope, p_drop, idx=None):
+    """(logits [B, classes, N], the three neighbour graphs used) of the whole network at depth 10.
+    x [B, F, N] float32 on the HIP device (any strides); convs: the nine convolution weights (conv1 .. conv9), bns: the eight
+    BatchNorm modules (running statistics and counters updated in place when training); idx: optional list of three int
+    [B, N, k] graphs to use instead of searching."""
+    _lib.require_device(x, "x")
+    B, _, N = x.shape
+    dev = x.device
+    drop = float(p_drop) if training else 0.0
+    seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64)) if drop > 0.0 else 0
+    params = list(convs) + [bn.weight for bn in bns] + [bn.bias for bn in bns]
+    if idx is not None:
+        graphs = [t.to(device=dev, dtype=torch.int32).contiguous() for t in idx]
+    else:
+        # ONE array for the three graphs: the backward then builds their reverse lists in one go (dgcnn_model_bwd)
+        graphs = list(torch.empty((3, B, N, int(k)), dtype=torch.int32, device=dev).unbind(0))
+    y = _DGCNNFull.apply(x, tuple(bns), int(k), bool(training), float(slope), drop, seed, graphs, idx is not None, *params)
+    return y, graphs
+
+
+def model_full_ready(bns, training):
+    """the module state dgcnn_full needs: running statistics present, counters int64 on the device"""
+    for bn in bns:
+        if bn.running_mean is None or bn.running_var is None or not bn.running_mean.is_cuda:
+            return False
+        t = bn.num_batches_tracked
+        if training and (t is None or not t.is_cuda or t.dtype != torch.int64):
+            return False
+    return True
+
+
+# ------------------------------------------------------------------------------------------------
 class _ToPointMajor(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

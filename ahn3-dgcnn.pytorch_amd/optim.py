@@ -64,6 +64,11 @@ class FlatAdam(torch.optim.Optimizer):
                 self.flat[off:off + n].copy_(p.reshape(-1))
                 p.data = self.flat[off:off + n].view_as(p)       # the module now computes on views of the flat buffer
                 self._grad_views.append(self.grad[off:off + n].view_as(p))
+                # the backward passes of ops write a parameter's gradient straight into this slice when they find it
+                # (ops._EdgeConv, ops._DGCNNFull): `_pack_grads` then has nothing to copy.  A sink a
+                # parallel.FlatGradAllReduce has named (the shared exchange buffer) stays.
+                if getattr(p, "_dgcnn_grad_sink", None) is None:
+                    p._dgcnn_grad_sink = self._grad_views[-1]
                 self._offsets.append(off)
                 off += n
         self._steps = [0] * len(uniq)   # torch.optim.Adam counts the steps per parameter (a skipped one lags)
@@ -74,6 +79,8 @@ class FlatAdam(torch.optim.Optimizer):
         gradient without an accumulation kernel (25 tiny launches per step otherwise); `step` packs them into the
         flat buffer with one multi-tensor copy.  set_to_none=False: the .grad tensors become (zeroed) views of the flat
         buffer and backward accumulates in place -- what a shared parallel.FlatGradAllReduce buffer expects."""
+        for p in self.params:
+            p._dgcnn_sink_claimed = False   # a new cycle: each sink may be handed out once again
         if set_to_none:
             for p in self.params:
                 p.grad = None
@@ -87,6 +94,7 @@ class FlatAdam(torch.optim.Optimizer):
         slices of the flat buffer with one multi-tensor copy"""
         src, dst, has = [], [], []
         for p, v in zip(self.params, self._grad_views):
+            p._dgcnn_sink_claimed = False
             has.append(p.grad is not None)
             if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
                 src.append(p.grad)

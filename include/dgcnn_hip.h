@@ -310,6 +310,55 @@ int dgcnn_head_tail_bwd(const dgcnn_head_tail_desc *d, const float *cat, const u
  * dgcnn_head_tail_* (tests; a caller that wants the mask of a step). */
 int dgcnn_dropout_mask(uint64_t seed, int P, int K, float p_drop, uint8_t *mask, void *stream);
 
+/* ---- the whole network as one forward and one backward call (DGCNN.forward at depth 10, model.py:144-193) -------------
+ * What a caller of the reference's training / inference loops needs per step: three kNN builds, three EdgeConv blocks,
+ * conv6 -> bn6 -> max over the points, the pooled feature's share of conv7, and the head's tail, enqueued by ONE call each
+ * way on the caller's stream.  Compared with calling the per-layer entry points from the host language this removes every
+ * framework op between them: the blocks write x1 | x2 | x3 into ONE [P][192] buffer and read their inputs from its column
+ * slices (no torch.cat, model.py:167), the gradients that meet in x1 / x2 / x3 (block b + 1's edge features, the cat of :167
+ * and the cat of :180) are accumulated where they are produced, the pooled-feature product W7[:, :emb] . g_b (model.py:179)
+ * and its three backward products are kernels of this library, and the eight `num_batches_tracked` counters are bumped by
+ * kernels that run anyway.  Results are those of the per-layer entry points (the same kernels run).
+ *
+ * w[i] = conv(i+1).weight: [64][2F], [64][64], [64][128], [64][64], [64][128], [emb][192], [c7][emb + 192], [c8][c7],
+ * [num_classes][c8], all dense.  bn[i] = bn(i+1) (64 x5, emb, c7, c8 channels); eps / momentum per BatchNorm (the two of a
+ * block share eps[first], momentum[first]).  idx[b]: int32 [B][N][k] of block b + 1 -- written by the forward (idx_given = 0)
+ * or supplied by the caller (idx_given = 1: the test hook that separates kNN parity from edge-MLP parity); the backward
+ * reads the same three arrays.  x: [B][F][N] by element strides; logits / glogits: [B][num_classes][N] by element strides.
+ * Limits: F <= 64, k <= 64, N >= 128, emb a multiple of 32, c7, c8 multiples of 32 (<= 1024), 1 <= num_classes <= 8,
+ * B <= 64, B N < 2^23 (dgcnn_model_*_bytes return 0 and dgcnn_last_error says which).  The network input gets no gradient. */
+typedef struct dgcnn_model_desc {
+    int32_t B, N, F, k;
+    int32_t num_classes, emb, c7, c8;
+    int32_t training;   /* 1: batch statistics (+ running update, counters) and dropout; 0: running statistics */
+    int32_t idx_given;
+    float slope, p_drop;
+    uint64_t seed;      /* of the dropout mask of this step (dgcnn_dropout_mask) */
+    const float *w[9];
+    dgcnn_bn_params bn[8];
+    float eps[8], momentum[8];
+    int32_t *idx[3];
+} dgcnn_model_desc;
+
+typedef struct dgcnn_model_grads {
+    float *gw[9];       /* shapes of w[] */
+    float *gbn_w[8];
+    float *gbn_b[8];
+} dgcnn_model_grads;
+
+size_t dgcnn_model_saved_bytes(const dgcnn_model_desc *d);
+size_t dgcnn_model_fwd_workspace_bytes(const dgcnn_model_desc *d);
+size_t dgcnn_model_bwd_workspace_bytes(const dgcnn_model_desc *d);
+int dgcnn_model_fwd(const dgcnn_model_desc *d, const float *x, int64_t x_sb, int64_t x_sc, int64_t x_sn, float *logits,
+                    int64_t l_sb, int64_t l_sc, int64_t l_sn, void *saved, void *workspace, size_t workspace_bytes,
+                    void *stream);
+/* x: the forward's input again (read in place when its strides are those of point-major memory -- (N F, 1, F), the permuted
+ * view train.py:176 hands over -- otherwise the forward's own copy in `saved` is used).  Every gradient is OVERWRITTEN;
+ * deterministic as dgcnn_edgeconv_bwd is. */
+int dgcnn_model_bwd(const dgcnn_model_desc *d, const float *x, int64_t x_sb, int64_t x_sc, int64_t x_sn, const float *glogits,
+                    int64_t g_sb, int64_t g_sc, int64_t g_sn, const void *saved, const dgcnn_model_grads *g, void *workspace,
+                    size_t workspace_bytes, void *stream);
+
 /* ---- the steps either side of DGCNN.forward in the reference's loops ("next") -------
  * Logits are addressed by element strides, (b, c, n) at b*stride_b + c*stride_c + n*stride_n, so both the
  * [B, classes, N] tensor DGCNN.forward returns and a point-major [B, N, classes] buffer are read in place.

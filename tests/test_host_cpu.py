@@ -161,3 +161,33 @@ def test_rccl_binding_behind_the_c_abi_loads_without_a_gpu():
     assert lib.dgcnn_comm_unique_id(buf) == 0
     assert any(b != 0 for b in buf.raw)
     assert lib.dgcnn_comm_allreduce_f32(None, None, 0, 0, None) != 0 and b"null" in lib.dgcnn_last_error()
+
+
+def test_model_structs_match_the_header(tmp_path):
+    """dgcnn_model_desc / dgcnn_model_grads (arrays of pointers, nested BatchNorm structs): sizes and member offsets as the
+    C compiler lays out include/dgcnn_hip.h against the ctypes mirrors; and the shape limits are reported by the queries"""
+    import subprocess
+    from ahn3_dgcnn_pytorch_amd import _lib
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "dgcnn_hip.h"\nint main(void) {\n'
+                   '  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(dgcnn_model_desc), offsetof(dgcnn_model_desc, slope), '
+                   'offsetof(dgcnn_model_desc, seed), offsetof(dgcnn_model_desc, w), offsetof(dgcnn_model_desc, bn), '
+                   'offsetof(dgcnn_model_desc, eps), offsetof(dgcnn_model_desc, momentum), offsetof(dgcnn_model_desc, idx), '
+                   'sizeof(dgcnn_model_grads));\n  return 0;\n}\n')
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    D = _lib.ModelDesc
+    want = [ctypes.sizeof(D), D.slope.offset, D.seed.offset, D.w.offset, D.bn.offset, D.eps.offset, D.momentum.offset, D.idx.offset,
+            ctypes.sizeof(_lib.ModelGrads)]
+    assert got == want
+    lib = _lib.load()
+    d = _lib.ModelDesc()
+    d.B, d.N, d.F, d.k, d.num_classes, d.emb, d.c7, d.c8, d.training = 8, 7000, 4, 30, 5, 1024, 512, 256, 1
+    assert lib.dgcnn_model_saved_bytes(d) > 56000 * 192 * 4 and lib.dgcnn_model_fwd_workspace_bytes(d) > 0
+    assert lib.dgcnn_model_bwd_workspace_bytes(d) > 56000 * 30 * 64 * 4
+    d.k = 65
+    assert lib.dgcnn_model_saved_bytes(d) == 0 and b"k=65" in lib.dgcnn_last_error()
+    d.k, d.N = 30, 40001
+    assert lib.dgcnn_model_fwd_workspace_bytes(d) > 0 and lib.dgcnn_model_bwd_workspace_bytes(d) == 0
+    assert b"40000" in lib.dgcnn_last_error()
