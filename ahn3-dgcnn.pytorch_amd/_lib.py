@@ -136,7 +136,7 @@ SIGNATURES = {
     "dgcnn_model_bwd_workspace_bytes": (_c_sz, [_c_md_p]),
     "dgcnn_model_fwd": (_c_int, [_c_md_p, _c_vp, _c_i64, _c_i64, _c_i64, _c_vp, _c_i64, _c_i64, _c_i64, _c_vp, _c_vp, _c_sz, _c_vp]),
     "dgcnn_model_bwd": (_c_int, [_c_md_p, _c_vp, _c_i64, _c_i64, _c_i64, _c_vp, _c_i64, _c_i64, _c_i64, _c_vp,
-                                 ctypes.POINTER(ModelGrads), _c_vp, _c_sz, _c_vp]),
+                                 ctypes.POINTER(ModelGrads), _c_vp, _c_sz, _c_int, _c_vp]),
     "dgcnn_comm_rccl_version": (_c_int, []),
     "dgcnn_comm_unique_id": (_c_int, [_c_vp]),
     "dgcnn_comm_init": (_c_int, [ctypes.POINTER(_c_vp), _c_vp, _c_int, _c_int]),
@@ -148,6 +148,8 @@ SIGNATURES = {
     "dgcnn_seg_loss_workspace_bytes": (_c_sz, [_c_int, _c_int]),
     "dgcnn_seg_loss": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_i64, _c_i64, _c_i64, _c_vp, _c_vp, _c_f, _c_vp, _c_vp,
                                 _c_vp, _c_vp, _c_sz, _c_vp]),
+    "dgcnn_seg_loss_labels": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_i64, _c_i64, _c_i64, _c_vp, _c_int, _c_vp, _c_f, _c_vp, _c_vp,
+                                       _c_vp, _c_vp, _c_sz, _c_vp]),
     "dgcnn_seg_predict": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_i64, _c_i64, _c_i64, _c_f, _c_int, _c_vp, _c_vp, _c_vp]),
     "dgcnn_adam_step": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_sz, _c_f, _c_f, _c_f, _c_f, _c_f, _c_int, _c_vp]),
     "dgcnn_cast_f64_f32": (_c_int, [_c_vp, _c_sz, _c_vp]),

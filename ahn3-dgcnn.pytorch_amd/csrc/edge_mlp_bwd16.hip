@@ -27,9 +27,10 @@ namespace dgcnn {
 // half h, element j  <->  edge row mfma32_row(8 s + j, h) = 16 s + 8 (j >> 2) + 4 h + (j & 3) -- so that du2, which the
 // u2 product leaves in accumulator registers (lane = channel, registers = edge rows), is the A operand of the weight
 // gradient as it stands, and the other operand is two 8-byte row reads of the a1' image (edges 16 s + 8 u + 4 h .. + 3).
-// LDG: row stride (floats) of gy and y -- 64 (dense rows) or 192 (64-column slices of the model's [P][192] concatenation); a
-// template parameter because the kernel sits at its register limit (two more scalar arguments cost 16 bytes of scratch)
-template <bool S01, int LDG>
+// LDG, LDY: row strides (floats) of gy and y -- 64 (dense rows) or 192 (64-column slices of the model's [P][192]
+// concatenation); template parameters because the kernel sits at its register limit (two more scalar arguments cost 16
+// bytes of scratch)
+template <bool S01, int LDG, int LDY>
 __global__ __launch_bounds__(512) void edge_mlp_bwd16_kernel(
     const float *__restrict__ TP, const float *__restrict__ TQ, const int32_t *__restrict__ idx, int N, int k, int P,
     const float *__restrict__ stats1, const float *__restrict__ stats2, const float *__restrict__ cc2,
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(512) void edge_mlp_bwd16_kernel(
         for (int nt = 0; nt < 2; ++nt) {
             hit[nt] = (int)hit2[(size_t)pt * EC + nt * 32 + i32] - 4 * h;  // relative to this lane half's rows
             dvs[nt] = sD * sc2[nt] * gy[(size_t)pt * LDG + nt * 32 + i32] *
-                      (y[(size_t)pt * LDG + nt * 32 + i32] > 0.0f ? 1.0f : slope);
+                      (y[(size_t)pt * LDY + nt * 32 + i32] > 0.0f ? 1.0f : slope);
         }
         for (int j0 = 0; j0 < k; j0 += 32) {
             const int kk = k - j0 < 32 ? k - j0 : 32;
@@ -348,18 +349,21 @@ int launch_edge_mlp_bwd16(const float *TP, const float *TQ, const int32_t *idx, 
                           float *dv1, float *dvsum, float *partial_dw2, const FoldSet &fs, const BnBackwardSums &fin1, int *guard,
                           int grid, hipStream_t st)
 {
-    DG_REQUIRE(ldgy == ldy && (ldgy == 64 || ldgy == 192), "edge_mlp_bwd16: row strides of gy / y must both be 64 or 192 (got %d, %d)",
-               ldgy, ldy);
+    DG_REQUIRE((ldgy == 64 || ldgy == 192) && (ldy == 64 || ldy == 192) && !(ldgy == 192 && ldy == 64),
+               "edge_mlp_bwd16: row strides of (gy, y) must be (64, 64), (64, 192) or (192, 192) (got %d, %d)", ldgy, ldy);
     const bool s01 = slope >= 0.0f && slope <= 1.0f;
-#define DG_BWD16(S01_, LD_)                                                                                                      \
-    hipLaunchKernelGGL((edge_mlp_bwd16_kernel<S01_, LD_>), dim3(grid), dim3(64 * MLP_BWD_WAVES), 0, st, TP, TQ, idx, N, k, P, stats1, \
+#define DG_BWD16(S01_, LDG_, LDY_)                                                                                                     \
+    hipLaunchKernelGGL((edge_mlp_bwd16_kernel<S01_, LDG_, LDY_>), dim3(grid), dim3(64 * MLP_BWD_WAVES), 0, st, TP, TQ, idx, N, k, P, stats1, \
                        stats2, cc2, w2, slope, training, gy, y, hit2, gmax_bits, dv1, dvsum, partial_dw2, fs, fin1, guard)
-    if (ldgy == 64) {
-        if (s01) DG_BWD16(true, 64);
-        else DG_BWD16(false, 64);
+    if (ldy == 64) {
+        if (s01) DG_BWD16(true, 64, 64);
+        else DG_BWD16(false, 64, 64);
+    } else if (ldgy == 64) {
+        if (s01) DG_BWD16(true, 64, 192);
+        else DG_BWD16(false, 64, 192);
     } else {
-        if (s01) DG_BWD16(true, 192);
-        else DG_BWD16(false, 192);
+        if (s01) DG_BWD16(true, 192, 192);
+        else DG_BWD16(false, 192, 192);
     }
 #undef DG_BWD16
     return 0;

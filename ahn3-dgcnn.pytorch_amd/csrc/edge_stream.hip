@@ -258,7 +258,11 @@ __device__ __forceinline__ void rev_slots_pass(const RevSlotsArgs &a, int block)
 // carries gradient through max-over-k, so  sum dv  and  sum dv * uhat  over all edges reduce to
 // sums over points of quantities at the selected extreme.  The pass finishes
 // the sums itself (fold.h): gbn_b, gbn_w and the two mean terms cc.
-__global__ __launch_bounds__(256) void bwd_point_kernel(const float *__restrict__ gy, int ldgy, const float *__restrict__ usel,
+// gy2 != NULL: dL/dy = gy + gy2 (gy2 dense [P][64]: the second gradient that reaches the block's output -- the next block's
+// input gradient); the sum is left in gysum [P][64] for the kernels behind this one (one extra stream here instead of a
+// read-modify-write of the strided slice in the product that makes gy2: 8 -> 22 us there at P = 28 000).
+__global__ __launch_bounds__(256) void bwd_point_kernel(const float *__restrict__ gy, int ldgy, const float *__restrict__ gy2,
+                                                        float *__restrict__ gysum, const float *__restrict__ usel,
                                                         const float *__restrict__ stats, float slope, int P,
                                                         FoldSet fs, BnBackwardSums fin, unsigned *__restrict__ gmax_bits,
                                                         int nbp, RevSlotsArgs slots)
@@ -285,10 +289,12 @@ __global__ __launch_bounds__(256) void bwd_point_kernel(const float *__restrict_
             const int p = pt + u * stride < P ? pt + u * stride : pt;  // clamped: the load is unconditional, the value masked
             us[u] = usel[(size_t)p * EC + lane];
             g4[u] = gy[(size_t)p * ldgy + lane];
+            if (gy2) g4[u] += gy2[(size_t)p * EC + lane];
         }
 #pragma unroll
         for (int u = 0; u < INF; ++u) {
             if (pt + u * stride < P) {  // (uniform; added in point order)
+                if (gy2) gysum[(size_t)(pt + u * stride) * EC + lane] = g4[u];
                 const float v = __builtin_fmaf(us[u], sc, sh);
                 const float dv = g4[u] * (v > 0.0f ? 1.0f : slope);
                 const float uhat = (us[u] - mean) * rstd;
@@ -592,16 +598,42 @@ __global__ __launch_bounds__(256) void edge_point_bwd_kernel(const float *__rest
                                                              const uint8_t *__restrict__ hitj,
                                                              const float *__restrict__ usum,
                                                              const float *__restrict__ dv, HitRec *__restrict__ hits,
-                                                             float *__restrict__ G, float *__restrict__ dD)
+                                                             float *__restrict__ G, float *__restrict__ dD, const SumRider sr)
 {
     __shared__ u64 smask[EDGE_WAVES][128];  // by slot (k <= 96)
     __shared__ float sval[EDGE_WAVES][128][HIT_REC];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // workgroups sr.main_blocks .. (two-stage blocks): the fold of the second convolution's weight-gradient partials
+    // (out[e] = sum over the chunks, in chunk order), which nothing in this call reads: it rides here instead of in a launch
+    // of its own.  Four waves take consecutive shares of the chunks, eight in flight; the four sums are added in wave order.
+    if (DENSE && sr.out && (int)blockIdx.x >= sr.main_blocks) {
+        float *red = reinterpret_cast<float *>(&sval[0][0][0]);  // [4][64]
+        const int e = ((int)blockIdx.x - sr.main_blocks) * 64 + lane;
+        const int q = (sr.nchunk + EDGE_WAVES - 1) / EDGE_WAVES;
+        const int c0 = wave * q, c1 = c0 + q < sr.nchunk ? c0 + q : sr.nchunk;
+        float s = 0.0f;
+        if (e < sr.n) {
+            int ch = c0;
+            for (; ch + 8 <= c1; ch += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = sr.partial[(size_t)(ch + u) * sr.n + e];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s += v[u];
+            }
+            for (; ch < c1; ++ch) s += sr.partial[(size_t)ch * sr.n + e];
+        }
+        red[wave * 64 + lane] = s;
+        __syncthreads();
+        if (wave == 0 && e < sr.n) sr.out[e] = (red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane]);
+        return;
+    }
     const float mean = stats[ST_MEAN + lane], rstd = stats[ST_RSTD + lane], sc = stats[ST_SC + lane];
     const float c1 = cc[lane], c2 = cc[64 + lane];
     const float alpha = sc * c2 * rstd;
     u64 *sm = smask[wave];
-    const PointIter it = point_iter(P, wave, EDGE_WAVES);
+    // (the launch may carry the fold's workgroups behind this pass's: the split over the POINT workgroups only)
+    const PointIter it = point_iter_at(P, wave, EDGE_WAVES, (int)blockIdx.x, DENSE && sr.out ? sr.main_blocks : (int)gridDim.x);
     for (int pt = it.cur; pt < it.end; pt += it.step) {
         const size_t o = (size_t)pt * EC + lane;
         const float q = TQ[o];
@@ -903,7 +935,7 @@ int launch_edge_bwd(const float *TP, const float *TQ, int B, int N, int k, const
                     const float *gy, const float *y, const uint8_t *hitj, const float *usum, const float *dv,
                     const float *dvsum, const int *rowptr, const int *indeg, const int *segbase, int *pcnt,
                     const int32_t *rev, const int *alloc, const int *extra, void *hits, float *G, float *part0,
-                    float *partx, float *dR, float *dD, hipStream_t st, int ldgy, int ldy)
+                    float *partx, float *dR, float *dD, hipStream_t st, int ldgy, int ldy, const SumRider *rider)
 {
     const int P = B * N;
     if (ldgy <= 0) ldgy = EC;
@@ -914,11 +946,15 @@ int launch_edge_bwd(const float *TP, const float *TQ, int B, int N, int k, const
     // pass rides with bwd_point -- gains nothing: 47.9 us against 28.0 + 17.3; its N-int LDS table is then reserved by
     // every workgroup of the launch and thins out the point pass)
     if (dv)
-        hipLaunchKernelGGL((edge_point_bwd_kernel<true>), grid, block, 0, st, TQ, k, P, stats, cc, slope, gy, ldgy, y, ldy, hitj, usum,
-                           dvsum, (HitRec *)hits, G, dD);
+    {
+        SumRider sr = rider ? *rider : SumRider{nullptr, 0, 0, nullptr, 0};
+        sr.main_blocks = (int)grid.x;
+        hipLaunchKernelGGL((edge_point_bwd_kernel<true>), dim3(grid.x + (sr.out ? ceil_div(sr.n, 64) : 0)), block, 0, st, TQ, k, P, stats,
+                           cc, slope, gy, ldgy, y, ldy, hitj, usum, dvsum, (HitRec *)hits, G, dD, sr);
+    }
     else
         hipLaunchKernelGGL((edge_point_bwd_kernel<false>), grid, block, 0, st, TQ, k, P, stats, cc, slope, gy, ldgy, y, ldy, hitj, usum,
-                           nullptr, (HitRec *)hits, G, dD);
+                           nullptr, (HitRec *)hits, G, dD, SumRider{nullptr, 0, 0, nullptr, 0});
     prof_begin(PROF_EDGE_RGATHER, st);
     // one launch: the point workgroups and, behind them, workgroups for the extra segments of the long lists
     const int main_blocks = (int)grid.x, extra_blocks = main_blocks / 2;
@@ -1003,7 +1039,7 @@ void launch_edge_out(const float *usel, const float *stats, float slope, int P, 
 
 void launch_bwd_point(const float *gy, const float *usel, const float *stats, float slope, int P, double count,
                       int training, const FoldSet &fs, float *gbn_w, float *gbn_b, float *cc, unsigned *gmax_bits,
-                      const RevSlotsArgs *slots, hipStream_t st, int ldgy)
+                      const RevSlotsArgs *slots, hipStream_t st, int ldgy, const float *gy2, float *gysum)
 {
     int grid = ceil_div(P, EDGE_WAVES * 8);
     if (grid > 512) grid = 512;
@@ -1011,8 +1047,8 @@ void launch_bwd_point(const float *gy, const float *usel, const float *stats, fl
     // (slots: the list-space pass of the reverse adjacency rides behind this pass's workgroups, see rev_slots_pass)
     const RevSlotsArgs none{0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0, 0, 0};
     const int extra_wgs = slots ? slots->nblk * ceil_div(slots->Pblk, 256) : 0;
-    hipLaunchKernelGGL(bwd_point_kernel, dim3(grid + extra_wgs), dim3(256), 0, st, gy, ldgy > 0 ? ldgy : EC, usel, stats, slope, P,
-                       fs, fin, gmax_bits, grid, slots ? *slots : none);
+    hipLaunchKernelGGL(bwd_point_kernel, dim3(grid + extra_wgs), dim3(256), 0, st, gy, ldgy > 0 ? ldgy : EC, gy2, gysum, usel, stats,
+                       slope, P, fs, fin, gmax_bits, grid, slots ? *slots : none);
 }
 
 void launch_graph_feature_fwd(const float *x, const int32_t *idx, int B, int N, int C, int k, float *out,

@@ -375,34 +375,29 @@ __global__ __launch_bounds__(256) void embed_bwd_coef_kernel(const float *__rest
     extern __shared__ unsigned long long skeys[];  // [C2] (sort workgroups only)
     const int ncb = (C + 255) / 256;
     if ((int)blockIdx.x >= ncb) {
-        const int b = (int)blockIdx.x - ncb;
+        // C2 <= 2048: C2 / 256 workgroups per batch element, each ranks 256 of its keys (rank sort); else one per element (bitonic)
+        const int parts = C2 <= 2048 ? (C2 + 255) / 256 : 1;
+        const int b = ((int)blockIdx.x - ncb) / parts, part = ((int)blockIdx.x - ncb) % parts;
         for (int i = threadIdx.x; i < C2; i += 256)
             skeys[i] = i < C ? ((unsigned long long)(unsigned)arg[(size_t)b * C + i] << 32) | (unsigned)i : ~0ull;
         __syncthreads();
         if (C2 <= 2048) {
             // rank sort: the keys are distinct (the channel is their low word), so the number of smaller keys IS the position;
-            // every thread ranks its <= 8 keys against all of them with broadcast LDS reads -- no barrier between the steps of
-            // a sorting network (the bitonic sort below takes 55 barrier-separated steps for 1024 keys: 30 us)
-            unsigned long long mine[8];
-            int rank[8];
+            // a thread ranks ONE key against all of them with broadcast LDS reads -- no barrier-separated steps (the bitonic
+            // network below takes 55 of them for 1024 keys: 30 us in one workgroup; this: 1024 compares per thread)
+            const int i = part * 256 + (int)threadIdx.x;
+            const unsigned long long mine = i < C2 ? skeys[i] : ~0ull;
+            int rank = 0;
+            for (int j = 0; j < C2; j += 8) {
+                unsigned long long kj[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = threadIdx.x + 256 * u;
-                mine[u] = i < C2 ? skeys[i] : ~0ull;
-                rank[u] = 0;
-            }
-            for (int j = 0; j < C2; ++j) {
-                const unsigned long long kj = skeys[j];
+                for (int u = 0; u < 8; ++u) kj[u] = skeys[j + u];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) rank[u] += kj < mine[u] ? 1 : 0;
+                for (int u = 0; u < 8; ++u) rank += kj[u] < mine ? 1 : 0;
             }
-            // (the padding keys ~0 are equal: they take the positions behind the C real keys in any order)
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = threadIdx.x + 256 * u;
-                if (i < C) sorted[(size_t)b * C2 + rank[u]] = mine[u];
-                else if (i < C2) sorted[(size_t)b * C2 + i] = ~0ull;
-            }
+            // (the padding keys ~0 are equal among themselves: they keep their positions behind the C real keys)
+            if (i < C) sorted[(size_t)b * C2 + rank] = mine;
+            else if (i < C2) sorted[(size_t)b * C2 + i] = ~0ull;
             return;
         }
         for (int k = 2; k <= C2; k <<= 1)
@@ -835,7 +830,8 @@ void launch_embed_bwd_coef(const float *uwin, const float *gg, const float *stat
 {
     int C2 = 1;
     while (C2 < C) C2 <<= 1;
-    hipLaunchKernelGGL(embed_bwd_coef_kernel, dim3(ceil_div(C, 256) + (sorted ? B : 0)), dim3(256),
+    const int sort_wgs = sorted ? B * (C2 <= 2048 ? ceil_div(C2, 256) : 1) : 0;
+    hipLaunchKernelGGL(embed_bwd_coef_kernel, dim3(ceil_div(C, 256) + sort_wgs), dim3(256),
                        sorted ? (size_t)C2 * sizeof(unsigned long long) : 0, st, uwin, gg, stats, B, N, C, training, slope, gweight, gbias,
                        coef_a, coef_b, s, arg, C2, sorted);
 }

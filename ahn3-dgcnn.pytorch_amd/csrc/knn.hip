@@ -939,15 +939,12 @@ __global__ __launch_bounds__(KNN_ST_THREADS, 2) void knn_bound16s_kernel(const h
 // of row j as in the epilogue of knn_bound16s_kernel.
 // k <= 32: only the parts' upper halves A, B (32 each, descending) were published; the top 32 of their union is the
 // bitonic sequence max(A[i], B[31 - i]), sorted by the in-lane merge.  One lane = one row.
-__global__ __launch_bounds__(64) void knn_bound_merge32_kernel(const unsigned *__restrict__ exch,
-                                                               const float *__restrict__ xxc,
-                                                               const float *__restrict__ xx_raw,
-                                                               const unsigned *__restrict__ bmax, int B, int Npad, int k,
-                                                               float *__restrict__ tau0, float *__restrict__ epsr)
+// (one row: the body of knn_bound_merge32_kernel, and -- since round 4 -- of the prologue of knn_filter16_kernel, whose lanes
+// form the thresholds of their own rows instead of reading them from a 5 us launch in front of every filter)
+__device__ __forceinline__ void knn_tau_merge32(const unsigned *__restrict__ exch, const float *__restrict__ xxc,
+                                                const float *__restrict__ xx_raw, float cmax, float rmax, size_t row, int k,
+                                                float &tau, float &eps)
 {
-    const int lane = threadIdx.x;
-    const int b = blockIdx.x % B, rb = blockIdx.x / B;  // rb: group of 64 rows
-    const size_t row = (size_t)b * Npad + rb * 64 + lane;
     const uint4 *pa = reinterpret_cast<const uint4 *>(exch + (row * 2 + 0) * 64);
     const uint4 *pb = reinterpret_cast<const uint4 *>(exch + (row * 2 + 1) * 64);
     unsigned w[32];
@@ -973,12 +970,25 @@ __global__ __launch_bounds__(64) void knn_bound_merge32_kernel(const unsigned *_
     unsigned kth = w[0];
 #pragma unroll
     for (int i = 1; i < 32; ++i) kth = k - 1 == i ? w[i] : kth;
-    const float cmax = batch_max(bmax, b, 0, Npad / 32), rmax = batch_max(bmax, b, 1, Npad / 32);
     const float vk = __uint_as_float((kth & 0x80000000u) ? (kth & 0x7fffffffu) : ~kth);
     const float xi = xxc[row], xr = xx_raw[row];
-    const float eps = knn_f16_eps(xi, cmax, xr, rmax);
+    eps = knn_f16_eps(xi, cmax, xr, rmax);
     const float t = (vk - xi) - eps;
-    tau0[row] = (t != t) ? -__builtin_inff() : t;  // NaN -> no bound
+    tau = (t != t) ? -__builtin_inff() : t;  // NaN -> no bound
+}
+__global__ __launch_bounds__(64) void knn_bound_merge32_kernel(const unsigned *__restrict__ exch,
+                                                               const float *__restrict__ xxc,
+                                                               const float *__restrict__ xx_raw,
+                                                               const unsigned *__restrict__ bmax, int B, int Npad, int k,
+                                                               float *__restrict__ tau0, float *__restrict__ epsr)
+{
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x % B, rb = blockIdx.x / B;  // rb: group of 64 rows
+    const size_t row = (size_t)b * Npad + rb * 64 + lane;
+    const float cmax = batch_max(bmax, b, 0, Npad / 32), rmax = batch_max(bmax, b, 1, Npad / 32);
+    float tau, eps;
+    knn_tau_merge32(exch, xxc, xx_raw, cmax, rmax, row, k, tau, eps);
+    tau0[row] = tau;
     epsr[row] = eps;
 }
 
@@ -1289,8 +1299,13 @@ __global__ __launch_bounds__(KNN_ST_THREADS, 2) void knn_filter16_kernel(const h
                                                            const float *__restrict__ epsr,
                                                            const unsigned *__restrict__ bmax, int B, int Npad,
                                                            int parts, unsigned *__restrict__ lists,
-                                                           int *__restrict__ lcount, int *__restrict__ rbflag)
+                                                           int *__restrict__ lcount, int *__restrict__ rbflag,
+                                                           const unsigned *__restrict__ exch, const float *__restrict__ xx_raw,
+                                                           int k, float *__restrict__ tau_out)
 {
+    // exch != NULL (the pre-pass ran over two candidate halves and k <= 32): the thresholds are formed HERE from the halves'
+    // sorted class maxima (knn_tau_merge32), one lane per row, instead of by knn_bound_merge32_kernel in front of this launch;
+    // the workgroups of candidate part 0 leave tau0 behind for the exact pass of flagged row blocks (knn_exact_block)
     constexpr int KS1 = CP / 16 + 1, RT = KNN_ST_RT, NG = KNN_ST_TILES * KS1, PD = 3, RING = KNN_ST_RING;
     constexpr int VPC = Stage16<KS1>::VEC_PER_CHUNK;
     static_assert(RT == 2 && KNN_ST_TILES == 4 && RING == 3, "the hand-laid stream below assumes these");
@@ -1329,8 +1344,17 @@ __global__ __launch_bounds__(KNN_ST_THREADS, 2) void knn_filter16_kernel(const h
         const bool real = rb0 + rt < ntiles;
         const int rbc = real ? rb0 + rt : ntiles - 1;
         const int row = rbc * 32 + j32;
-        const float tau = tau0[(size_t)b * Npad + row], yy = yb[row];
-        const float v = (tau - epsr[(size_t)b * Npad + row]) + yy;
+        float tau, eps_row;
+        const float yy = yb[row];
+        if (exch) {
+            const float cmax = batch_max(bmax, b, 0, Npad / 32), rmax = batch_max(bmax, b, 1, Npad / 32);
+            knn_tau_merge32(exch, xxc, xx_raw, cmax, rmax, (size_t)b * Npad + row, k, tau, eps_row);
+            if (part == 0 && h == 0 && real) tau_out[(size_t)b * Npad + row] = tau;
+        } else {
+            tau = tau0[(size_t)b * Npad + row];
+            eps_row = epsr[(size_t)b * Npad + row];
+        }
+        const float v = (tau - eps_row) + yy;
         const float thr = v - (__builtin_fabsf(v) + __builtin_fabsf(tau) + yy) * 2.4e-7f;
         // padding rows (yy = +inf) give NaN: nothing may pass there (T = +inf: the accumulator is +inf)
         knn_stream_a<KS1, SPLIT>(xbatch, rbc, lane, (thr != thr || !real) ? __builtin_inff() : thr,
@@ -1949,12 +1973,13 @@ static KnnWs knn_ws(int B, int C, int N, void *base)
 
 template <int CP>
 static void knn_f16_launch(int cap, int parts, const KnnWs &w, const float *x, int ldx, int B, int N, int C, int Npad, int k,
-                           int32_t *idx, hipStream_t st)
+                           int32_t *idx, hipStream_t st, bool merge_here)
 {
     const dim3 grid(B * (Npad / 32)), block(64);
     prof_begin(PROF_KNN_FILTER, st);
     hipLaunchKernelGGL((knn_filter16_kernel<CP>), dim3(B * parts * ceil_div(Npad / 32, KNN_ST_ROWS)), dim3(KNN_ST_THREADS), 0,
-                       st, w.xh, w.xxc, w.tau0, w.eps, w.bmax, B, Npad, parts, w.lists, w.lcount, w.rbflag);
+                       st, w.xh, w.xxc, w.tau0, w.eps, w.bmax, B, Npad, parts, w.lists, w.lcount, w.rbflag,
+                       merge_here ? w.exch : (const unsigned *)nullptr, w.xx, k, w.tau0);
     prof_end(PROF_KNN_FILTER, st);
     prof_begin(PROF_KNN_REFINE, st);
     // (two waves per block for k <= 32 as well -- knn_refine_kernel<CP, 64, 2> -- measured: 125 us against 80 at B = 8,
@@ -2048,6 +2073,12 @@ int dgcnn::knn_ld(const float *x, int ldx, int B, int N, int C, int k, int32_t *
     static const int fparts_env = getenv("DGCNN_KNN_FPARTS") ? atoi(getenv("DGCNN_KNN_FPARTS")) : 0;  // experiments
     int fparts = Npad / (32 * KNN_ST_TILES) >= 16 ? KNN_MAXPARTS : parts;
     if (fparts_env >= 1 && fparts_env <= KNN_MAXPARTS && Npad / (32 * KNN_ST_TILES) >= fparts_env) fparts = fparts_env;
+    // two candidate halves and k <= 32: the thresholds CAN be merged inside the fp16 filter's prologue (knn_tau_merge32 per
+    // lane) instead of by knn_bound_merge32_kernel -- measured (round 4, B = 4 and 8, N = 7000): the filter then takes 48.1
+    // instead of 38.5 us per launch at B = 4, more than the 4.9 us launch it saves: every one of the filter's four candidate
+    // parts repeats the merge of its rows in front of its stream.  Kept behind DGCNN_KNN_MERGE_IN_FILTER=1 for the record.
+    static const bool merge_in_filter = getenv("DGCNN_KNN_MERGE_IN_FILTER") != nullptr;
+    const bool merge_here = parts == 2 && k <= 32 && (f16path || split4) && merge_in_filter;
     if (prepass) {
         // (knn_bound_kernel writes tau0 for every row, padded rows included)
         if (CP >= 16 || split4) {
@@ -2064,7 +2095,9 @@ int dgcnn::knn_ld(const float *x, int ldx, int B, int N, int C, int k, int32_t *
                 default: DG_BOUND16(128); break;
             }
 #undef DG_BOUND16
-            if (parts == 2 && k <= 32)  // (Npad is a multiple of 128)
+            if (parts == 2 && k <= 32 && merge_here) {
+                // the filter's own lanes merge the two halves' class maxima into the thresholds (knn_tau_merge32)
+            } else if (parts == 2 && k <= 32)  // (Npad is a multiple of 128)
                 hipLaunchKernelGGL(knn_bound_merge32_kernel, dim3(B * (Npad / 64)), dim3(64), 0, st, w.exch, w.xxc, xx, w.bmax, B,
                                    Npad, k, w.tau0, w.eps);
             else if (parts == 2)
@@ -2085,7 +2118,8 @@ int dgcnn::knn_ld(const float *x, int ldx, int B, int N, int C, int k, int32_t *
         rbflag = w.rbflag;
         prof_begin(PROF_KNN_FILTER, st);
         hipLaunchKernelGGL((knn_filter16_kernel<16, true>), dim3(B * fparts * ceil_div(Npad / 32, KNN_ST_ROWS)), dim3(KNN_ST_THREADS),
-                           0, st, w.xh, w.xxc, w.tau0, w.eps, w.bmax, B, Npad, fparts, w.lists, w.lcount, w.rbflag);
+                           0, st, w.xh, w.xxc, w.tau0, w.eps, w.bmax, B, Npad, fparts, w.lists, w.lcount, w.rbflag,
+                           merge_here ? w.exch : (const unsigned *)nullptr, xx, k, w.tau0);
         prof_end(PROF_KNN_FILTER, st);
         prof_begin(PROF_KNN_REFINE, st);
         const dim3 rgrid(B * (Npad / 32));
@@ -2131,10 +2165,10 @@ int dgcnn::knn_ld(const float *x, int ldx, int B, int N, int C, int k, int32_t *
         // kernels flagged (it returns at once for the others)
         rbflag = w.rbflag;
         switch (CP) {
-            case 16: knn_f16_launch<16>(cap, fparts, w, x, ldx, B, N, C, Npad, k, idx, st); break;
-            case 32: knn_f16_launch<32>(cap, fparts, w, x, ldx, B, N, C, Npad, k, idx, st); break;
-            case 64: knn_f16_launch<64>(cap, fparts, w, x, ldx, B, N, C, Npad, k, idx, st); break;
-            default: knn_f16_launch<128>(cap, fparts, w, x, ldx, B, N, C, Npad, k, idx, st); break;
+            case 16: knn_f16_launch<16>(cap, fparts, w, x, ldx, B, N, C, Npad, k, idx, st, merge_here); break;
+            case 32: knn_f16_launch<32>(cap, fparts, w, x, ldx, B, N, C, Npad, k, idx, st, merge_here); break;
+            case 64: knn_f16_launch<64>(cap, fparts, w, x, ldx, B, N, C, Npad, k, idx, st, merge_here); break;
+            default: knn_f16_launch<128>(cap, fparts, w, x, ldx, B, N, C, Npad, k, idx, st, merge_here); break;
         }
         DG_CHECK_LAUNCH("knn_filter16_kernel / knn_refine_kernel");
     }

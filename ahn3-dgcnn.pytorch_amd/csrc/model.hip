@@ -11,7 +11,8 @@
 //             add7 = g W7[:, :emb]^T  (pooled_fwd_kernel);  head tail(cat, add7) -> logits [P][NC] --from_point_major--> caller
 //   backward  dlogits -> head tail bwd -> gcat [P][192], gadd7;  pooled_bwd_kernel -> gg = gadd7 W7[:, :emb];
 //             gw7_kernel -> gW7 = [gadd7^T g | gW7c];  embed bwd: gcat += dL/dcat of conv6;
-//             block 2, 1, 0 backward with gy = gcat[:, 64 b ..] and gx ADDED into gcat[:, 64 (b - 1) ..]
+//             block 2, 1, 0 backward with gy = gcat[:, 64 b ..] (+ block b + 1's dense input gradient, added by the block's
+//             first kernel)
 #include "model_parts.h"
 
 namespace dgcnn {
@@ -150,6 +151,7 @@ FwdWs fwd_ws(const dgcnn_model_desc *d, void *p)
 
 struct BwdWs {
     float *gl_pm, *gcat, *gadd7, *gg, *gw7c;
+    float *gxd, *gysum;  // [P][64] each: a block's input gradient (dense), and gcat slice + gxd as the previous block's dL/dy
     // the reverse neighbour lists of the three blocks, built in one go (launch_rev_build_merged)
     int *rzero, *rcnt, *rindeg, *rrowptr, *rsegbase, *rpcnt, *rrev, *rextra;
     int rextra_stride;
@@ -166,6 +168,8 @@ BwdWs bwd_ws(const dgcnn_model_desc *d, void *p)
     w.gadd7 = c.take<float>((size_t)d->B * d->c7);
     w.gg = c.take<float>((size_t)d->B * d->emb);
     w.gw7c = c.take<float>((size_t)d->c7 * CATW);
+    w.gxd = c.take<float>(P * EC);
+    w.gysum = c.take<float>(P * EC);
     {
         const size_t E = P * d->k;
         w.rextra_stride = (int)(2 * (E / REV_SEG + 1));
@@ -325,7 +329,7 @@ extern "C" int dgcnn_model_fwd(const dgcnn_model_desc *d, const float *x, int64_
         const float *in = b == 0 ? xpm : s.cat + EC * (b - 1);
         const int ldin = b == 0 ? 0 : CATW;
         if (!d->idx_given && knn_ld(in, ldin, B, N, e.C, d->k, d->idx[b], w.scratch, w.scratch_bytes, stream)) return 1;
-        if (edgeconv_fwd_ld(&e, EdgeLd{ldin, CATW, 0, 0, 0}, in, d->idx[b], s.cat + EC * b, s.edge[b], w.scratch, w.scratch_bytes, stream))
+        if (edgeconv_fwd_ld(&e, EdgeLd{ldin, CATW, 0, 0, 0, nullptr, nullptr}, in, d->idx[b], s.cat + EC * b, s.edge[b], w.scratch, w.scratch_bytes, stream))
             return 1;
     }
     // max |cat| (the operand scale of every product that reads cat) and its column sums (conv6's backward)
@@ -347,8 +351,12 @@ extern "C" int dgcnn_model_fwd(const dgcnn_model_desc *d, const float *x, int64_
 
 extern "C" int dgcnn_model_bwd(const dgcnn_model_desc *d, const float *x, int64_t x_sb, int64_t x_sc, int64_t x_sn,
                                const float *glogits, int64_t g_sb, int64_t g_sc, int64_t g_sn, const void *saved,
-                               const dgcnn_model_grads *g, void *workspace, size_t workspace_bytes, void *stream)
+                               const dgcnn_model_grads *g, void *workspace, size_t workspace_bytes, int phases, void *stream)
 {
+    // phases: bit 0 = the head (everything up to dL/dcat: afterwards the gradients of conv6 .. conv9 and bn6 .. bn8 are
+    // final), bit 1 = the three EdgeConv blocks.  A data-parallel caller runs them as two calls on the same workspace and starts
+    // the all-reduce of the head's 97 % of the gradient bytes in between, under the blocks' backward.
+    DG_REQUIRE(phases >= 1 && phases <= 3, "dgcnn_model_bwd: phases must be 1 (head), 2 (blocks) or 3 (both)");
     if (check_model(d, "dgcnn_model_bwd", true)) return 1;
     DG_REQUIRE(x && glogits && saved && g && workspace, "dgcnn_model_bwd: null pointer");
     for (int i = 0; i < 9; ++i) DG_REQUIRE(g->gw[i], "dgcnn_model_bwd: gradient output gw[%d] missing", i);
@@ -366,6 +374,7 @@ extern "C" int dgcnn_model_bwd(const dgcnn_model_desc *d, const float *x, int64_
     // the caller keeps the three graphs in one array (ops.dgcnn_full does; graphs injected one by one take the per-block build)
     const size_t Pn = (size_t)B * N, En = Pn * d->k;
     const bool merged = d->idx[1] == d->idx[0] + En && d->idx[2] == d->idx[1] + En && (size_t)3 * En < ((size_t)1 << 31);
+    if (phases & 1) {
     if (merged && launch_rev_build_merged(d->idx[0], 3, B, N, d->k, w.rcnt, w.rindeg, w.rrowptr, w.rsegbase, w.rpcnt, w.rrev, w.rextra,
                                           w.rextra_stride, w.rzero, Z_WORDS, Z_ALLOC, st))
         return 1;
@@ -383,14 +392,16 @@ extern "C" int dgcnn_model_bwd(const dgcnn_model_desc *d, const float *x, int64_
     if (embed_bwd_ld(s.cat, CATW, s.amax_cat, s.catsum, d->w[5], CATW, s.arg, s.uwin, s.stats6, w.gg, B, N, CATW, emb, d->training,
                      d->slope, w.gcat, CATW, 1, g->gw[5], g->gbn_w[5], g->gbn_b[5], w.scratch, w.scratch_bytes, stream))
         return 1;
+    }  // phase 1
+    if (!(phases & 2)) return 0;
     for (int b = 2; b >= 0; --b) {
         const dgcnn_edgeconv_desc e = block_desc(d, b);
         dgcnn_edgeconv_grads eg{};
-        eg.gx = b > 0 ? w.gcat + EC * (b - 1) : nullptr;
+        eg.gx = b > 0 ? w.gxd : nullptr;  // dense; block b - 1 adds it to its slice of gcat in its first kernel (bwd_point)
         eg.gw1 = g->gw[2 * b], eg.gbn1_w = g->gbn_w[2 * b], eg.gbn1_b = g->gbn_b[2 * b];
         if (b < 2) eg.gw2 = g->gw[2 * b + 1], eg.gbn2_w = g->gbn_w[2 * b + 1], eg.gbn2_b = g->gbn_b[2 * b + 1];
         const float *in = b == 0 ? xpm : s.cat + EC * (b - 1);
-        const EdgeLd ld{b == 0 ? 0 : CATW, CATW, CATW, b > 0 ? CATW : 0, b > 0 ? 1 : 0};
+        const EdgeLd ld{b == 0 ? 0 : CATW, CATW, CATW, 0, 0, b < 2 ? w.gxd : nullptr, b < 2 ? w.gysum : nullptr};
         const RevPrebuilt pre{w.rzero + b * Z_WORDS, w.rindeg + b * Pn, w.rrowptr + b * Pn, w.rsegbase + b * Pn, w.rpcnt + b * Pn,
                               w.rrev + b * En,   w.rextra + (size_t)b * w.rextra_stride};
         if (edgeconv_bwd_ld(&e, ld, in, d->idx[b], s.cat + EC * b, w.gcat + EC * b, s.edge[b], &eg, w.scratch, w.scratch_bytes, stream,

@@ -51,7 +51,7 @@ __device__ __forceinline__ void seg_softmax(const float *__restrict__ z, const S
 // mask != 0, (0, ..., 0, 1) with label `cls` elsewhere (constant rows: they count in the mean, carry no gradient).
 template <int MAXC>
 __global__ __launch_bounds__(SEG_THREADS) void seg_loss_kernel(const float *__restrict__ z, SegView vw,
-                                                               const int64_t *__restrict__ labels,
+                                                               const void *__restrict__ labels, int labels_f64,
                                                                const uint8_t *__restrict__ mask, float smoothing,
                                                                float *__restrict__ gz, int64_t *__restrict__ pred,
                                                                double *__restrict__ partial)
@@ -64,7 +64,8 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_loss_kernel(const float *__re
         seg_softmax<MAXC>(z, vw, t, p);
         const int nn = vw.cls + (mask ? 1 : 0);
         const bool in = mask ? mask[t] != 0 : true;
-        const int lab = in ? (int)labels[t] : vw.cls;
+        // (labels as the reference's loader hands them over -- float64, data.py:169-182 -- or int64)
+        const int lab = in ? (labels_f64 ? (int)((const double *)labels)[t] : (int)((const int64_t *)labels)[t]) : vw.cls;
 #pragma unroll
         for (int c = 0; c < MAXC + 1; ++c) {
             float x = 0.0f;
@@ -211,6 +212,15 @@ extern "C" int dgcnn_seg_loss(const float *logits, int B, int N, int classes, in
                               float *loss, float *grad_logits, int64_t *pred, void *workspace, size_t workspace_bytes,
                               void *stream)
 {
+    return dgcnn_seg_loss_labels(logits, B, N, classes, stride_b, stride_c, stride_n, labels, 0, mask, smoothing, loss, grad_logits,
+                                 pred, workspace, workspace_bytes, stream);
+}
+
+extern "C" int dgcnn_seg_loss_labels(const float *logits, int B, int N, int classes, int64_t stride_b, int64_t stride_c,
+                                     int64_t stride_n, const void *labels, int labels_f64, const uint8_t *mask, float smoothing,
+                                     float *loss, float *grad_logits, int64_t *pred, void *workspace, size_t workspace_bytes,
+                                     void *stream)
+{
     if (seg_check("dgcnn_seg_loss", logits, B, N, classes)) return 1;
     DG_REQUIRE(labels && loss && grad_logits && pred && workspace, "dgcnn_seg_loss: null pointer");
     DG_REQUIRE(classes + (mask ? 1 : 0) >= 2, "dgcnn_seg_loss: label smoothing needs at least two classes");
@@ -220,10 +230,10 @@ extern "C" int dgcnn_seg_loss(const float *logits, int B, int N, int classes, in
     const int grid = ceil_div(vw.P, SEG_THREADS);
     double *partial = (double *)workspace;
     if (classes <= 8)
-        hipLaunchKernelGGL(seg_loss_kernel<8>, dim3(grid), dim3(SEG_THREADS), 0, st, logits, vw, labels, mask, smoothing,
+        hipLaunchKernelGGL(seg_loss_kernel<8>, dim3(grid), dim3(SEG_THREADS), 0, st, logits, vw, labels, labels_f64, mask, smoothing,
                            grad_logits, pred, partial);
     else
-        hipLaunchKernelGGL(seg_loss_kernel<32>, dim3(grid), dim3(SEG_THREADS), 0, st, logits, vw, labels, mask,
+        hipLaunchKernelGGL(seg_loss_kernel<32>, dim3(grid), dim3(SEG_THREADS), 0, st, logits, vw, labels, labels_f64, mask,
                            smoothing, grad_logits, pred, partial);
     hipLaunchKernelGGL(seg_loss_finalize_kernel, dim3(1), dim3(256), 0, st, partial, grid, vw.P, loss);
     DG_CHECK_LAUNCH("dgcnn_seg_loss");

@@ -884,9 +884,24 @@ class _DGCNNFull(torch.autograd.Function):
         if ws_bytes == 0:
             _lib.check(1, "dgcnn_model_bwd (shape)")
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
-        _lib.check(lib.dgcnn_model_bwd(d, _lib.ptr(x), x.stride(0), x.stride(1), x.stride(2), _lib.ptr(gl), gl.stride(0), gl.stride(1),
-                                       gl.stride(2), _lib.ptr(saved), ctypes.byref(g), _lib.ptr(ws), ws_bytes, _lib.stream_ptr(dev)),
-                   "dgcnn_model_bwd")
+
+        def run(phases):
+            _lib.check(lib.dgcnn_model_bwd(d, _lib.ptr(x), x.stride(0), x.stride(1), x.stride(2), _lib.ptr(gl), gl.stride(0),
+                                           gl.stride(1), gl.stride(2), _lib.ptr(saved), ctypes.byref(g), _lib.ptr(ws), ws_bytes,
+                                           phases, _lib.stream_ptr(dev)), "dgcnn_model_bwd")
+
+        # data parallel: when conv6 .. conv9 (the last four tensors of the flat exchange buffer, 97 % of its bytes) have been
+        # written into their slices, their all-reduce can start as soon as the head's backward is enqueued and runs under the
+        # three blocks' backward (parallel.FlatGradAllReduce(overlap=True))
+        sync = getattr(ctx.sinks[5][0], "_dgcnn_grad_sync", None)
+        in_place = all(outs[i].data_ptr() == ctx.sinks[i][1].data_ptr() for i in (5, 6, 7, 8) if ctx.sinks[i][1] is not None) and \
+            all(ctx.sinks[i][1] is not None for i in (5, 6, 7, 8))
+        if sync is not None and in_place and sync.wants_overlap():
+            run(1)
+            sync.reduce_tail_async(ctx.sinks[5][0], [ctx.sinks[i][0] for i in (5, 6, 7, 8)])
+            run(2)
+        else:
+            run(3)
         return (None,) * 9 + tuple(o.view(sh) for o, sh in zip(outs, shapes))
 
 
@@ -982,9 +997,10 @@ class _SegLoss(torch.autograd.Function):
         pred = torch.empty((B, N), dtype=torch.int64, device=dev)
         ws_bytes = lib.dgcnn_seg_loss_workspace_bytes(B, N)
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
-        _lib.check(lib.dgcnn_seg_loss(_lib.ptr(logits), B, N, C, sb, sc, sn, _lib.ptr(labels),
-                                      _lib.ptr(mask) if mask is not None else None, smoothing, _lib.ptr(loss),
-                                      _lib.ptr(grad), _lib.ptr(pred), _lib.ptr(ws), ws_bytes, _lib.stream_ptr(dev)),
+        _lib.check(lib.dgcnn_seg_loss_labels(_lib.ptr(logits), B, N, C, sb, sc, sn, _lib.ptr(labels),
+                                             1 if labels.dtype == torch.float64 else 0,
+                                             _lib.ptr(mask) if mask is not None else None, smoothing, _lib.ptr(loss),
+                                             _lib.ptr(grad), _lib.ptr(pred), _lib.ptr(ws), ws_bytes, _lib.stream_ptr(dev)),
                    "dgcnn_seg_loss")
         ctx.save_for_backward(grad)
         ctx.mark_non_differentiable(pred)
@@ -1010,7 +1026,11 @@ def seg_loss(logits, labels, mask=None, smoothing=0.2):
     Returns (loss: 0-d tensor with autograd to the logits, pred: int64 [B, N])."""
     B, C, N = logits.shape
     dev = logits.device
-    labels = labels.to(device=dev, dtype=torch.int64).reshape(B, N).contiguous()
+    # float64 labels (what the reference's loader hands over, data.py:169-182) are read as they are; others become int64
+    if labels.dtype == torch.float64:
+        labels = labels.to(device=dev).reshape(B, N).contiguous()
+    else:
+        labels = labels.to(device=dev, dtype=torch.int64).reshape(B, N).contiguous()
     if mask is not None:
         mask = (mask.to(device=dev) != 0).to(torch.uint8).reshape(B, N).contiguous()
     # overlapping / broadcast strides cannot hold a gradient of the same layout

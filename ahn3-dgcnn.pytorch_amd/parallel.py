@@ -108,10 +108,16 @@ class FlatGradAllReduce:
     tensors stay (zeroed) views of the buffer and backward accumulates in place (gradient accumulation
     over several backward passes)."""
 
-    def __init__(self, params, group=None, comm=None):
+    def __init__(self, params, group=None, comm=None, overlap=False):
         """comm: a HipComm -- the all-reduce then runs through the C ABI (dgcnn_comm_allreduce_f32) instead of
-        torch.distributed"""
+        torch.distributed.
+        overlap: the backward of ops.dgcnn_full starts the all-reduce of the buffer's TAIL -- conv6 .. conv9, the last four
+        tensors, 951 552 of the model's 980 864 gradient floats -- as soon as the head's backward is enqueued
+        (`reduce_tail_async`), so that it runs on the collective's own stream under the three EdgeConv blocks' backward;
+        `sync` then reduces the short front part and waits for the tail.  torch.distributed exchange only."""
         self.comm = comm
+        self.overlap = bool(overlap)
+        self._tail = None        # (offset, work, host copy or None) of a tail reduction in flight
         self.params = [p for p in params if p.requires_grad]
         seen, uniq = set(), []
         for p in self.params:  # bnN and convN.1 alias the same tensors in the reference's layout
@@ -134,6 +140,7 @@ class FlatGradAllReduce:
             # ops' backward passes write a parameter's gradient straight into its slice when they find this (ops._EdgeConv):
             # `pack` then has nothing to copy for it
             p._dgcnn_grad_sink = self.views[-1]
+            p._dgcnn_grad_sync = self
             off += n
 
     @property
@@ -168,10 +175,56 @@ class FlatGradAllReduce:
         if src:
             torch._foreach_copy_(dst, src)
 
+    def wants_overlap(self):
+        return self.overlap and self.comm is None and self._tail is None and self.world_size > 1
+
+    def reduce_tail_async(self, first, final):
+        """start the all-reduce (mean) of the flat buffer from parameter `first` to its end.  `final`: the parameters whose
+        gradients are final and already sit in their slices (enqueued on the current stream); nothing is started (False)
+        unless every parameter from `first` on is one of them.  Returns at once: the collective runs on torch.distributed's
+        own stream."""
+        k = next((i for i, p in enumerate(self.params) if p is first), None)
+        if k is None or not all(any(p is q for q in final) for p in self.params[k:]):
+            return False
+        off = sum(p.numel() for p in self.params[:k])
+        tail = self.flat[off:]
+        if _host_staged(tail, self.group):          # gloo rehearsal: the host copy travels
+            h = tail.cpu()
+            work = dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._tail = (off, work, h)
+        else:
+            if self._avg is None:
+                self._avg = dist.get_backend(self.group) == "nccl"
+            op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+            work = dist.all_reduce(tail, op=op, group=self.group, async_op=True)
+            self._tail = (off, work, None)
+        return True
+
+    def _finish_tail(self, ws):
+        off, work, h = self._tail
+        self._tail = None
+        work.wait()
+        tail = self.flat[off:]
+        if h is not None:
+            tail.copy_(h)
+            tail.div_(ws)
+        elif not self._avg:
+            tail.div_(ws)
+
     def sync(self):
         """sum over ranks, then divide by the world size (gradient of the mean loss over the global batch)."""
         self.pack()
         ws = self.world_size
+        if self._tail is not None:      # the tail is in flight since the backward: reduce the front, then join
+            front = self.flat[:self._tail[0]]
+            if front.numel():
+                if self._avg and not _host_staged(front, self.group):
+                    dist.all_reduce(front, op=dist.ReduceOp.AVG, group=self.group)
+                else:
+                    all_reduce_sum(front, self.group)
+                    front.div_(ws)
+            self._finish_tail(ws)
+            return self.flat
         if self.comm is not None:
             if ws > 1:
                 self.comm.all_reduce(self.flat, average=True)

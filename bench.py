@@ -77,6 +77,8 @@ def parse_args():
                     help="nccl = RCCL over xGMI (the product path); gloo only to rehearse the N-rank code on a box "
                          "with fewer GPUs than ranks (together with --same-device)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--no-overlap", action="store_true", help="train workload, N > 1: one all-reduce after the backward instead of "
+                                                             "starting the head's share inside it")
     ap.add_argument("--graph-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-graph-leg", action="store_true", help="block workload: skip the hipGraph replay of the step (a child process)")
     ap.add_argument("--no-model-legs", action="store_true", help="block workload: skip the `eval_forward` (configs[2]) and `stress` (configs[4]) objects")
@@ -533,7 +535,9 @@ def run_train(args, rank, world, dev, steps, warmup, with_cpu, global_batch=None
     torch.manual_seed(0)                                  # the same initial weights on every rank
     model = DGCNN(5, 4, k, dropout=0.5, emb_dims=1024, cuda=True)
     model.train()
-    sync = FlatGradAllReduce(model.parameters(), comm=make_comm(args, rank, world))
+    # (overlap: with more than one rank the all-reduce of conv6 .. conv9 -- 97 % of the bytes -- starts inside the backward,
+    # behind the head's part, and runs under the three blocks' backward; torch.distributed exchange only)
+    sync = FlatGradAllReduce(model.parameters(), comm=make_comm(args, rank, world), overlap=not args.no_overlap)
     opt = FlatAdam(model.parameters(), lr=1e-3, weight_decay=1e-4, grad_buffer=sync.flat)   # train.py:118
     if dist.is_initialized() and world > 1:
         broadcast(opt.flat, 0)
@@ -637,7 +641,10 @@ def run_train(args, rank, world, dev, steps, warmup, with_cpu, global_batch=None
                    "backend": (args.backend if world > 1 else None), "launch": "eager", "exchange": args.exchange},
         "rccl_ranks": ranks,
         "allreduce": {"ms": ar_ms, "bytes": sync.flat.numel() * 4, "samples": len(ar_events),
-                      "note": "pack (one multi-tensor copy) + one all-reduce (AVG) of %d floats" % sync.flat.numel()},
+                      "overlapped": bool(sync.overlap and world > 1 and sync.comm is None),
+                      "note": "all-reduce (AVG) of %d floats; with `overlapped` the last 951 552 (conv6 .. conv9) are in flight "
+                              "since the head's backward and `ms` is what is left of the exchange behind the backward: the "
+                              "front part and the wait for the tail" % sync.flat.numel()},
         "step_tflops": step_flops / (dt / steps) / 1e12,
         "roofline": kernels[0] if kernels else None,
         "kernels": kernels[1:],

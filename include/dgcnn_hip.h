@@ -357,7 +357,10 @@ int dgcnn_model_fwd(const dgcnn_model_desc *d, const float *x, int64_t x_sb, int
  * deterministic as dgcnn_edgeconv_bwd is. */
 int dgcnn_model_bwd(const dgcnn_model_desc *d, const float *x, int64_t x_sb, int64_t x_sc, int64_t x_sn, const float *glogits,
                     int64_t g_sb, int64_t g_sc, int64_t g_sn, const void *saved, const dgcnn_model_grads *g, void *workspace,
-                    size_t workspace_bytes, void *stream);
+                    size_t workspace_bytes, int phases, void *stream);
+/* phases = 3: the whole backward.  phases = 1 then phases = 2 on the SAME workspace (untouched in between): first the head --
+ * after it the gradients of conv6 .. conv9 and bn6 .. bn8 are final (97 % of the model's gradient bytes), so a data-parallel
+ * caller can start their all-reduce on another stream --, then the three EdgeConv blocks. */
 
 /* ---- the steps either side of DGCNN.forward in the reference's loops ("next") -------
  * Logits are addressed by element strides, (b, c, n) at b*stride_b + c*stride_c + n*stride_n, so both the
@@ -375,6 +378,12 @@ size_t dgcnn_seg_loss_workspace_bytes(int B, int N);
 int dgcnn_seg_loss(const float *logits, int B, int N, int classes, int64_t stride_b, int64_t stride_c,
                    int64_t stride_n, const int64_t *labels, const uint8_t *mask, float smoothing, float *loss,
                    float *grad_logits, int64_t *pred, void *workspace, size_t workspace_bytes, void *stream);
+/* the same with the labels as the reference's loader hands them to the loop: float64 [B*N] (data.py:169-182, train.py:177;
+ * labels_f64 = 1) -- no conversion pass in front of the loss -- or int64 (labels_f64 = 0) */
+int dgcnn_seg_loss_labels(const float *logits, int B, int N, int classes, int64_t stride_b, int64_t stride_c,
+                          int64_t stride_n, const void *labels, int labels_f64, const uint8_t *mask, float smoothing,
+                          float *loss, float *grad_logits, int64_t *pred, void *workspace, size_t workspace_bytes,
+                          void *stream);
 
 /* Inference post-step (test.py:123-127, :308-311): softmax over the classes, maximum and arg-max; points whose
  * maximum probability is below min_confidence get the label `unclassified` (31 in the reference).  pred int64

@@ -51,7 +51,8 @@ def main():
         from ahn3_dgcnn_pytorch_amd.parallel import FlatGradAllReduce, broadcast, shard_batch, sync_buffers
         cfg = torch.load(fin, weights_only=False)
         model = build_model(cfg)
-        sync = FlatGradAllReduce(model.parameters())
+        # DGCNN_DP_OVERLAP=1: the tail of the buffer (conv6 .. conv9) is reduced under the blocks' backward
+        sync = FlatGradAllReduce(model.parameters(), overlap=bool(os.environ.get("DGCNN_DP_OVERLAP")))
         opt = FlatAdam(model.parameters(), lr=1e-3, weight_decay=1e-4, grad_buffer=sync.flat)
         assert sync.flat.numel() == 980864 + (cfg["classes"] - 5) * 256 and len(sync.params) == 25
         broadcast(opt.flat, 0)

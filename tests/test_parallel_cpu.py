@@ -101,3 +101,36 @@ def test_shard_batch_contract():
     assert torch.equal(torch.cat(parts), x) and all(p.shape[0] == 2 for p in parts)
     with pytest.raises(ValueError):
         shard_batch(x, 0, 3)
+
+
+def _overlap_worker(rank, port):
+    from ahn3_dgcnn_pytorch_amd.parallel import FlatGradAllReduce
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    try:
+        sizes = (3, 5, 7, 11)
+        ps = [torch.nn.Parameter(torch.zeros(n)) for n in sizes]
+        sync = FlatGradAllReduce(ps, overlap=True)
+        for _ in range(2):                                   # two steps: the tail state is cleared by sync()
+            sync.zero()
+            for i, (p, v) in enumerate(zip(ps, sync.views)):
+                v.fill_(float(rank + 1) * (i + 1))           # what a backward would have written into the slices
+                p.grad = v
+            assert sync.wants_overlap()
+            assert not sync.reduce_tail_async(ps[2], [ps[2]])        # ps[3] lies behind it and is not final: refused
+            assert sync.reduce_tail_async(ps[2], [ps[2], ps[3]])     # the tail is in flight ...
+            assert not sync.wants_overlap()
+            flat = sync.sync()                                       # ... the front is reduced here, then the join
+            want = torch.cat([torch.full((n,), 1.5 * (i + 1)) for i, n in enumerate(sizes)])
+            assert torch.allclose(flat, want), (flat, want)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_tail_of_the_buffer_reduced_ahead_of_sync():
+    """FlatGradAllReduce(overlap=True): the all-reduce of the buffer's tail is started early (by the backward of
+    ops.dgcnn_full, once the head's gradients are final) and joined by sync(), which reduces the front part; the result
+    is the plain one-bucket average."""
+    mp.spawn(_overlap_worker, args=(_free_port(),), nprocs=WORLD, join=True)

@@ -34,7 +34,8 @@ def _env():
 
 
 @pytest.mark.timeout(600)
-def test_two_rank_product_step_matches_shardwise_run(tmp_path, device):
+@pytest.mark.parametrize("overlap", [False, True])   # True: the all-reduce of conv6 .. conv9 starts inside the backward
+def test_two_rank_product_step_matches_shardwise_run(tmp_path, device, overlap):
     sys.path.insert(0, HERE)
     import dp_child
     from ahn3_dgcnn_pytorch_amd.optim import FlatAdam
@@ -47,8 +48,11 @@ def test_two_rank_product_step_matches_shardwise_run(tmp_path, device):
     fin, fout = str(tmp_path / "in.pt"), str(tmp_path / "out.pt")
     torch.save(cfg, fin)
     port = str(_free_port())
+    env = _env()
+    if overlap:
+        env["DGCNN_DP_OVERLAP"] = "1"
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dp_child.py"), str(r), str(WORLD), port, "gloo", fin, fout],
-                              env=_env(), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(WORLD)]
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(WORLD)]
     outs = [p.communicate(timeout=540)[0] for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o[-4000:]
