@@ -1615,6 +1615,51 @@ __global__ __launch_bounds__(64 * FW) void colsum_fold_kernel(const double *__re
     colsum[c] = (float)t;
 }
 
+// out[e] = sum over nchunk partials [nchunk][n] (chunk order) for up to three jobs in ONE launch: the tail's three weight
+// gradients (dW9's records, dW8's and dW7c's chunk partials) were three launches of 5 - 11 us.  1024 threads = 16 waves x
+// 64 elements; a wave adds its contiguous share of the chunks (eight in flight), the 16 sums are added in wave order.
+struct FoldJob {
+    const float *partial;
+    int nchunk, n;
+    float *out;
+    int first_block;
+};
+struct Fold3Args {
+    FoldJob job[3];
+    int njobs;
+};
+__global__ __launch_bounds__(1024) void fold3_kernel(const Fold3Args a)
+{
+    __shared__ float red[16][64];
+    int j = 0;
+    while (j + 1 < a.njobs && (int)blockIdx.x >= a.job[j + 1].first_block) ++j;
+    const FoldJob J = a.job[j];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int e = ((int)blockIdx.x - J.first_block) * 64 + lane;
+    const int q = (J.nchunk + 15) / 16;
+    const int c0 = w * q, c1 = c0 + q < J.nchunk ? c0 + q : J.nchunk;
+    float s = 0.0f;
+    if (e < J.n) {
+        int ch = c0;
+        for (; ch + 8 <= c1; ch += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = J.partial[(size_t)(ch + u) * J.n + e];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; ch < c1; ++ch) s += J.partial[(size_t)ch * J.n + e];
+    }
+    red[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && e < J.n) {
+        float t = red[0][lane];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) t += red[i][lane];
+        J.out[e] = t;
+    }
+}
+
 // ---- host side: layouts and launch sequences ----------------------------------------------------------------------------
 struct Carver {
     char *base;
@@ -1699,7 +1744,7 @@ struct BwdWs {
     unsigned *zero;  // one block, zeroed by a memset node: oa8, ob8, oa7, ob7 [nrb + 1] each, sb8 [4], sb7 [4]
     size_t zero_words;
     unsigned *oa8, *ob8, *oa7, *ob7, *sb8, *sb7;
-    float *dv8, *dv7, *pdw9, *cc8, *cc7, *wpart;
+    float *dv8, *dv7, *pdw9, *cc8, *cc7, *wpart, *wpart7;
     double *pbn8, *pdv7, *bsum7;
     size_t bytes;
 };
@@ -1725,7 +1770,9 @@ static BwdWs bwd_ws(const dgcnn_head_tail_desc *d, void *p)
     w.cc7 = c.take<float>(2 * (size_t)d->C7);
     w.bsum7 = c.take<double>((size_t)d->B * 3 * d->C7);
     const size_t wp8 = (size_t)wgrad_chunks(d->C8, d->C7, (int)P) * d->C8 * d->C7, wp7 = (size_t)wgrad_chunks(d->C7, d->F, (int)P) * d->C7 * d->F;
-    w.wpart = c.take<float>(wp8 > wp7 ? wp8 : wp7);
+    // (one buffer each: the three weight gradients of the tail are folded by ONE launch at the end of the backward)
+    w.wpart = c.take<float>(wp8);
+    w.wpart7 = c.take<float>(wp7);
     w.bytes = c.off;
     return w;
 }
@@ -1907,6 +1954,7 @@ extern "C" int dgcnn_head_tail_bwd(const dgcnn_head_tail_desc *d, const float *c
     const float *mean8 = s.stats8, *rstd8 = s.stats8 + C8, *sc8 = s.stats8 + 2 * (size_t)C8, *sh8 = s.stats8 + 3 * (size_t)C8;
 
     if (hipMemsetAsync(w.zero, 0, w.zero_words * sizeof(unsigned), st) != hipSuccess) DG_FAIL("dgcnn_head_tail_bwd: hipMemsetAsync failed");
+    int nch8 = 0, nch7 = 0;
     {   // classifier backward: dv8, dW9 records, BatchNorm-8 sums, tile maxima
         ClsArgs a{};
         a.u = s.u8, a.P = P, a.K = C8, a.nrb = nrb, a.nblk = cls_blocks(nrb);
@@ -1920,7 +1968,6 @@ extern "C" int dgcnn_head_tail_bwd(const dgcnn_head_tail_desc *d, const float *c
         } else {
             HF_CLS_DISPATCH(NC, hipLaunchKernelGGL((cls_bwd_fused_kernel<NCV, false>), dim3(a.nblk), dim3(256), 0, st, a));
         }
-        launch_sum_partials(w.pdw9, a.nblk, NC * C8, g->gw9, st);
         hipLaunchKernelGGL(bwd_finalize_kernel, dim3(ceil_div(C8, 64)), dim3(64 * FW), 0, st, w.pbn8, a.nblk, P, C8, d->training,
                            s.stats8, g->gbn8_w, g->gbn8_b, w.cc8, w.sb8);
     }
@@ -1962,7 +2009,7 @@ extern "C" int dgcnn_head_tail_bwd(const dgcnn_head_tail_desc *d, const float *c
         if (occ3()) hipLaunchKernelGGL((hwgrad_kernel<A_DU, B_BN, 3>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((hwgrad_kernel<A_DU, B_BN, 2>), grid, dim3(256), 0, st, a);
         prof_end(PROF_HEAD_DW8, st);
-        launch_sum_partials(w.wpart, nch, C8 * C7, g->gw8, st);
+        nch8 = nch;
     }
     if (nrb > 256) {
         hipLaunchKernelGGL(bwd_finalize_slots_kernel, dim3(ceil_div(C7, 64), d->B), dim3(64), 0, st, w.pdv7, nrb, d->B, d->N, C7,
@@ -1998,14 +2045,22 @@ extern "C" int dgcnn_head_tail_bwd(const dgcnn_head_tail_desc *d, const float *c
         a.slope = d->slope;
         a.ta = w.oa7, a.tb = w.ob7, a.sb = w.sb7, a.gi = nrb;
         a.amax_b = amax_cat;
-        a.partial = w.wpart;
+        a.partial = w.wpart7;
         const int nch = ceil_div(P, a.chunk);
         const dim3 grid((unsigned)align_up((size_t)ceil_div(C7, 128) * a.ntiles_n * nch, 8));
         prof_begin(PROF_HEAD_DW7, st);
         if (occ3()) hipLaunchKernelGGL((hwgrad_kernel<A_DU, B_RAW, 3>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((hwgrad_kernel<A_DU, B_RAW, 2>), grid, dim3(256), 0, st, a);
         prof_end(PROF_HEAD_DW7, st);
-        launch_sum_partials(w.wpart, nch, C7 * F, g->gw7c, st);
+        nch7 = nch;
+    }
+    {   // the three weight gradients' partials, folded by one launch
+        Fold3Args f{};
+        f.job[0] = FoldJob{w.pdw9, cls_blocks(nrb), NC * C8, g->gw9, 0};
+        f.job[1] = FoldJob{w.wpart, nch8, C8 * C7, g->gw8, ceil_div(NC * C8, 64)};
+        f.job[2] = FoldJob{w.wpart7, nch7, C7 * F, g->gw7c, f.job[1].first_block + ceil_div(C8 * C7, 64)};
+        f.njobs = 3;
+        hipLaunchKernelGGL(fold3_kernel, dim3(f.job[2].first_block + ceil_div(C7 * F, 64)), dim3(1024), 0, st, f);
     }
     DG_CHECK_LAUNCH("dgcnn_head_tail_bwd");
     return 0;

@@ -220,6 +220,13 @@ constexpr float KNN_AUG_K1 = 32768.0f, KNN_AUG_K2 = 16.0f, KNN_AUG_K3 = 0.007812
 constexpr float KNN_PAIR_SLACK = 2.1e-3f;
 // the same slack for SPLIT operands (C <= 4, see knn_prep_split4_kernel): the product is hi.hi + hi.lo + lo.hi of two-piece
 // fp16 operands -- the dropped lo.lo term, the rounding of lo and the fp32 accumulation are each below 2^-22 |x| |y|
+// WHILE lo is a normal fp16 number.  The prep kernel applies no power-of-two scaling, so for centred coordinates below
+// about 2^-3 (normalised clouds) lo is subnormal or zero and its rounding is ABSOLUTE: 2^-25 per element (fp16's subnormal
+// spacing 2^-24, halved), i.e. up to 2^-25 (|x| + |y|) per product term, which for |x| below about 0.03 exceeds this relative
+// slack.  That absolute term is covered by the LINEAR term of knn_f16_eps (1e-6 (|y_i| + sqrt(cmax)): 2^-25 = 3e-8 per
+// element times C <= 4 elements is 30 times smaller), and it relies on the matrix instruction not flushing fp16 subnormals
+// (gfx950's MFMA keeps them).  tests/test_knn_gpu.py::test_knn_small_c_filter_path_is_exact runs C <= 4 at scales 1e-1,
+// 1e-2, 1e-3 without an offset for exactly this range.
 constexpr float KNN_PAIR_SLACK_SPLIT = 4.0e-6f;
 constexpr float KNN_PAD_NORM = 1073741824.0f;  // 2^30: the "norm" of a padding candidate (never a neighbour, no inf - inf)
 constexpr float KNN_F16_CMAX = 1.0e8f;         // largest centred norm the fp16 streams accept (|T| stays below 2^31)

@@ -175,8 +175,12 @@ def sample_stride(args, steps):
     return max(1, -(-steps // (1 if steps <= 30 else 3)))
 
 
-def timed_steps(step, n, every, dev):
-    """EXACTLY n steps between two fences; `step(sampled)` with sampled=True on every `every`-th.  Returns the wall
+def timed_steps(step, n, every, dev, warmup=0):
+    """`warmup` untimed steps, then EXACTLY n steps between two fences; `step(sampled)` with sampled=True on every `every`-th.
+    The warm-up runs HERE, behind the garbage collection and directly in front of the first fence: with the collection (tens
+    of milliseconds of host time) or the creation of the profiling events between warm-up and region, the region started on a
+    GPU that had idled -- its first steps ran below the clocks of a loaded chip and a 20-step mean read 5 % above the per-step
+    median.  Returns the wall
     time (max over ranks) and this rank's host timeline of the region: `host_enqueue_ms` = the time the host took to
     enqueue the n steps (when it is close to `region_total_ms` the host, not the GPU, paced the region), `region_total_ms`
     = enqueue + the wait of the final fence."""
@@ -186,6 +190,8 @@ def timed_steps(step, n, every, dev):
     marks = []
     debug = bool(os.environ.get("DGCNN_BENCH_DEBUG"))
     try:
+        for _ in range(warmup):
+            step(False)
         fence()
         t0 = time.perf_counter()
         for i in range(n):
@@ -376,11 +382,10 @@ def run_block(args, rank, world, dev):
         if sampled:
             lib.dgcnn_profile_enable(0)
 
-    for _ in range(args.warmup):
-        step(False)
-    lib.dgcnn_profile_enable(1)  # reset the sample rings ...
+    lib.dgcnn_profile_enable(1)  # create the events, reset the sample rings ...
     lib.dgcnn_profile_enable(0)  # ... recording is switched on for the sampled steps only
-    dt, host = timed_steps(step, args.steps, sample_stride(args, args.steps), dev)
+    step(False)                  # (first call: code objects, allocator pools; NOT one of the counted warm-up steps)
+    dt, host = timed_steps(step, args.steps, sample_stride(args, args.steps), dev, args.warmup)
     knn_ms = sum(a.elapsed_time(b) for a, b in knn_events) / max(1, len(knn_events))
     regions = region_times(lib)
     dist_ms = per_step_ms(step, min(args.steps, 50))
@@ -566,11 +571,10 @@ def run_train(args, rank, world, dev, steps, warmup, with_cpu, global_batch=None
         if sampled:
             lib.dgcnn_profile_enable(0)
 
-    for _ in range(warmup):
-        step(False)
     lib.dgcnn_profile_enable(1)
     lib.dgcnn_profile_enable(0)
-    dt, host = timed_steps(step, steps, sample_stride(args, steps), dev)
+    step(False)                  # (first call: code objects, allocator pools; not one of the counted warm-up steps)
+    dt, host = timed_steps(step, steps, sample_stride(args, steps), dev, warmup)
     regions = region_times(lib)
     ar_ms = sum(a.elapsed_time(b) for a, b in ar_events) / max(1, len(ar_events))
     dist_ms = per_step_ms(step, min(steps, 20))

@@ -5,7 +5,7 @@ OUT=gpurun_out/pmc_l2
 rm -rf $OUT; mkdir -p $OUT
 rocprofv3 --list-avail 2>/dev/null | grep -o "TCP_TCC_READ_REQ_sum\|TCC_REQ_sum\|TCC_HIT_sum\|TCC_MISS_sum\|TCP_TOTAL_CACHE_ACCESSES_sum\|TCP_TCC_READ_REQ_LATENCY_sum" | sort -u > $OUT/avail.txt
 cat $OUT/avail.txt
-rocprofv3 --kernel-trace --pmc TCP_TCC_READ_REQ_sum TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum -d $OUT/a --output-format csv -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-train-leg > $OUT/a.log 2>&1
+rocprofv3 --kernel-trace --pmc TCP_TCC_READ_REQ_sum TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum -d $OUT/a --output-format csv -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-train-leg --no-model-legs --no-graph-leg > $OUT/a.log 2>&1
 python3 - <<'PY'
 import csv,glob,collections
 fs=glob.glob('gpurun_out/pmc_l2/a/**/*counter_collection.csv',recursive=True)

@@ -2,7 +2,7 @@
 # LDS bank-conflict share per kernel of the block workloads (one PMC pass each)   usage: scripts/pmc_lds_conflicts.sh <tag>
 export TMPDIR=/tmp
 O=gpurun_out/prof_lds_$1; rm -rf $O; mkdir -p $O
-B="--no-cpu-baseline --no-train-leg --steps 4 --warmup 2"
+B="--no-cpu-baseline --no-train-leg --no-model-legs --no-graph-leg --steps 4 --warmup 2"
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_BUSY_CYCLES -d $O/one --output-format csv -- python3 bench.py $B > $O/one.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_BUSY_CYCLES -d $O/two --output-format csv -- python3 bench.py $B --stages 2 > $O/two.log 2>&1
 python3 - <<PY

@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 TAG=$1
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
-B="--no-cpu-baseline --no-train-leg"
+B="--no-cpu-baseline --no-train-leg --no-model-legs --no-graph-leg"
 rocprofv3 --kernel-trace --stats -d $OUT/block --output-format csv -- python3 bench.py --steps 20 --warmup 3 $B > $OUT/block.log 2>&1
 echo block done
 rocprofv3 --kernel-trace --stats -d $OUT/two --output-format csv -- python3 bench.py --steps 20 --warmup 3 --stages 2 $B > $OUT/two.log 2>&1

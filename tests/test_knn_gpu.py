@@ -142,6 +142,11 @@ def test_knn_small_c_filter_path_is_exact(device):
             "offset_1000": base + 1000.0,
             "utm_like": base * 10.0 + np.array([5.0e5, 4.0e6, 50.0, 3.0, 0, 0, 0, 0], np.float32)[None, :C, None],
             "tiny": base * 1e-5,
+            # centred coordinates below 2^-3: the low fp16 piece of the two-piece operands is subnormal or zero there (an
+            # absolute rounding of 2^-25 per element, covered by the linear term of knn_f16_eps -- ADVICE round 3)
+            "scale_1e-1": base * 1e-1,
+            "scale_1e-2": base * 1e-2,
+            "scale_1e-3": base * 1e-3,
             "duplicates": np.concatenate([base[:, :, :600], base[:, :, :600]], axis=2),
             "clustered": base * 0.01 + rng.integers(0, 3, size=(2, 1, 1200)).astype(np.float32) * 7.0,
         }

@@ -378,3 +378,38 @@ def test_full_model_eval_at_stress_size(device):
         explained = ref(x, idx=[u.cpu().long() for u in used])
     err = float((own.cpu() - explained).abs().max())
     assert err <= 1e-4, "max |HIP logit - CPU restatement on the HIP graphs| = %.3g" % err
+
+
+def test_model_level_call_against_the_per_layer_path(device, monkeypatch):
+    """DGCNN.forward at depth 10 runs as dgcnn_model_fwd / _bwd (one call each way).  Three ways through the same kernels
+    must agree: (1) own kNN, the three graphs in ONE array -> the backward builds the three reverse lists in one go;
+    (2) the same graphs injected as three separate tensors -> per-block list builds: bit-identical to (1) (the lists are
+    sorted by edge id whoever builds them); (3) DGCNN_PER_LAYER=1: the per-layer entry points composed in Python, where the
+    gradient fan-in of x1 / x2 / x3 is added by autograd in another order: equal within rounding."""
+    from ahn3_dgcnn_pytorch_amd import DGCNN
+    g = torch.Generator().manual_seed(12)
+    B, N, k = 3, 260, 9
+    x = (torch.rand(B, N, 4, generator=g) * torch.tensor([30.0, 30.0, 20.0, 20.0])).permute(0, 2, 1).to(device)
+    m = DGCNN(5, 4, k, dropout=0.0, emb_dims=1024, cuda=True)
+    fill_module(m)
+    m.train()
+    R = cotangent((B, 5, N), tag="paths").to(device)
+
+    def run(idx):
+        m.zero_grad(set_to_none=True)
+        y, used = m(x, idx=idx, return_idx=True)
+        (y * R).sum().backward()
+        return y.detach().clone(), used, {n: p.grad.detach().clone() for n, p in m.named_parameters()}
+
+    y1, used, g1 = run(None)
+    assert used[1].data_ptr() == used[0].data_ptr() + 4 * used[0].numel()          # one array: the merged build ran
+    y2, _, g2 = run([u.clone() for u in used])
+    assert torch.equal(y1, y2)
+    for n in g1:
+        assert torch.equal(g1[n], g2[n]), n
+    monkeypatch.setenv("DGCNN_PER_LAYER", "1")
+    y3, _, g3 = run([u.clone() for u in used])
+    assert float((y3 - y1).abs().max()) <= 2e-5
+    for n in g1:
+        scale = float(g1[n].abs().max())
+        assert float((g3[n] - g1[n]).abs().max()) <= 1e-4 * scale + 2e-5, n

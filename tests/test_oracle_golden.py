@@ -32,6 +32,9 @@ def _host_factor():
 
 
 HOSTX = _host_factor()
+# a few head gradients vanish analytically (bn6.bias: |g| ~ 1e-7 of rounding noise, which another host's kernels produce
+# differently): on another host gradients get the absolute floor the GPU parity test uses
+GRAD_FLOOR = 0.0 if HOSTX == 1.0 else 2e-5
 
 
 def load(name):
@@ -96,12 +99,12 @@ def test_ref_model_train_step_matches_reference():
         if key.startswith("grad/"):
             want = g[key]
             got = params[key[5:]].grad.numpy()
-            np.testing.assert_allclose(got, want, rtol=0, atol=1e-5 * HOSTX * np.abs(want).max())
+            np.testing.assert_allclose(got, want, rtol=0, atol=1e-5 * HOSTX * np.abs(want).max() + GRAD_FLOOR)
             n += 1
         elif key.startswith("grad_sample/"):
             want = g[key]
             got = params[key[12:]].grad.numpy().reshape(-1)[::97]
-            np.testing.assert_allclose(got, want, rtol=0, atol=1e-5 * HOSTX * np.abs(want).max())
+            np.testing.assert_allclose(got, want, rtol=0, atol=1e-5 * HOSTX * np.abs(want).max() + GRAD_FLOOR)
             n += 1
     assert n == 25
 
