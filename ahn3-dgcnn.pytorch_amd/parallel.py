@@ -175,6 +175,20 @@ class FlatGradAllReduce:
         if src:
             torch._foreach_copy_(dst, src)
 
+    def _use_avg(self):
+        """RCCL averages inside the collective (ncclAvg); decided ONCE, by a one-element probe every rank runs at the same
+        point of its first exchange (a build without it: sum and scale instead)"""
+        if self._avg is None:
+            self._avg = False
+            if dist.get_backend(self.group) == "nccl":
+                try:
+                    probe = torch.ones(1, dtype=self.flat.dtype, device=self.flat.device)
+                    dist.all_reduce(probe, op=dist.ReduceOp.AVG, group=self.group)
+                    self._avg = True
+                except RuntimeError:
+                    self._avg = False
+        return self._avg
+
     def wants_overlap(self):
         return self.overlap and self.comm is None and self._tail is None and self.world_size > 1
 
@@ -193,9 +207,7 @@ class FlatGradAllReduce:
             work = dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self._tail = (off, work, h)
         else:
-            if self._avg is None:
-                self._avg = dist.get_backend(self.group) == "nccl"
-            op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+            op = dist.ReduceOp.AVG if self._use_avg() else dist.ReduceOp.SUM
             work = dist.all_reduce(tail, op=op, group=self.group, async_op=True)
             self._tail = (off, work, None)
         return True
@@ -218,7 +230,7 @@ class FlatGradAllReduce:
         if self._tail is not None:      # the tail is in flight since the backward: reduce the front, then join
             front = self.flat[:self._tail[0]]
             if front.numel():
-                if self._avg and not _host_staged(front, self.group):
+                if not _host_staged(front, self.group) and self._use_avg():
                     dist.all_reduce(front, op=dist.ReduceOp.AVG, group=self.group)
                 else:
                     all_reduce_sum(front, self.group)
@@ -230,14 +242,9 @@ class FlatGradAllReduce:
                 self.comm.all_reduce(self.flat, average=True)
             return self.flat
         if ws > 1:
-            if self._avg is None:
-                self._avg = dist.get_backend(self.group) == "nccl"  # RCCL averages inside the collective
-            if self._avg:
-                try:
-                    dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=self.group)
-                    return self.flat
-                except RuntimeError:  # a build without ncclAvg: sum and scale instead
-                    self._avg = False
+            if not _host_staged(self.flat, self.group) and self._use_avg():
+                dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=self.group)
+                return self.flat
             all_reduce_sum(self.flat, self.group)
             self.flat.div_(ws)
         return self.flat

@@ -380,7 +380,8 @@ def test_full_model_eval_at_stress_size(device):
     assert err <= 1e-4, "max |HIP logit - CPU restatement on the HIP graphs| = %.3g" % err
 
 
-def test_model_level_call_against_the_per_layer_path(device, monkeypatch):
+@pytest.mark.parametrize("F_,k,N,B", [(4, 9, 260, 3), (3, 20, 131, 2), (6, 33, 300, 1)])   # (the CLI's default is 3 features, k = 20)
+def test_model_level_call_against_the_per_layer_path(F_, k, N, B, device, monkeypatch):
     """DGCNN.forward at depth 10 runs as dgcnn_model_fwd / _bwd (one call each way).  Three ways through the same kernels
     must agree: (1) own kNN, the three graphs in ONE array -> the backward builds the three reverse lists in one go;
     (2) the same graphs injected as three separate tensors -> per-block list builds: bit-identical to (1) (the lists are
@@ -388,9 +389,8 @@ def test_model_level_call_against_the_per_layer_path(device, monkeypatch):
     gradient fan-in of x1 / x2 / x3 is added by autograd in another order: equal within rounding."""
     from ahn3_dgcnn_pytorch_amd import DGCNN
     g = torch.Generator().manual_seed(12)
-    B, N, k = 3, 260, 9
-    x = (torch.rand(B, N, 4, generator=g) * torch.tensor([30.0, 30.0, 20.0, 20.0])).permute(0, 2, 1).to(device)
-    m = DGCNN(5, 4, k, dropout=0.0, emb_dims=1024, cuda=True)
+    x = (torch.rand(B, N, F_, generator=g) * 20.0).permute(0, 2, 1).to(device)
+    m = DGCNN(5, F_, k, dropout=0.0, emb_dims=1024, cuda=True)
     fill_module(m)
     m.train()
     R = cotangent((B, 5, N), tag="paths").to(device)
