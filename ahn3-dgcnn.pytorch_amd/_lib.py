@@ -10,7 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdgcnn_hip.so")
+# (DGCNN_HIP_LIB: another build of the same library -- ablation builds of scripts/ablate_rgather.sh; never a fallback)
+LIB_PATH = os.environ.get("DGCNN_HIP_LIB") or os.path.join(_HERE, "libdgcnn_hip.so")
 
 _c_int, _c_i64, _c_sz, _c_vp, _c_f = ctypes.c_int, ctypes.c_int64, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_float
 

@@ -702,7 +702,11 @@ __device__ __forceinline__ void rgather_segment(const __amdgpu_buffer_rsrc_t TQb
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int i = __builtin_amdgcn_readlane(src, t + u);
+#ifdef DGCNN_ABL_RGATHER_NOTQ   // ablation (times only, results invalid): the pass without its TQ row gathers
+            q[u] = (float)i;
+#else
             q[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(TQb, lane * 4, (int)((unsigned)i * (unsigned)(EC * 4)), 0));  // scalar row offset
+#endif
             if (DENSE) d[u] = __builtin_nontemporal_load(&(dv + (size_t)(unsigned)__builtin_amdgcn_readlane(ev, t + u) * EC)[(unsigned)lane]);
         }
 #pragma unroll
@@ -723,7 +727,11 @@ __device__ __forceinline__ void rgather_segment(const __amdgpu_buffer_rsrc_t TQb
         for (int u = 0; u < 8; ++u) {
             const int tt = t + u < cnt ? t + u : t;  // clamped: no branch around the loads
             const int i = __builtin_amdgcn_readlane(src, tt);
+#ifdef DGCNN_ABL_RGATHER_NOTQ
+            q[u] = (float)i;
+#else
             q[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(TQb, lane * 4, (int)((unsigned)i * (unsigned)(EC * 4)), 0));
+#endif
             // (dv1 rows are read once: streamed past the L2 that holds the TQ table)
             if (DENSE) d[u] = __builtin_nontemporal_load(&(dv + (size_t)(unsigned)__builtin_amdgcn_readlane(ev, tt) * EC)[(unsigned)lane]);
         }
@@ -866,11 +874,13 @@ __global__ __launch_bounds__(256) void edge_rgather_kernel(const float *__restri
             const int ev = lane < cnt ? rev[pbeg + e0 + lane] : 0;
             u64 hm = 0;
             float4 rec = float4{0.0f, 0.0f, 0.0f, 0.0f};
+#ifndef DGCNN_ABL_RGATHER_NOREC   // ablation (times only, results invalid): the pass without its hit-record reads
             if (!DENSE && lane < cnt) {
                 const HitRec *h = hits + ev;
                 hm = h->mask;
                 rec = *reinterpret_cast<const float4 *>(h->v);
             }
+#endif
             float sq, sd;
             rgather_segment<DENSE>(TQb, k, dv, hits, G, cnt, ev, hm, rec, sacc, lane, sq, sd);
             rgather_publish(cx, pt, seg, deg, sq, sd, lane);
@@ -915,11 +925,13 @@ __global__ __launch_bounds__(256) void edge_rgather_kernel(const float *__restri
         const int cnt = deg < REV_SEG ? deg : REV_SEG;
         u64 hm = 0;
         float4 rec = float4{0.0f, 0.0f, 0.0f, 0.0f};
+#ifndef DGCNN_ABL_RGATHER_NOREC
         if (!DENSE && lane < cnt) {
             const HitRec *h = hits + ev;
             hm = h->mask;
             rec = *reinterpret_cast<const float4 *>(h->v);
         }
+#endif
         float sq, sd;
         rgather_segment<DENSE>(TQb, k, dv, hits, G, cnt, ev, hm, rec, sacc, lane, sq, sd);
         if (deg <= REV_SEG) {
