@@ -55,11 +55,10 @@ void launch_sum_partials(const float *partial, int nchunk, int n, float *out, hi
 // x, y, gy, gx: row strides in floats of the block's input, output, output gradient and input gradient when those are
 // column slices of wider rows; gx_acc: the input gradient is added to its slice instead of overwriting it.  The second
 // convolution's backward takes gy == y == 64 or 192 only.
-// gy2 / gysum: dL/dy = gy + gy2 with gy2 dense [P][64]; the first kernel of the backward leaves the sum in gysum [P][64]
+// gy2: dL/dy = gy + gy2 with gy2 dense [P][64] (added by the first kernel of the backward)
 struct EdgeLd {
     int x, y, gy, gx, gx_acc;
     const float *gy2;
-    float *gysum;
 };
 int edgeconv_fwd_ld(const dgcnn_edgeconv_desc *d, const EdgeLd &ld, const float *x, const int32_t *idx, float *y, void *saved,
                     void *workspace, size_t workspace_bytes, void *stream);
@@ -102,8 +101,7 @@ void launch_edge_out(const float *usel, const float *stats, float slope, int P, 
 struct RevSlotsArgs;
 void launch_bwd_point(const float *gy, const float *usel, const float *stats, float slope, int P, double count,
                       int training, const FoldSet &fs, float *gbn_w, float *gbn_b, float *cc, unsigned *gmax_bits,
-                      const struct RevSlotsArgs *slots, hipStream_t st, int ldgy = 0, const float *gy2 = nullptr,
-                      float *gysum = nullptr);
+                      const struct RevSlotsArgs *slots, hipStream_t st, int ldgy, const float *gy2, float *gdv);
 // Reverse adjacency of the neighbour graph (depends on idx only), every list sorted by edge id.  Scratch: cnt
 // [B * rev_chunks][N]; results: rowptr [P] (list start), indeg [P], segbase [P], pcnt [P] (zeroed), rev [E], alloc [2]
 // (alloc[1] = number of extra (point, segment) pairs), extra [2 (E / REV_SEG + 1)] ints.  The first kernel also zeroes
@@ -146,15 +144,14 @@ struct SumRider {
     int main_blocks;
 };
 // stage-1 backward as a gather over the reverse lists (see edge_stream.hip): dR and dD are overwritten.
-// dv == NULL: sparse dv from (gy, y, hitj) -- hits [E] x 32 bytes and G [P][64] are scratch; else dense dv [E][64] with
+// dv == NULL: sparse dv from (gdv = dL/dy . LReLU'(y) as launch_bwd_point leaves it, hitj) -- hits [E] x 32 bytes and G [P][64] are scratch; else dense dv [E][64] with
 // dvsum [P][64] = its sums over k.  part0 [P][128], partx [E / REV_SEG + 1][128] floats: segment partials of long lists.
 // cc = 0 (eval mode) drops the BatchNorm mean terms.
 int launch_edge_bwd(const float *TP, const float *TQ, int B, int N, int k, const float *stats, const float *cc, float slope,
-                    const float *gy, const float *y, const uint8_t *hitj, const float *usum, const float *dv,
+                    const float *gdv, const uint8_t *hitj, const float *usum, const float *dv,
                     const float *dvsum, const int *rowptr, const int *indeg, const int *segbase, int *pcnt,
                     const int32_t *rev, const int *alloc, const int *extra, void *hits, float *G, float *part0,
-                    float *partx, float *dR, float *dD, hipStream_t st, int ldgy = 0, int ldy = 0,
-                    const struct SumRider *rider = nullptr);
+                    float *partx, float *dR, float *dD, hipStream_t st, const struct SumRider *rider = nullptr);
 void launch_graph_feature_fwd(const float *x, const int32_t *idx, int B, int N, int C, int k, float *out,
                               hipStream_t st);
 void launch_graph_feature_bwd(const float *gout, const int *rowptr, const int *indeg, const int32_t *rev, int B, int N,
@@ -176,8 +173,8 @@ void launch_edge_mlp_fwd(const float *TP, const float *TQ, const int32_t *idx, i
 // leaves the fp16 range, in which case the fp32 form of the pass (fold counters fs_fallback) redoes it in the same call
 int launch_edge_mlp_bwd(const float *TP, const float *TQ, const int32_t *idx, int N, int k, int P,
                          const float *stats1, const float *stats2, const float *cc2, const float *w2, float slope,
-                         int training, const float *gy, const float *y, const uint8_t *hit2, const unsigned *gmax_bits,
+                         int training, const float *gdv, const uint8_t *hit2, const unsigned *gmax_bits,
                          float *dv1, float *dvsum, float *partial_dw2, const FoldSet &fs, const FoldSet &fs_fallback,
-                         const BnBackwardSums &fin1, int *guard, hipStream_t st, int ldgy = 0, int ldy = 0);
+                         const BnBackwardSums &fin1, int *guard, hipStream_t st);
 
 }  // namespace dgcnn

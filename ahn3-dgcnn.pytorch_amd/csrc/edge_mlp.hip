@@ -168,8 +168,8 @@ __global__ __launch_bounds__(256) void edge_mlp_fwd_f32_kernel(const float *__re
 __global__ __launch_bounds__(512) void edge_mlp_bwd_f32_kernel(
     const float *__restrict__ TP, const float *__restrict__ TQ, const int32_t *__restrict__ idx, int N, int k, int P,
     const float *__restrict__ stats1, const float *__restrict__ stats2, const float *__restrict__ cc2,
-    const float *__restrict__ w2, float slope, int training, const float *__restrict__ gy, int ldgy,
-    const float *__restrict__ y, int ldy, const uint8_t *__restrict__ hit2, float *__restrict__ dv1,
+    const float *__restrict__ w2, float slope, int training, const float *__restrict__ gdv,
+    const uint8_t *__restrict__ hit2, float *__restrict__ dv1,
     float *__restrict__ dvsum, float *__restrict__ partial_dw2, FoldSet fs, BnBackwardSums fin1,
     const int *__restrict__ guard)
 {
@@ -228,8 +228,7 @@ __global__ __launch_bounds__(512) void edge_mlp_bwd_f32_kernel(
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             hit[nt] = hit2[(size_t)pt * EC + nt * 32 + i32];
-            dvs[nt] = sc2[nt] * gy[(size_t)pt * ldgy + nt * 32 + i32] *
-                      (y[(size_t)pt * ldy + nt * 32 + i32] > 0.0f ? 1.0f : slope);
+            dvs[nt] = sc2[nt] * gdv[(size_t)pt * EC + nt * 32 + i32];  // gdv = dL/dy . LReLU'(y) (bwd_point_kernel)
         }
         for (int j0 = 0; j0 < k; j0 += 32) {
             const int kk = k - j0 < 32 ? k - j0 : 32;
@@ -374,33 +373,30 @@ void launch_edge_mlp_fwd(const float *TP, const float *TQ, const int32_t *idx, i
     prof_end(PROF_EDGE_MLP_FWD, st);
 }
 
-int launch_edge_mlp_bwd16(const float *TP, const float *TQ, const int32_t *idx, int N, int k, int P, const float *stats1,
-                          const float *stats2, const float *cc2, const float *w2, float slope, int training,
-                          const float *gy, int ldgy, const float *y, int ldy, const uint8_t *hit2, const unsigned *gmax_bits,
-                          float *dv1, float *dvsum, float *partial_dw2, const FoldSet &fs, const BnBackwardSums &fin1, int *guard,
-                          int grid, hipStream_t st);  // edge_mlp_bwd16.hip
+void launch_edge_mlp_bwd16(const float *TP, const float *TQ, const int32_t *idx, int N, int k, int P, const float *stats1,
+                           const float *stats2, const float *cc2, const float *w2, float slope, int training,
+                           const float *gdv, const uint8_t *hit2, const unsigned *gmax_bits, float *dv1,
+                           float *dvsum, float *partial_dw2, const FoldSet &fs, const BnBackwardSums &fin1, int *guard,
+                           int grid, hipStream_t st);  // edge_mlp_bwd16.hip
 
 int launch_edge_mlp_bwd(const float *TP, const float *TQ, const int32_t *idx, int N, int k, int P,
-                         const float *stats1, const float *stats2, const float *cc2, const float *w2, float slope,
-                         int training, const float *gy, const float *y, const uint8_t *hit2, const unsigned *gmax_bits,
-                         float *dv1, float *dvsum, float *partial_dw2, const FoldSet &fs, const FoldSet &fs_fallback,
-                         const BnBackwardSums &fin1, int *guard, hipStream_t st, int ldgy, int ldy)
+                        const float *stats1, const float *stats2, const float *cc2, const float *w2, float slope,
+                        int training, const float *gdv, const uint8_t *hit2, const unsigned *gmax_bits,
+                        float *dv1, float *dvsum, float *partial_dw2, const FoldSet &fs, const FoldSet &fs_fallback,
+                        const BnBackwardSums &fin1, int *guard, hipStream_t st)
 {
-    if (ldgy <= 0) ldgy = EC;
-    if (ldy <= 0) ldy = EC;
     static const int force32 = getenv("DGCNN_MLP_BWD_F32") ? atoi(getenv("DGCNN_MLP_BWD_F32")) : 0;  // experiments / tests
     const dim3 grid(mlp_grid(P)), block(64 * MLP_BWD_WAVES);
     prof_begin(PROF_EDGE_MLP_BWD, st);
     if (force32) {
         hipLaunchKernelGGL(edge_mlp_bwd_f32_kernel, grid, block, 0, st, TP, TQ, idx, N, k, P, stats1, stats2, cc2, w2, slope,
-                           training, gy, ldgy, y, ldy, hit2, dv1, dvsum, partial_dw2, fs, fin1, (const int *)nullptr);
+                           training, gdv, hit2, dv1, dvsum, partial_dw2, fs, fin1, (const int *)nullptr);
     } else {
-        if (launch_edge_mlp_bwd16(TP, TQ, idx, N, k, P, stats1, stats2, cc2, w2, slope, training, gy, ldgy, y, ldy, hit2, gmax_bits, dv1,
-                                  dvsum, partial_dw2, fs, fin1, guard, (int)grid.x, st))
-            return 1;
+        launch_edge_mlp_bwd16(TP, TQ, idx, N, k, P, stats1, stats2, cc2, w2, slope, training, gdv, hit2, gmax_bits, dv1,
+                              dvsum, partial_dw2, fs, fin1, guard, (int)grid.x, st);
         // the fp32 form of the same pass: returns at once unless the fp16 kernel raised *guard
         hipLaunchKernelGGL(edge_mlp_bwd_f32_kernel, grid, block, 0, st, TP, TQ, idx, N, k, P, stats1, stats2, cc2, w2, slope,
-                           training, gy, ldgy, y, ldy, hit2, dv1, dvsum, partial_dw2, fs_fallback, fin1, (const int *)guard);
+                           training, gdv, hit2, dv1, dvsum, partial_dw2, fs_fallback, fin1, (const int *)guard);
     }
     prof_end(PROF_EDGE_MLP_BWD, st);
     return 0;

@@ -27,15 +27,14 @@ namespace dgcnn {
 // half h, element j  <->  edge row mfma32_row(8 s + j, h) = 16 s + 8 (j >> 2) + 4 h + (j & 3) -- so that du2, which the
 // u2 product leaves in accumulator registers (lane = channel, registers = edge rows), is the A operand of the weight
 // gradient as it stands, and the other operand is two 8-byte row reads of the a1' image (edges 16 s + 8 u + 4 h .. + 3).
-// LDG, LDY: row strides (floats) of gy and y -- 64 (dense rows) or 192 (64-column slices of the model's [P][192]
-// concatenation); template parameters because the kernel sits at its register limit (two more scalar arguments cost 16
-// bytes of scratch)
-template <bool S01, int LDG, int LDY>
+// gdv [P][64] = dL/dy . LReLU'(y) of the block's output, left dense by bwd_point_kernel (round 4: one row per point instead of
+// a row of dL/dy and a row of y, which in the model are 64-column slices of 192-wide rows)
+template <bool S01>
 __global__ __launch_bounds__(512) void edge_mlp_bwd16_kernel(
     const float *__restrict__ TP, const float *__restrict__ TQ, const int32_t *__restrict__ idx, int N, int k, int P,
     const float *__restrict__ stats1, const float *__restrict__ stats2, const float *__restrict__ cc2,
-    const float *__restrict__ w2, float slope, int training, const float *__restrict__ gy,
-    const float *__restrict__ y, const uint8_t *__restrict__ hit2, const unsigned *__restrict__ gmax_bits,
+    const float *__restrict__ w2, float slope, int training, const float *__restrict__ gdv,
+    const uint8_t *__restrict__ hit2, const unsigned *__restrict__ gmax_bits,
     float *__restrict__ dv1, float *__restrict__ dvsum, float *__restrict__ partial_dw2, FoldSet fs,
     BnBackwardSums fin1, int *__restrict__ guard)
 {
@@ -141,8 +140,7 @@ __global__ __launch_bounds__(512) void edge_mlp_bwd16_kernel(
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             hit[nt] = (int)hit2[(size_t)pt * EC + nt * 32 + i32] - 4 * h;  // relative to this lane half's rows
-            dvs[nt] = sD * sc2[nt] * gy[(size_t)pt * LDG + nt * 32 + i32] *
-                      (y[(size_t)pt * LDY + nt * 32 + i32] > 0.0f ? 1.0f : slope);
+            dvs[nt] = sD * sc2[nt] * gdv[(size_t)pt * EC + nt * 32 + i32];
         }
         for (int j0 = 0; j0 < k; j0 += 32) {
             const int kk = k - j0 < 32 ? k - j0 : 32;
@@ -343,30 +341,18 @@ __global__ __launch_bounds__(512) void edge_mlp_bwd16_kernel(
 }
 
 
-int launch_edge_mlp_bwd16(const float *TP, const float *TQ, const int32_t *idx, int N, int k, int P, const float *stats1,
-                          const float *stats2, const float *cc2, const float *w2, float slope, int training,
-                          const float *gy, int ldgy, const float *y, int ldy, const uint8_t *hit2, const unsigned *gmax_bits,
-                          float *dv1, float *dvsum, float *partial_dw2, const FoldSet &fs, const BnBackwardSums &fin1, int *guard,
-                          int grid, hipStream_t st)
+void launch_edge_mlp_bwd16(const float *TP, const float *TQ, const int32_t *idx, int N, int k, int P, const float *stats1,
+                           const float *stats2, const float *cc2, const float *w2, float slope, int training,
+                           const float *gdv, const uint8_t *hit2, const unsigned *gmax_bits, float *dv1,
+                           float *dvsum, float *partial_dw2, const FoldSet &fs, const BnBackwardSums &fin1, int *guard,
+                           int grid, hipStream_t st)
 {
-    DG_REQUIRE((ldgy == 64 || ldgy == 192) && (ldy == 64 || ldy == 192) && !(ldgy == 192 && ldy == 64),
-               "edge_mlp_bwd16: row strides of (gy, y) must be (64, 64), (64, 192) or (192, 192) (got %d, %d)", ldgy, ldy);
-    const bool s01 = slope >= 0.0f && slope <= 1.0f;
-#define DG_BWD16(S01_, LDG_, LDY_)                                                                                                     \
-    hipLaunchKernelGGL((edge_mlp_bwd16_kernel<S01_, LDG_, LDY_>), dim3(grid), dim3(64 * MLP_BWD_WAVES), 0, st, TP, TQ, idx, N, k, P, stats1, \
-                       stats2, cc2, w2, slope, training, gy, y, hit2, gmax_bits, dv1, dvsum, partial_dw2, fs, fin1, guard)
-    if (ldy == 64) {
-        if (s01) DG_BWD16(true, 64, 64);
-        else DG_BWD16(false, 64, 64);
-    } else if (ldgy == 64) {
-        if (s01) DG_BWD16(true, 64, 192);
-        else DG_BWD16(false, 64, 192);
-    } else {
-        if (s01) DG_BWD16(true, 192, 192);
-        else DG_BWD16(false, 192, 192);
-    }
-#undef DG_BWD16
-    return 0;
+    if (slope >= 0.0f && slope <= 1.0f)
+        hipLaunchKernelGGL(edge_mlp_bwd16_kernel<true>, dim3(grid), dim3(64 * MLP_BWD_WAVES), 0, st, TP, TQ, idx, N, k, P, stats1,
+                           stats2, cc2, w2, slope, training, gdv, hit2, gmax_bits, dv1, dvsum, partial_dw2, fs, fin1, guard);
+    else
+        hipLaunchKernelGGL(edge_mlp_bwd16_kernel<false>, dim3(grid), dim3(64 * MLP_BWD_WAVES), 0, st, TP, TQ, idx, N, k, P, stats1,
+                           stats2, cc2, w2, slope, training, gdv, hit2, gmax_bits, dv1, dvsum, partial_dw2, fs, fin1, guard);
 }
 
 }  // namespace dgcnn

@@ -259,10 +259,11 @@ __device__ __forceinline__ void rev_slots_pass(const RevSlotsArgs &a, int block)
 // sums over points of quantities at the selected extreme.  The pass finishes
 // the sums itself (fold.h): gbn_b, gbn_w and the two mean terms cc.
 // gy2 != NULL: dL/dy = gy + gy2 (gy2 dense [P][64]: the second gradient that reaches the block's output -- the next block's
-// input gradient); the sum is left in gysum [P][64] for the kernels behind this one (one extra stream here instead of a
-// read-modify-write of the strided slice in the product that makes gy2: 8 -> 22 us there at P = 28 000).
+// input gradient: one extra stream here instead of a read-modify-write of the strided slice in the product that makes gy2:
+// 8 -> 22 us there at P = 28 000).  gdv [P][64] <- dL/dy . LReLU'(y) (y > 0 <=> sc usel + sh > 0): what every kernel behind
+// this one needs of (dL/dy, y) -- they read ONE dense row per point instead of two rows that may be column slices of wider ones.
 __global__ __launch_bounds__(256) void bwd_point_kernel(const float *__restrict__ gy, int ldgy, const float *__restrict__ gy2,
-                                                        float *__restrict__ gysum, const float *__restrict__ usel,
+                                                        float *__restrict__ gdv, const float *__restrict__ usel,
                                                         const float *__restrict__ stats, float slope, int P,
                                                         FoldSet fs, BnBackwardSums fin, unsigned *__restrict__ gmax_bits,
                                                         int nbp, RevSlotsArgs slots)
@@ -283,20 +284,26 @@ __global__ __launch_bounds__(256) void bwd_point_kernel(const float *__restrict_
     constexpr int INF = 16;
     const int stride = nbp * EDGE_WAVES;
     for (int pt = blockIdx.x * EDGE_WAVES + wave; pt < P; pt += INF * stride) {
-        float us[INF], g4[INF];
+        float us[INF], g4[INF], g2[INF];
 #pragma unroll
         for (int u = 0; u < INF; ++u) {
             const int p = pt + u * stride < P ? pt + u * stride : pt;  // clamped: the load is unconditional, the value masked
             us[u] = usel[(size_t)p * EC + lane];
             g4[u] = gy[(size_t)p * ldgy + lane];
-            if (gy2) g4[u] += gy2[(size_t)p * EC + lane];
+            // (its own register: added below, behind ALL the loads -- as `g4[u] += gy2[..]` here the sum waited for its two loads
+            // before the next point's were issued: 100 us against 51 without the second addend at B = 32)
+            g2[u] = gy2 ? gy2[(size_t)p * EC + lane] : 0.0f;
         }
+#pragma unroll
+        for (int u = 0; u < INF; ++u) g4[u] += g2[u];
 #pragma unroll
         for (int u = 0; u < INF; ++u) {
             if (pt + u * stride < P) {  // (uniform; added in point order)
-                if (gy2) gysum[(size_t)(pt + u * stride) * EC + lane] = g4[u];
                 const float v = __builtin_fmaf(us[u], sc, sh);
                 const float dv = g4[u] * (v > 0.0f ? 1.0f : slope);
+                // (streamed: 57 MB at B = 32 that nothing reads before the list kernels behind this one have run -- kept in
+                // L2 they crowd out the merging of the placement pass's scattered stores: rev_place 87 -> 111 us per launch)
+                __builtin_nontemporal_store(dv, &gdv[(size_t)(pt + u * stride) * EC + lane]);
                 const float uhat = (us[u] - mean) * rstd;
                 acc[0] += (double)dv;
                 acc[1] = __builtin_fma((double)dv, (double)uhat, acc[1]);
@@ -593,8 +600,7 @@ template <bool DENSE>
 __global__ __launch_bounds__(256) void edge_point_bwd_kernel(const float *__restrict__ TQ, int k, int P,
                                                              const float *__restrict__ stats,
                                                              const float *__restrict__ cc, float slope,
-                                                             const float *__restrict__ gy, int ldgy,
-                                                             const float *__restrict__ y, int ldy,
+                                                             const float *__restrict__ gdv,
                                                              const uint8_t *__restrict__ hitj,
                                                              const float *__restrict__ usum,
                                                              const float *__restrict__ dv, HitRec *__restrict__ hits,
@@ -642,8 +648,7 @@ __global__ __launch_bounds__(256) void edge_point_bwd_kernel(const float *__rest
         if (DENSE) {
             dsum = sc * dv[o];
         } else {
-            const float yv = y[(size_t)pt * ldy + lane];
-            dsum = sc * gy[(size_t)pt * ldgy + lane] * (yv > 0.0f ? 1.0f : slope);
+            dsum = sc * gdv[o];  // gdv = dL/dy . LReLU'(y), left by bwd_point_kernel
             G[o] = dsum;
             const int hj = hitj[o];
             sm[lane] = 0;
@@ -944,14 +949,12 @@ __global__ __launch_bounds__(256) void edge_rgather_kernel(const float *__restri
 }
 
 int launch_edge_bwd(const float *TP, const float *TQ, int B, int N, int k, const float *stats, const float *cc, float slope,
-                    const float *gy, const float *y, const uint8_t *hitj, const float *usum, const float *dv,
+                    const float *gdv, const uint8_t *hitj, const float *usum, const float *dv,
                     const float *dvsum, const int *rowptr, const int *indeg, const int *segbase, int *pcnt,
                     const int32_t *rev, const int *alloc, const int *extra, void *hits, float *G, float *part0,
-                    float *partx, float *dR, float *dD, hipStream_t st, int ldgy, int ldy, const SumRider *rider)
+                    float *partx, float *dR, float *dD, hipStream_t st, const SumRider *rider)
 {
     const int P = B * N;
-    if (ldgy <= 0) ldgy = EC;
-    if (ldy <= 0) ldy = EC;
     DG_REQUIRE((size_t)P * EC * 4 < ((size_t)1 << 32), "edge backward: B * N = %d points exceed the 4 GB row-offset range of the TQ gather", P);
     const dim3 grid(stream_grid(P)), block(256);
     // (measured: the placement pass of the reverse adjacency as extra workgroups of this launch -- as the list-space
@@ -962,10 +965,10 @@ int launch_edge_bwd(const float *TP, const float *TQ, int B, int N, int k, const
         SumRider sr = rider ? *rider : SumRider{nullptr, 0, 0, nullptr, 0};
         sr.main_blocks = (int)grid.x;
         hipLaunchKernelGGL((edge_point_bwd_kernel<true>), dim3(grid.x + (sr.out ? ceil_div(sr.n, 64) : 0)), block, 0, st, TQ, k, P, stats,
-                           cc, slope, gy, ldgy, y, ldy, hitj, usum, dvsum, (HitRec *)hits, G, dD, sr);
+                           cc, slope, gdv, hitj, usum, dvsum, (HitRec *)hits, G, dD, sr);
     }
     else
-        hipLaunchKernelGGL((edge_point_bwd_kernel<false>), grid, block, 0, st, TQ, k, P, stats, cc, slope, gy, ldgy, y, ldy, hitj, usum,
+        hipLaunchKernelGGL((edge_point_bwd_kernel<false>), grid, block, 0, st, TQ, k, P, stats, cc, slope, gdv, hitj, usum,
                            nullptr, (HitRec *)hits, G, dD, SumRider{nullptr, 0, 0, nullptr, 0});
     prof_begin(PROF_EDGE_RGATHER, st);
     // one launch: the point workgroups and, behind them, workgroups for the extra segments of the long lists
@@ -1051,7 +1054,7 @@ void launch_edge_out(const float *usel, const float *stats, float slope, int P, 
 
 void launch_bwd_point(const float *gy, const float *usel, const float *stats, float slope, int P, double count,
                       int training, const FoldSet &fs, float *gbn_w, float *gbn_b, float *cc, unsigned *gmax_bits,
-                      const RevSlotsArgs *slots, hipStream_t st, int ldgy, const float *gy2, float *gysum)
+                      const RevSlotsArgs *slots, hipStream_t st, int ldgy, const float *gy2, float *gdv)
 {
     int grid = ceil_div(P, EDGE_WAVES * 8);
     if (grid > 512) grid = 512;
@@ -1059,7 +1062,7 @@ void launch_bwd_point(const float *gy, const float *usel, const float *stats, fl
     // (slots: the list-space pass of the reverse adjacency rides behind this pass's workgroups, see rev_slots_pass)
     const RevSlotsArgs none{0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0, 0, 0};
     const int extra_wgs = slots ? slots->nblk * ceil_div(slots->Pblk, 256) : 0;
-    hipLaunchKernelGGL(bwd_point_kernel, dim3(grid + extra_wgs), dim3(256), 0, st, gy, ldgy > 0 ? ldgy : EC, gy2, gysum, usel, stats,
+    hipLaunchKernelGGL(bwd_point_kernel, dim3(grid + extra_wgs), dim3(256), 0, st, gy, ldgy > 0 ? ldgy : EC, gy2, gdv, usel, stats,
                        slope, P, fs, fin, gmax_bits, grid, slots ? *slots : none);
 }
 

@@ -93,7 +93,7 @@ static FwdWs fwd_ws(const dgcnn_edgeconv_desc *d, void *p)
 struct BwdWs {
     int *zero;  // [Z_WORDS]: fold counters, list allocation
     FoldBufs fa, fb;
-    float *cc1, *cc2, *dR, *dD, *wg_partial, *dv1, *dvsum, *dw2_partial, *G, *part0, *partx;
+    float *cc1, *cc2, *dR, *dD, *wg_partial, *dv1, *dvsum, *dw2_partial, *G, *part0, *partx, *gdv;
     int *cnt, *indeg, *rowptr, *segbase, *pcnt, *rev, *extra;  // reverse adjacency of the neighbour graph
     void *hits;
     size_t bytes;
@@ -110,6 +110,7 @@ static BwdWs bwd_ws(const dgcnn_edgeconv_desc *d, void *p)
     w.cc2 = c.take<float>(128);
     w.dR = c.take<float>(P * EC);
     w.dD = c.take<float>(P * EC);
+    w.gdv = c.take<float>(P * EC);   // dL/dy . LReLU'(y), left by bwd_point for every kernel behind it
     w.wg_partial = c.take<float>((size_t)wgrad_chunks((int)P, d->C) * 128 * d->C);
     w.cnt = c.take<int>((size_t)d->B * rev_chunks(d->B, d->N, d->k) * d->N);
     w.indeg = c.take<int>(P);
@@ -191,7 +192,7 @@ extern "C" size_t dgcnn_edgeconv_bwd_workspace_bytes(const dgcnn_edgeconv_desc *
 extern "C" int dgcnn_edgeconv_fwd(const dgcnn_edgeconv_desc *d, const float *x, const int32_t *idx, float *y,
                                   void *saved, void *workspace, size_t workspace_bytes, void *stream)
 {
-    return edgeconv_fwd_ld(d, EdgeLd{0, 0, 0, 0, 0, nullptr, nullptr}, x, idx, y, saved, workspace, workspace_bytes, stream);
+    return edgeconv_fwd_ld(d, EdgeLd{0, 0, 0, 0, 0, nullptr}, x, idx, y, saved, workspace, workspace_bytes, stream);
 }
 
 // the forward with row strides: x and y may be 64-column slices of wider rows (model.hip: the [P][192] concatenation of the
@@ -239,7 +240,7 @@ extern "C" int dgcnn_edgeconv_bwd(const dgcnn_edgeconv_desc *d, const float *x, 
                                   const float *gy, const void *saved, const dgcnn_edgeconv_grads *g, void *workspace,
                                   size_t workspace_bytes, void *stream)
 {
-    return edgeconv_bwd_ld(d, EdgeLd{0, 0, 0, 0, 0, nullptr, nullptr}, x, idx, y, gy, saved, g, workspace, workspace_bytes, stream, nullptr);
+    return edgeconv_bwd_ld(d, EdgeLd{0, 0, 0, 0, 0, nullptr}, x, idx, y, gy, saved, g, workspace, workspace_bytes, stream, nullptr);
 }
 
 // the backward with row strides (x, y, gy, gx as 64-column slices of wider rows) and, with ld.gx_acc, gx ADDED to what the
@@ -261,10 +262,6 @@ int dgcnn::edgeconv_bwd_ld(const dgcnn_edgeconv_desc *d, const EdgeLd &ld, const
     hipStream_t st = (hipStream_t)stream;
     const int P = d->B * d->N, N = d->N, C = d->C, k = d->k;
     const double E = (double)P * k;
-    DG_REQUIRE(!ld.gy2 || ld.gysum, "dgcnn_edgeconv_bwd: a second output gradient needs room for the sum");
-    // the kernels behind bwd_point read dL/dy from gyk with row stride ldk: the caller's, or the sum bwd_point leaves
-    const float *gyk = ld.gy2 ? ld.gysum : gy;
-    const int ldk = ld.gy2 ? EC : ld.gy;
     if (pre) {  // the lists exist (launch_rev_build_merged, which has also zeroed the call's counters)
         w.zero = pre->zero, w.indeg = pre->indeg, w.rowptr = pre->rowptr, w.segbase = pre->segbase, w.pcnt = pre->pcnt;
         w.rev = pre->rev, w.extra = pre->extra;
@@ -282,27 +279,27 @@ int dgcnn::edgeconv_bwd_ld(const dgcnn_edgeconv_desc *d, const EdgeLd &ld, const
     const FoldSet fsa{w.fa.rec, w.fa.folded, w.zero + Z_FOLD_A}, fsb{w.fb.rec, w.fb.folded, w.zero + Z_FOLD_B};
     if (d->n_stage == 1) {
         launch_bwd_point(gy, s.usel, s.stats1, d->slope, P, E, d->training, fsa, g->gbn1_w, g->gbn1_b, w.cc1, nullptr, slots, st,
-                         ld.gy, ld.gy2, ld.gysum);
+                         ld.gy, ld.gy2, w.gdv);
         if (!pre && launch_rev_place(idx, d->B, N, k, w.cnt, w.rev, st)) return 1;
-        if (launch_edge_bwd(s.TP, s.TQ, d->B, N, k, s.stats1, w.cc1, d->slope, gyk, y, s.hitj, s.usum, nullptr, nullptr,
+        if (launch_edge_bwd(s.TP, s.TQ, d->B, N, k, s.stats1, w.cc1, d->slope, w.gdv, s.hitj, s.usum, nullptr, nullptr,
                             w.rowptr, w.indeg, w.segbase, w.pcnt, w.rev, w.zero + Z_ALLOC, w.extra, w.hits, w.G, w.part0,
-                            w.partx, w.dR, w.dD, st, ldk, ld.y))
+                            w.partx, w.dR, w.dD, st))
             return 1;
     } else {
         launch_bwd_point(gy, s.usel, s.stats2, d->slope, P, E, d->training, fsa, g->gbn2_w, g->gbn2_b, w.cc2,
-                         reinterpret_cast<unsigned *>(w.zero + Z_GMAX), slots, st, ld.gy, ld.gy2, ld.gysum);
+                         reinterpret_cast<unsigned *>(w.zero + Z_GMAX), slots, st, ld.gy, ld.gy2, w.gdv);
         if (!pre && launch_rev_place(idx, d->B, N, k, w.cnt, w.rev, st)) return 1;
         const BnBackwardSums fin1{E, d->training, g->gbn1_w, g->gbn1_b, w.cc1};
         const FoldSet fsc{w.fb.rec, w.fb.folded, w.zero + Z_FOLD_C};
-        if (launch_edge_mlp_bwd(s.TP, s.TQ, idx, N, k, P, s.stats1, s.stats2, w.cc2, d->w2, d->slope, d->training, gyk, y,
+        if (launch_edge_mlp_bwd(s.TP, s.TQ, idx, N, k, P, s.stats1, s.stats2, w.cc2, d->w2, d->slope, d->training, w.gdv,
                                 s.hitj, reinterpret_cast<const unsigned *>(w.zero + Z_GMAX), w.dv1, w.dvsum, w.dw2_partial, fsb,
-                                fsc, fin1, w.zero + Z_GUARD, st, ldk, ld.y))
+                                fsc, fin1, w.zero + Z_GUARD, st))
             return 1;
         // (the fold of the gW2 partials rides in the per-point pass's launch)
         const SumRider fold_gw2{w.dw2_partial, mlp_grid(P), EC * EC, g->gw2, 0};
-        if (launch_edge_bwd(s.TP, s.TQ, d->B, N, k, s.stats1, w.cc1, d->slope, gyk, y, nullptr, s.usum, w.dv1, w.dvsum,
+        if (launch_edge_bwd(s.TP, s.TQ, d->B, N, k, s.stats1, w.cc1, d->slope, w.gdv, nullptr, s.usum, w.dv1, w.dvsum,
                             w.rowptr, w.indeg, w.segbase, w.pcnt, w.rev, w.zero + Z_ALLOC, w.extra, nullptr, nullptr,
-                            w.part0, w.partx, w.dR, w.dD, st, 0, 0, &fold_gw2))
+                            w.part0, w.partx, w.dR, w.dD, st, &fold_gw2))
             return 1;
     }
     launch_wgrad(w.dR, EC, w.dD, EC, x, C, P, w.wg_partial, st, ld.x);

@@ -1682,7 +1682,9 @@ __global__ __launch_bounds__(256) void knn_filter32_kernel(const float *__restri
 // the list entries of its 16 rows -- the other half's entries are inert lanes of a batch -- bring seven to a CU:
 // knn_refine<64, 128> 1.99 -> 1.52 ms, <4, 128> 0.76 -> 0.52 ms at B = 8, N = 32768, k = 64): exact pd of every listed survivor, selection, output.
 template <int CP, int CAP, int HALVES_ = (CAP == 64 ? 1 : 2)>
-__global__ __launch_bounds__(64, 2) void knn_refine_kernel(const float *__restrict__ x, int ldx, const float *__restrict__ xx,
+// (the register budget is that of the refine phase -- 150 registers up to CP = 32, 243 at CP = 64 --, pinned by the second
+// launch bound: the inlined exact phase, which alone would take 170 - 256 and an occupancy step, spills instead)
+__global__ __launch_bounds__(64, (CP <= 32 ? 3 : 2)) void knn_refine_kernel(const float *__restrict__ x, int ldx, const float *__restrict__ xx,
                                                         const unsigned *__restrict__ lists,
                                                         const int *__restrict__ lcount, int *__restrict__ rbflag,
                                                         int B, int N, int C, int Npad, int k, int parts,

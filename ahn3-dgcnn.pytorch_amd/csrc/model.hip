@@ -151,7 +151,7 @@ FwdWs fwd_ws(const dgcnn_model_desc *d, void *p)
 
 struct BwdWs {
     float *gl_pm, *gcat, *gadd7, *gg, *gw7c;
-    float *gxd, *gysum;  // [P][64] each: a block's input gradient (dense), and gcat slice + gxd as the previous block's dL/dy
+    float *gxd;          // [P][64]: a block's input gradient (dense); the previous block's first kernel adds it to its gcat slice
     // the reverse neighbour lists of the three blocks, built in one go (launch_rev_build_merged)
     int *rzero, *rcnt, *rindeg, *rrowptr, *rsegbase, *rpcnt, *rrev, *rextra;
     int rextra_stride;
@@ -169,7 +169,6 @@ BwdWs bwd_ws(const dgcnn_model_desc *d, void *p)
     w.gg = c.take<float>((size_t)d->B * d->emb);
     w.gw7c = c.take<float>((size_t)d->c7 * CATW);
     w.gxd = c.take<float>(P * EC);
-    w.gysum = c.take<float>(P * EC);
     {
         const size_t E = P * d->k;
         w.rextra_stride = (int)(2 * (E / REV_SEG + 1));
@@ -329,7 +328,7 @@ extern "C" int dgcnn_model_fwd(const dgcnn_model_desc *d, const float *x, int64_
         const float *in = b == 0 ? xpm : s.cat + EC * (b - 1);
         const int ldin = b == 0 ? 0 : CATW;
         if (!d->idx_given && knn_ld(in, ldin, B, N, e.C, d->k, d->idx[b], w.scratch, w.scratch_bytes, stream)) return 1;
-        if (edgeconv_fwd_ld(&e, EdgeLd{ldin, CATW, 0, 0, 0, nullptr, nullptr}, in, d->idx[b], s.cat + EC * b, s.edge[b], w.scratch, w.scratch_bytes, stream))
+        if (edgeconv_fwd_ld(&e, EdgeLd{ldin, CATW, 0, 0, 0, nullptr}, in, d->idx[b], s.cat + EC * b, s.edge[b], w.scratch, w.scratch_bytes, stream))
             return 1;
     }
     // max |cat| (the operand scale of every product that reads cat) and its column sums (conv6's backward)
@@ -373,7 +372,13 @@ extern "C" int dgcnn_model_bwd(const dgcnn_model_desc *d, const float *x, int64_
     // the reverse neighbour lists of all three blocks (they depend on the graphs alone) in three launches instead of nine, when
     // the caller keeps the three graphs in one array (ops.dgcnn_full does; graphs injected one by one take the per-block build)
     const size_t Pn = (size_t)B * N, En = Pn * d->k;
-    const bool merged = d->idx[1] == d->idx[0] + En && d->idx[2] == d->idx[1] + En && (size_t)3 * En < ((size_t)1 << 31);
+    // ... and when the lists under construction fit the L2s: the placement pass merges its scattered 4-byte stores into whole
+    // lines behind ONE XCD's L2 per batch element (edge_stream.hip); a merged build has 3 B / 8 list regions of N k ints in
+    // flight per XCD.  At B = 32 that is 10 MB per 4 MB L2 and the merged placement took 285 us against 3 x 34 (measured,
+    // profiles/r4_90_train_step_kernel_stats.csv); up to ~3.5 MB per XCD the merged form wins (B = 4: 101 -> 68 us for the
+    // three builds).
+    const bool merged = d->idx[1] == d->idx[0] + En && d->idx[2] == d->idx[1] + En && (size_t)3 * En < ((size_t)1 << 31) &&
+                        (size_t)3 * En * sizeof(int) <= (size_t)8 * 3584 * 1024;
     if (phases & 1) {
     if (merged && launch_rev_build_merged(d->idx[0], 3, B, N, d->k, w.rcnt, w.rindeg, w.rrowptr, w.rsegbase, w.rpcnt, w.rrev, w.rextra,
                                           w.rextra_stride, w.rzero, Z_WORDS, Z_ALLOC, st))
@@ -401,7 +406,7 @@ extern "C" int dgcnn_model_bwd(const dgcnn_model_desc *d, const float *x, int64_
         eg.gw1 = g->gw[2 * b], eg.gbn1_w = g->gbn_w[2 * b], eg.gbn1_b = g->gbn_b[2 * b];
         if (b < 2) eg.gw2 = g->gw[2 * b + 1], eg.gbn2_w = g->gbn_w[2 * b + 1], eg.gbn2_b = g->gbn_b[2 * b + 1];
         const float *in = b == 0 ? xpm : s.cat + EC * (b - 1);
-        const EdgeLd ld{b == 0 ? 0 : CATW, CATW, CATW, 0, 0, b < 2 ? w.gxd : nullptr, b < 2 ? w.gysum : nullptr};
+        const EdgeLd ld{b == 0 ? 0 : CATW, CATW, CATW, 0, 0, b < 2 ? w.gxd : nullptr};
         const RevPrebuilt pre{w.rzero + b * Z_WORDS, w.rindeg + b * Pn, w.rrowptr + b * Pn, w.rsegbase + b * Pn, w.rpcnt + b * Pn,
                               w.rrev + b * En,   w.rextra + (size_t)b * w.rextra_stride};
         if (edgeconv_bwd_ld(&e, ld, in, d->idx[b], s.cat + EC * b, w.gcat + EC * b, s.edge[b], &eg, w.scratch, w.scratch_bytes, stream,
