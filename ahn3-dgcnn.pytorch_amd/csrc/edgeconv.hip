@@ -271,16 +271,22 @@ int dgcnn::edgeconv_bwd_ld(const dgcnn_edgeconv_desc *d, const EdgeLd &ld, const
     // per-point pass, costs more in cross-stream barriers than it hides: 0.776 ms against 0.725 ms per step)
     // The reverse adjacency: its counting pass first (it also zeroes the call's counters), its list-space pass inside the
     // launch of bwd_point (two short passes that leave most of the chip idle on their own), then the placement.
+    // Large batches (>= 16 batch elements): the three list passes back to back, in front of bwd_point.  Riding in
+    // bwd_point's launch, the list-space pass put the placement pass BEHIND bwd_point, which since round 4 streams 57 MB of
+    // dL/dy . LReLU'(y) at B = 32: the placement's scattered stores then ran into that write-back (110 us against 91 per
+    // launch).  Small batches keep the rider (two short passes that each leave most of the chip idle).
+    const bool lists_first = !pre && d->B >= 16;
     if (!pre && launch_rev_build(idx, d->B, N, k, w.cnt, w.indeg, w.rowptr, w.segbase, w.pcnt, w.rev, w.zero + Z_ALLOC, w.extra,
-                                 w.zero, Z_WORDS, false, false, st))
+                                 w.zero, Z_WORDS, lists_first, lists_first, st))
         return 1;
     const RevSlotsArgs slots_ = rev_slots_args(d->B, N, k, w.cnt, w.indeg, w.rowptr, w.segbase, w.pcnt, w.zero + Z_ALLOC, w.extra);
-    const RevSlotsArgs *slots = pre ? nullptr : &slots_;
+    const RevSlotsArgs *slots = (pre || lists_first) ? nullptr : &slots_;
+    const bool place_later = !pre && !lists_first;
     const FoldSet fsa{w.fa.rec, w.fa.folded, w.zero + Z_FOLD_A}, fsb{w.fb.rec, w.fb.folded, w.zero + Z_FOLD_B};
     if (d->n_stage == 1) {
         launch_bwd_point(gy, s.usel, s.stats1, d->slope, P, E, d->training, fsa, g->gbn1_w, g->gbn1_b, w.cc1, nullptr, slots, st,
                          ld.gy, ld.gy2, w.gdv);
-        if (!pre && launch_rev_place(idx, d->B, N, k, w.cnt, w.rev, st)) return 1;
+        if (place_later && launch_rev_place(idx, d->B, N, k, w.cnt, w.rev, st)) return 1;
         if (launch_edge_bwd(s.TP, s.TQ, d->B, N, k, s.stats1, w.cc1, d->slope, w.gdv, s.hitj, s.usum, nullptr, nullptr,
                             w.rowptr, w.indeg, w.segbase, w.pcnt, w.rev, w.zero + Z_ALLOC, w.extra, w.hits, w.G, w.part0,
                             w.partx, w.dR, w.dD, st))
@@ -288,7 +294,7 @@ int dgcnn::edgeconv_bwd_ld(const dgcnn_edgeconv_desc *d, const EdgeLd &ld, const
     } else {
         launch_bwd_point(gy, s.usel, s.stats2, d->slope, P, E, d->training, fsa, g->gbn2_w, g->gbn2_b, w.cc2,
                          reinterpret_cast<unsigned *>(w.zero + Z_GMAX), slots, st, ld.gy, ld.gy2, w.gdv);
-        if (!pre && launch_rev_place(idx, d->B, N, k, w.cnt, w.rev, st)) return 1;
+        if (place_later && launch_rev_place(idx, d->B, N, k, w.cnt, w.rev, st)) return 1;
         const BnBackwardSums fin1{E, d->training, g->gbn1_w, g->gbn1_b, w.cc1};
         const FoldSet fsc{w.fb.rec, w.fb.folded, w.zero + Z_FOLD_C};
         if (launch_edge_mlp_bwd(s.TP, s.TQ, idx, N, k, P, s.stats1, s.stats2, w.cc2, d->w2, d->slope, d->training, w.gdv,

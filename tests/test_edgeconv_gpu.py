@@ -107,13 +107,14 @@ def compare(B, C, N, k, n_stage, train, device, seed=0, scale=1.0):
 
 
 @pytest.mark.parametrize("train", [True, False])
-@pytest.mark.parametrize("B,C,N,k", [(2, 64, 300, 20), (2, 4, 257, 30), (1, 3, 100, 8), (1, 64, 70, 40)])
+@pytest.mark.parametrize("B,C,N,k", [(2, 64, 300, 20), (2, 4, 257, 30), (1, 3, 100, 8), (1, 64, 70, 40), (16, 64, 75, 6)])
 def test_single_stage_block(B, C, N, k, train, device):
     compare(B, C, N, k, 1, train, device)
 
 
 @pytest.mark.parametrize("train", [True, False])
-@pytest.mark.parametrize("B,C,N,k", [(2, 64, 300, 20), (2, 4, 257, 30), (1, 5, 100, 8), (1, 64, 70, 40), (1, 64, 40, 32)])
+@pytest.mark.parametrize("B,C,N,k", [(2, 64, 300, 20), (2, 4, 257, 30), (1, 5, 100, 8), (1, 64, 70, 40), (1, 64, 40, 32),
+                                     (17, 64, 90, 7)])   # (>= 16 batch elements: the backward builds its lists ahead of bwd_point)
 def test_two_stage_block(B, C, N, k, train, device):
     compare(B, C, N, k, 2, train, device)
 
