@@ -1733,7 +1733,11 @@ static FwdWs fwd_ws(const dgcnn_head_tail_desc *d, void *p)
 static int wgrad_chunks(int M, int Nn, int P)
 {
     const int tiles = ceil_div(M, 128) * ceil_div(Nn, 128);
-    int chunks = 768 / tiles;  // about three workgroups per CU
+    // (one and a half workgroups per CU.  768 -- three per CU -- until round 4: every chunk leaves a 128 x 128 partial tile, 88 MB
+    // for dW8 and dW7c together whatever the batch; at B = 4 the two products 54 + 53 -> 48 + 45 us and the fold of the partials
+    // 30 -> 20 us, at B = 32 the products 320 + 306 -> 337 + 304 and the fold 34 -> 20; 192: 62 + 60 us at B = 4)
+    static const int target = getenv("DGCNN_WGRAD_TARGET") ? atoi(getenv("DGCNN_WGRAD_TARGET")) : 384;  // experiments
+    int chunks = target / tiles;
     if (chunks < 8) chunks = 8;
     const int most = ceil_div(P, 128);
     if (chunks > most) chunks = most;

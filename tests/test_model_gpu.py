@@ -380,7 +380,7 @@ def test_full_model_eval_at_stress_size(device):
     assert err <= 1e-4, "max |HIP logit - CPU restatement on the HIP graphs| = %.3g" % err
 
 
-@pytest.mark.parametrize("F_,k,N,B", [(4, 9, 260, 3), (3, 20, 131, 2), (6, 33, 300, 1), (4, 6, 70, 18)])   # (the CLI's default is 3 features, k = 20)
+@pytest.mark.parametrize("F_,k,N,B", [(4, 9, 260, 3), (3, 20, 131, 2), (6, 33, 300, 1), (4, 6, 130, 18)])   # (the CLI's default is 3 features, k = 20)
 def test_model_level_call_against_the_per_layer_path(F_, k, N, B, device, monkeypatch):
     """DGCNN.forward at depth 10 runs as dgcnn_model_fwd / _bwd (one call each way).  Three ways through the same kernels
     must agree: (1) own kNN, the three graphs in ONE array -> the backward builds the three reverse lists in one go;
