@@ -11,7 +11,21 @@ namespace dgcnn {
 // Every workgroup builds Wcat^T in LDS from w1; workgroup 0 also leaves wcat [128][C] for the backward's dgrad,
 // zeroes zero_words[0 .. nzero) (the fold.h counters of the statistics passes behind it) and, in eval mode (nbn = 1 or 2),
 // writes the BatchNorm affine pairs of the block's layers from their running statistics (ST_* layout of edge_common.h).
+// the counting pass of the reverse neighbour lists as extra workgroups of the forward's per-point product (see rev_count_rider)
+// (training forward of the 64-channel blocks: the product is bound by its matrix instructions, the counting pass by its LDS
+// atomics -- 23.7 + 17.0 us as two launches, 27.0 us as one at B = 8, N = 7000, k = 30); the rider's first workgroup also zeroes
+// zero_words[0 .. nzero): the counters of the BACKWARD call that will use the counts
+struct RevCountRider {
+    const int32_t *idx;
+    int N, k, chunks, rows_per, nblocks, main_blocks;
+    int *cnt;
+    int *zero_words;
+    int nzero;
+};
+// does launch_rowgemm_fwd carry the rider for this shape?  (the table of a chunk lives in the product's 32 KB of LDS)
+bool rowgemm_fwd_carries_count(int C, int N, int k);
 struct FwdSide {
+    RevCountRider rc;
     float *wcat;
     int *zero_words;
     int nzero;
@@ -38,16 +52,18 @@ int wgrad_chunks(int P, int C);
 void launch_wgrad(const float *A0, int M0, const float *A1, int M1, const float *X, int C, int P, float *partial,
                   hipStream_t st, int ldx = 0);
 // G [128][C] = sum of the partials, then gw1[o][c]:  c < C: G[o][c] - G[64 + o][c];  c >= C: G[64 + o][c - C]
-void launch_finish_dw1(const float *partial, int nchunk, int C, float *gw1, hipStream_t st);
+void launch_finish_dw1(const float *partial, int nchunk, int C, float *gw1, hipStream_t st, int *zero_words = nullptr, int nzero = 0);
 // that fold as extra workgroups of the input-gradient product's launch
 struct Dw1Rider {
     const float *partial;
     int nchunk, C;
     float *gw1;
     int main_blocks;
+    int *zero_words;  // counters the call leaves at zero behind itself (its last launch), or NULL
+    int nzero;
 };
 void launch_dgrad_and_dw1(const float *dR, const float *dD, const float *wcat, int C, float *gx, int ldgx, int gx_acc, int P,
-                          const float *partial, int nchunk, float *gw1, hipStream_t st);
+                          const float *partial, int nchunk, float *gw1, hipStream_t st, int *zero_words = nullptr, int nzero = 0);
 // out[e] = sum_chunk partial[chunk][e]   (fixed order: deterministic)
 void launch_sum_partials(const float *partial, int nchunk, int n, float *out, hipStream_t st);
 
@@ -56,9 +72,12 @@ void launch_sum_partials(const float *partial, int nchunk, int n, float *out, hi
 // column slices of wider rows; gx_acc: the input gradient is added to its slice instead of overwriting it.  The second
 // convolution's backward takes gy == y == 64 or 192 only.
 // gy2: dL/dy = gy + gy2 with gy2 dense [P][64] (added by the first kernel of the backward)
+// no_fwd_lists: the forward does not run the counting pass of the reverse lists and the backward does not expect its result
+// (the model builds the lists of its three blocks in one go where that is the faster way)
 struct EdgeLd {
     int x, y, gy, gx, gx_acc;
     const float *gy2;
+    int no_fwd_lists = 0;
 };
 int edgeconv_fwd_ld(const dgcnn_edgeconv_desc *d, const EdgeLd &ld, const float *x, const int32_t *idx, float *y, void *saved,
                     void *workspace, size_t workspace_bytes, void *stream);
@@ -118,12 +137,14 @@ struct RevSlotsArgs {
     // a merged build of nblk graphs of Pblk points each (launch_rev_build_merged): alloc / extra of graph g at
     // alloc + g alloc_stride ints, extra + g extra_stride pairs; one graph: nblk = 1, Pblk = P
     int nblk, Pblk, alloc_stride, extra_stride;
+    int *cnt_out = nullptr;  // where the first slots go (NULL: over the counts, in place); the counts of a training forward stay as
+                             // they are -- a second backward from the same saved state reads them again
 };
 RevSlotsArgs rev_slots_args(int B, int N, int k, int *cnt, int *indeg, int *rowptr, int *segbase, int *pcnt, int *alloc,
                             int *extra);
 int launch_rev_build(const int32_t *idx, int B, int N, int k, int *cnt, int *indeg, int *rowptr, int *segbase, int *pcnt,
                      int32_t *rev, int *alloc, int *extra, int *zero_words, int nzero, bool with_slots, bool with_place,
-                     hipStream_t st);
+                     hipStream_t st, bool with_count = true, int *slots_out = nullptr);
 int launch_rev_place(const int32_t *idx, int B, int N, int k, const int *cnt, int32_t *rev, hipStream_t st);
 struct RevPlaceArgs {
     const int32_t *idx;

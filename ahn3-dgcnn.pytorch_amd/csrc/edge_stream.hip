@@ -177,10 +177,11 @@ __device__ __forceinline__ void rev_slots_pass(const RevSlotsArgs &a, int block)
     int2 *__restrict__ extra = a.extra + (size_t)blk * a.extra_stride;
     const int g = blk * a.Pblk + gl;
     int deg = 0;
-    int *cb = nullptr;
+    int *cb = nullptr, *co = nullptr;
     if (live) {
         const int b = g / N, m = g - b * N;
         cb = cnt + (size_t)b * chunks * N + m;
+        co = (a.cnt_out ? a.cnt_out : cnt) + (size_t)b * chunks * N + m;
         int c = 0;
         for (; c + 16 <= chunks; c += 16) {  // 16 loads in flight (one workgroup per CU: nothing else hides them)
             int v[16];
@@ -239,13 +240,13 @@ __device__ __forceinline__ void rev_slots_pass(const RevSlotsArgs &a, int block)
             for (int u = 0; u < 16; ++u) v[u] = cb[(size_t)(c + u) * N];
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
-                cb[(size_t)(c + u) * N] = slot;
+                co[(size_t)(c + u) * N] = slot;
                 slot += v[u];
             }
         }
         for (; c < chunks; ++c) {
             const int n = cb[(size_t)c * N];
-            cb[(size_t)c * N] = slot;
+            co[(size_t)c * N] = slot;
             slot += n;
         }
         for (int sg = 0; sg < nseg; ++sg) extra[sb + sg] = int2{gl, sg + 1};  // (the point's number inside its graph)
@@ -503,7 +504,7 @@ __global__ __launch_bounds__(256) void rev_slots_kernel(RevSlotsArgs a) { rev_sl
 
 int launch_rev_build(const int32_t *idx, int B, int N, int k, int *cnt, int *indeg, int *rowptr, int *segbase, int *pcnt,
                      int32_t *rev, int *alloc, int *extra, int *zero_words, int nzero, bool with_slots, bool with_place,
-                     hipStream_t st)
+                     hipStream_t st, bool with_count, int *slots_out)
 {
     DG_REQUIRE(N <= REV_MAX_N, "dgcnn: N=%d > %d unsupported in the backward", N, REV_MAX_N);
     const int P = B * N, chunks = rev_chunks(B, N, k), rows_per = ceil_div(N, chunks);
@@ -524,16 +525,21 @@ int launch_rev_build(const int32_t *idx, int B, int N, int k, int *cnt, int *ind
             attr_done[dev] = true;
         }
     }
-    if (k > 64)
+    // (with_count = false: cnt comes from the forward, where the counting pass rode in the per-point product, and the call's
+    // counters are already zero)
+    if (!with_count) {
+    } else if (k > 64)
         hipLaunchKernelGGL((rev_count_kernel<true>), dim3(B * chunks), dim3(64), lds, st, idx, N, k, chunks, rows_per, cnt,
                            zero_words, nzero);
     else
         hipLaunchKernelGGL((rev_count_kernel<false>), dim3(B * chunks), dim3(64), lds, st, idx, N, k, chunks, rows_per, cnt,
                            zero_words, nzero);
     if (!with_slots) return 0;  // (the caller carries the list-space pass in its next launch: launch_bwd_point)
-    hipLaunchKernelGGL(rev_slots_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, st, rev_slots_args(B, N, k, cnt, indeg, rowptr, segbase, pcnt, alloc, extra));
+    RevSlotsArgs sa = rev_slots_args(B, N, k, cnt, indeg, rowptr, segbase, pcnt, alloc, extra);
+    sa.cnt_out = slots_out;
+    hipLaunchKernelGGL(rev_slots_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, st, sa);
     if (!with_place) return 0;
-    return launch_rev_place(idx, B, N, k, cnt, rev, st);
+    return launch_rev_place(idx, B, N, k, slots_out ? slots_out : cnt, rev, st);
 }
 
 // The reverse adjacencies of nblk graphs over the same B x N points (idx [nblk][B][N][k], contiguous) in three launches: the

@@ -43,8 +43,18 @@ struct Carver {
 struct SavedLayout {
     float *TP, *TQ, *usel, *usum, *stats1, *stats2, *wcat;
     uint8_t *hitj;
+    int *cnt, *bzero;  // lists_in_forward: the count tables of the reverse lists and the backward's counters (zeroed by the forward)
     size_t bytes;
 };
+// Training forward of a 64-channel block: the counting pass of the backward's reverse neighbour lists rides in the forward's
+// per-point product (pointgemm.hip, rev_count_rider), its tables [B rev_chunks][N] wait in the saved state, and the backward
+// starts at its BatchNorm sums.  The forward also zeroes the backward's counters (they live in the saved state too); the
+// backward's last launch zeroes them again, so that a second backward from the same saved state finds them as the first did.
+// A function of the descriptor alone: the two calls must agree.
+static bool lists_in_forward(const dgcnn_edgeconv_desc *d)
+{
+    return d->training && rowgemm_fwd_carries_count(d->C, d->N, d->k);
+}
 static SavedLayout saved_layout(const dgcnn_edgeconv_desc *d, void *p)
 {
     Carver c(p);
@@ -58,6 +68,12 @@ static SavedLayout saved_layout(const dgcnn_edgeconv_desc *d, void *p)
     s.stats1 = c.take<float>(ST_SIZE);
     s.stats2 = c.take<float>(ST_SIZE);
     s.wcat = c.take<float>((size_t)128 * d->C);  // [Wa ; Wb - Wa] of the forward, reused by the backward's dgrad
+    if (lists_in_forward(d)) {
+        s.cnt = c.take<int>((size_t)d->B * rev_chunks(d->B, d->N, d->k) * d->N);
+        s.bzero = c.take<int>(Z_WORDS);
+    } else {
+        s.cnt = nullptr, s.bzero = nullptr;
+    }
     s.bytes = c.off;
     return s;
 }
@@ -218,6 +234,10 @@ int dgcnn::edgeconv_fwd_ld(const dgcnn_edgeconv_desc *d, const EdgeLd &ld, const
         sd.bn[0] = d->bn1, sd.stats[0] = s.stats1;
         sd.bn[1] = d->bn2, sd.stats[1] = s.stats2;
     }
+    if (lists_in_forward(d) && !ld.no_fwd_lists) {
+        const int chunks = rev_chunks(d->B, N, k);
+        sd.rc = RevCountRider{idx, N, k, chunks, ceil_div(N, chunks), d->B * chunks, 0, s.cnt, s.bzero, Z_WORDS};
+    }
     launch_rowgemm_fwd(x, C, d->w1, s.TP, s.TQ, sd, P, st, ld.x);
     const FoldSet fs1{w.f1.rec, w.f1.folded, w.zero + Z_FOLD_A}, fs2{w.f2.rec, w.f2.folded, w.zero + Z_FOLD_B};
     const BnBatchStats fin1{d->bn1, E, d->eps, d->momentum, s.stats1}, fin2{d->bn2, E, d->eps, d->momentum, s.stats2};
@@ -276,10 +296,15 @@ int dgcnn::edgeconv_bwd_ld(const dgcnn_edgeconv_desc *d, const EdgeLd &ld, const
     // dL/dy . LReLU'(y) at B = 32: the placement's scattered stores then ran into that write-back (110 us against 91 per
     // launch).  Small batches keep the rider (two short passes that each leave most of the chip idle).
     const bool lists_first = !pre && d->B >= 16;
-    if (!pre && launch_rev_build(idx, d->B, N, k, w.cnt, w.indeg, w.rowptr, w.segbase, w.pcnt, w.rev, w.zero + Z_ALLOC, w.extra,
-                                 w.zero, Z_WORDS, lists_first, lists_first, st))
+    // (the counts and the zeroed counters come from the forward where its per-point product carried the counting pass)
+    const bool counted = !pre && lists_in_forward(d) && !ld.no_fwd_lists;
+    if (counted) w.zero = s.bzero;
+    int *counts = counted ? s.cnt : w.cnt;  // (the forward's counts are read only: the first slots go to w.cnt)
+    if (!pre && launch_rev_build(idx, d->B, N, k, counts, w.indeg, w.rowptr, w.segbase, w.pcnt, w.rev, w.zero + Z_ALLOC, w.extra,
+                                 w.zero, Z_WORDS, lists_first, lists_first, st, !counted, counted ? w.cnt : nullptr))
         return 1;
-    const RevSlotsArgs slots_ = rev_slots_args(d->B, N, k, w.cnt, w.indeg, w.rowptr, w.segbase, w.pcnt, w.zero + Z_ALLOC, w.extra);
+    RevSlotsArgs slots_ = rev_slots_args(d->B, N, k, counts, w.indeg, w.rowptr, w.segbase, w.pcnt, w.zero + Z_ALLOC, w.extra);
+    if (counted) slots_.cnt_out = w.cnt;
     const RevSlotsArgs *slots = (pre || lists_first) ? nullptr : &slots_;
     const bool place_later = !pre && !lists_first;
     const FoldSet fsa{w.fa.rec, w.fa.folded, w.zero + Z_FOLD_A}, fsb{w.fb.rec, w.fb.folded, w.zero + Z_FOLD_B};
@@ -309,8 +334,11 @@ int dgcnn::edgeconv_bwd_ld(const dgcnn_edgeconv_desc *d, const EdgeLd &ld, const
             return 1;
     }
     launch_wgrad(w.dR, EC, w.dD, EC, x, C, P, w.wg_partial, st, ld.x);
-    if (g->gx) launch_dgrad_and_dw1(w.dR, w.dD, s.wcat, C, g->gx, ld.gx, ld.gx_acc, P, w.wg_partial, wgrad_chunks(P, C), g->gw1, st);
-    else launch_finish_dw1(w.wg_partial, wgrad_chunks(P, C), C, g->gw1, st);
+    int *rezero = counted ? s.bzero : nullptr;
+    if (g->gx)
+        launch_dgrad_and_dw1(w.dR, w.dD, s.wcat, C, g->gx, ld.gx, ld.gx_acc, P, w.wg_partial, wgrad_chunks(P, C), g->gw1, st, rezero, Z_WORDS);
+    else
+        launch_finish_dw1(w.wg_partial, wgrad_chunks(P, C), C, g->gw1, st, rezero, Z_WORDS);
     DG_CHECK_LAUNCH("dgcnn_edgeconv_bwd");
     return 0;
 }

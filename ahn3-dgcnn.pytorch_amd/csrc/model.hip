@@ -306,6 +306,15 @@ extern "C" size_t dgcnn_model_bwd_workspace_bytes(const dgcnn_model_desc *d)
     return bwd_ws(d, nullptr).bytes;
 }
 
+// the backward builds the reverse lists of the three graphs in one go (see dgcnn_model_bwd); the forward must know: its blocks
+// then leave the counting pass of their own lists alone (EdgeLd::no_fwd_lists)
+static bool lists_merged(const dgcnn_model_desc *d)
+{
+    const size_t En = (size_t)d->B * d->N * d->k;
+    return d->idx[1] == d->idx[0] + En && d->idx[2] == d->idx[1] + En && (size_t)3 * En < ((size_t)1 << 31) &&
+           (size_t)3 * En * sizeof(int) <= (size_t)8 * 3584 * 1024;
+}
+
 extern "C" int dgcnn_model_fwd(const dgcnn_model_desc *d, const float *x, int64_t x_sb, int64_t x_sc, int64_t x_sn, float *logits,
                                int64_t l_sb, int64_t l_sc, int64_t l_sn, void *saved, void *workspace, size_t workspace_bytes,
                                void *stream)
@@ -323,12 +332,13 @@ extern "C" int dgcnn_model_fwd(const dgcnn_model_desc *d, const float *x, int64_
         if (dgcnn_to_point_major(x, B, d->F, N, x_sb, x_sc, x_sn, s.xpm, stream)) return 1;
         xpm = s.xpm;
     }
+    const int nolists = lists_merged(d) ? 1 : 0;
     for (int b = 0; b < 3; ++b) {
         const dgcnn_edgeconv_desc e = block_desc(d, b);
         const float *in = b == 0 ? xpm : s.cat + EC * (b - 1);
         const int ldin = b == 0 ? 0 : CATW;
         if (!d->idx_given && knn_ld(in, ldin, B, N, e.C, d->k, d->idx[b], w.scratch, w.scratch_bytes, stream)) return 1;
-        if (edgeconv_fwd_ld(&e, EdgeLd{ldin, CATW, 0, 0, 0, nullptr}, in, d->idx[b], s.cat + EC * b, s.edge[b], w.scratch, w.scratch_bytes, stream))
+        if (edgeconv_fwd_ld(&e, EdgeLd{ldin, CATW, 0, 0, 0, nullptr, nolists}, in, d->idx[b], s.cat + EC * b, s.edge[b], w.scratch, w.scratch_bytes, stream))
             return 1;
     }
     // max |cat| (the operand scale of every product that reads cat) and its column sums (conv6's backward)
@@ -377,8 +387,7 @@ extern "C" int dgcnn_model_bwd(const dgcnn_model_desc *d, const float *x, int64_
     // flight per XCD.  At B = 32 that is 10 MB per 4 MB L2 and the merged placement took 285 us against 3 x 34 (measured,
     // profiles/r4_90_train_step_kernel_stats.csv); up to ~3.5 MB per XCD the merged form wins (B = 4: 101 -> 68 us for the
     // three builds).
-    const bool merged = d->idx[1] == d->idx[0] + En && d->idx[2] == d->idx[1] + En && (size_t)3 * En < ((size_t)1 << 31) &&
-                        (size_t)3 * En * sizeof(int) <= (size_t)8 * 3584 * 1024;
+    const bool merged = lists_merged(d);
     if (phases & 1) {
     if (merged && launch_rev_build_merged(d->idx[0], 3, B, N, d->k, w.rcnt, w.rindeg, w.rrowptr, w.rsegbase, w.rpcnt, w.rrev, w.rextra,
                                           w.rextra_stride, w.rzero, Z_WORDS, Z_ALLOC, st))
@@ -406,7 +415,7 @@ extern "C" int dgcnn_model_bwd(const dgcnn_model_desc *d, const float *x, int64_
         eg.gw1 = g->gw[2 * b], eg.gbn1_w = g->gbn_w[2 * b], eg.gbn1_b = g->gbn_b[2 * b];
         if (b < 2) eg.gw2 = g->gw[2 * b + 1], eg.gbn2_w = g->gbn_w[2 * b + 1], eg.gbn2_b = g->gbn_b[2 * b + 1];
         const float *in = b == 0 ? xpm : s.cat + EC * (b - 1);
-        const EdgeLd ld{b == 0 ? 0 : CATW, CATW, CATW, 0, 0, b < 2 ? w.gxd : nullptr};
+        const EdgeLd ld{b == 0 ? 0 : CATW, CATW, CATW, 0, 0, b < 2 ? w.gxd : nullptr, merged ? 1 : 0};
         const RevPrebuilt pre{w.rzero + b * Z_WORDS, w.rindeg + b * Pn, w.rrowptr + b * Pn, w.rsegbase + b * Pn, w.rpcnt + b * Pn,
                               w.rrev + b * En,   w.rextra + (size_t)b * w.rextra_stride};
         if (edgeconv_bwd_ld(&e, ld, in, d->idx[b], s.cat + EC * b, w.gcat + EC * b, s.edge[b], &eg, w.scratch, w.scratch_bytes, stream,

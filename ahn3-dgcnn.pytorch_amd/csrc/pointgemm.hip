@@ -43,6 +43,36 @@ __device__ __forceinline__ void fwd_side_jobs(const float *__restrict__ w1, int 
     }
 }
 
+// cnt[b][chunk][m] = number of edges from the chunk's rows into m (rev_count_kernel's result), by one 256-thread workgroup whose
+// four waves share the N-entry table in LDS (counting does not depend on the order the adds arrive in)
+__device__ __forceinline__ void rev_count_rider(const RevCountRider &a, int block, int *table)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int B_ = a.nblocks / a.chunks, b = block % B_, chunk = block / B_;
+    const int N = a.N, k = a.k;
+    const int r0 = chunk * a.rows_per, r1 = r0 + a.rows_per < N ? r0 + a.rows_per : N;
+    const int32_t *ib = a.idx + (size_t)b * N * k;
+    int *out = a.cnt + (size_t)(b * a.chunks + chunk) * N;
+    if (block == 0)
+        for (int i = threadIdx.x; i < a.nzero; i += 256) a.zero_words[i] = 0;
+    for (int m = threadIdx.x; m < N; m += 256) table[m] = 0;
+    __syncthreads();
+    const int l0 = lane < k ? lane : k - 1;
+    for (int r = r0 + wave * 8; r < r1; r += 32) {
+        int nv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int rr = r + u < r1 ? r + u : r1 - 1;
+            nv[u] = ib[(size_t)rr * k + l0] | (r + u < r1 && lane < k ? 0 : (int)0x80000000);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (nv[u] >= 0) atomicAdd(&table[nv[u]], 1);
+    }
+    __syncthreads();
+    for (int m = threadIdx.x; m < N; m += 256) out[m] = table[m];
+}
+
 // One wave = one 32-row tile of points x all NO (<= 32 NT) output columns.
 // MFMA operand maps (32x32x2): A lane (i, h) = A[row i][k(s, h)];  B lane (n, h) = B[k(s, h)][col n];
 // C/D lane (n, h), register r = D[row mfma32_row(r, h)][col n].  The contraction order is free here
@@ -148,6 +178,10 @@ __global__ __launch_bounds__(256) void rowgemm_fast_kernel(const float *__restri
 {
     constexpr int K = 2 * KH, NO = 32 * NT;
     __shared__ float wl[K * NO];
+    if (FROM_W1 && sd.rc.cnt && (int)blockIdx.x >= sd.rc.main_blocks) {
+        rev_count_rider(sd.rc, (int)blockIdx.x - sd.rc.main_blocks, reinterpret_cast<int *>(wl));
+        return;
+    }
     if (FROM_W1) {  // K = C = 64, NO = 128: wl[c][o] = Wcat[o][c]; lanes run over o (conflict-free LDS writes), each
                     // reads 16 bytes of row o of w1
         static_assert(!FROM_W1 || (K == 64 && NO == 128), "forward shape");
@@ -216,8 +250,13 @@ __global__ __launch_bounds__(256) void rowgemm_fast_kernel(const float *__restri
 // elements.  The body of finish_dw1_kernel (NW = 16) and of the workgroups that ride behind the input-gradient product
 // (NW = 4, rowgemm_split_kernel: the two kernels read the same [dR | dD] and neither needs the other's result).
 template <int NW>
-__device__ __forceinline__ void finish_dw1_body(const float *__restrict__ partial, int nchunk, int C, float *__restrict__ gw1, int block)
+__device__ __forceinline__ void finish_dw1_body(const float *__restrict__ partial, int nchunk, int C, float *__restrict__ gw1, int block,
+                                                int *__restrict__ zero_words = nullptr, int nzero = 0)
 {
+    // (the last launch of a backward call: its first workgroup leaves the call's counters at zero for the next call that uses
+    // the same saved state -- the forward zeroed them for this one)
+    if (block == 0 && zero_words)
+        for (int i = threadIdx.x; i < nzero; i += 64 * NW) zero_words[i] = 0;
     __shared__ float red[NW][2][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int t = block * 64 + lane, n = 128 * C;
@@ -262,9 +301,9 @@ __device__ __forceinline__ void finish_dw1_body(const float *__restrict__ partia
     }
 }
 __global__ __launch_bounds__(1024) void finish_dw1_kernel(const float *__restrict__ partial, int nchunk, int C,
-                                                          float *__restrict__ gw1)
+                                                          float *__restrict__ gw1, int *__restrict__ zero_words, int nzero)
 {
-    finish_dw1_body<16>(partial, nchunk, C, gw1, (int)blockIdx.x);
+    finish_dw1_body<16>(partial, nchunk, C, gw1, (int)blockIdx.x, zero_words, nzero);
 }
 
 // The same two products on the fp16 matrix cores: both operands scaled by an exact power of two and split in two fp16
@@ -284,7 +323,7 @@ __global__ __launch_bounds__(256) void rowgemm_split_kernel(const float *__restr
 {
     // workgroups rd.main_blocks .. : the weight gradient's fold (finish_dw1_body), riding in this launch
     if (!FROM_W1 && rd.gw1 && (int)blockIdx.x >= rd.main_blocks) {
-        finish_dw1_body<4>(rd.partial, rd.nchunk, rd.C, rd.gw1, (int)blockIdx.x - rd.main_blocks);
+        finish_dw1_body<4>(rd.partial, rd.nchunk, rd.C, rd.gw1, (int)blockIdx.x - rd.main_blocks, rd.zero_words, rd.nzero);
         return;
     }
     constexpr int K = 2 * KH, NO = 32 * NT, ROWB = K * 2, PLANE = NO * ROWB;
@@ -525,6 +564,12 @@ static bool rowgemm_split_fwd()
     return v != 0;
 }
 
+bool rowgemm_fwd_carries_count(int C, int N, int k)
+{
+    static const bool off = getenv("DGCNN_NO_FWD_LISTS") != nullptr;   // experiments / tests: the backward counts itself
+    return !off && C == 64 && !rowgemm_split_fwd() && N <= RG_LDS_FLOATS && k <= 64;
+}
+
 void launch_rowgemm_fwd(const float *x, int C, const float *w1, float *TP, float *TQ, const FwdSide &sd, int P, hipStream_t st,
                         int ldx)
 {
@@ -532,8 +577,12 @@ void launch_rowgemm_fwd(const float *x, int C, const float *w1, float *TP, float
     const RowLd ld{ldx > 0 ? ldx : C, EC, 0};
     if (C == 64 && rowgemm_split_fwd())
         hipLaunchKernelGGL((rowgemm_split_kernel<32, 4, true>), grid, block, 0, st, x, C, nullptr, 0, w1, TP, EC, TQ, P, sd, ld, Dw1Rider{});
-    else if (C == 64)
-        hipLaunchKernelGGL((rowgemm_fast_kernel<32, 4, true>), grid, block, 0, st, x, C, nullptr, 0, w1, TP, EC, TQ, P, sd, ld);
+    else if (C == 64) {
+        FwdSide s2 = sd;
+        s2.rc.main_blocks = (int)grid.x;
+        const dim3 g2(grid.x + (sd.rc.cnt ? sd.rc.nblocks : 0));
+        hipLaunchKernelGGL((rowgemm_fast_kernel<32, 4, true>), g2, block, 0, st, x, C, nullptr, 0, w1, TP, EC, TQ, P, s2, ld);
+    }
     else
         hipLaunchKernelGGL((rowgemm_kernel<4, true>), grid, block, 0, st, x, C, nullptr, 0, w1, 128, TP, EC, TQ, P, sd, ld);
 }
@@ -742,23 +791,23 @@ void launch_wgrad(const float *A0, int M0, const float *A1, int M1, const float 
 // gradient (launch_finish_dw1) in ONE launch where the shapes allow (the 64-channel blocks): the fold's 128 workgroups ride
 // behind the product's
 void launch_dgrad_and_dw1(const float *dR, const float *dD, const float *wcat, int C, float *gx, int ldgx, int gx_acc, int P,
-                          const float *partial, int nchunk, float *gw1, hipStream_t st)
+                          const float *partial, int nchunk, float *gw1, hipStream_t st, int *zero_words, int nzero)
 {
     if (C == 64 && !rowgemm_force_f32()) {
         const int main_blocks = ceil_div(ceil_div(P, 32), 4);
-        const Dw1Rider rd{partial, nchunk, C, gw1, main_blocks};
+        const Dw1Rider rd{partial, nchunk, C, gw1, main_blocks, zero_words, nzero};
         const RowLd ld{EC, ldgx > 0 ? ldgx : C, gx_acc};
         hipLaunchKernelGGL((rowgemm_split_kernel<64, 2, false>), dim3(main_blocks + ceil_div(EC * 2 * C, 64)), dim3(256), 0, st, dR, EC,
                            dD, EC, wcat, gx, C, nullptr, P, FwdSide{}, ld, rd);
         return;
     }
-    launch_finish_dw1(partial, nchunk, C, gw1, st);
+    launch_finish_dw1(partial, nchunk, C, gw1, st, zero_words, nzero);
     launch_rowgemm(dR, EC, dD, EC, wcat, C, gx, C, nullptr, P, st, ldgx, gx_acc);
 }
 
-void launch_finish_dw1(const float *partial, int nchunk, int C, float *gw1, hipStream_t st)
+void launch_finish_dw1(const float *partial, int nchunk, int C, float *gw1, hipStream_t st, int *zero_words, int nzero)
 {
-    hipLaunchKernelGGL(finish_dw1_kernel, dim3(ceil_div(EC * 2 * C, 64)), dim3(1024), 0, st, partial, nchunk, C, gw1);
+    hipLaunchKernelGGL(finish_dw1_kernel, dim3(ceil_div(EC * 2 * C, 64)), dim3(1024), 0, st, partial, nchunk, C, gw1, zero_words, nzero);
 }
 
 void launch_sum_partials(const float *partial, int nchunk, int n, float *out, hipStream_t st)

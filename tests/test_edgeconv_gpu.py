@@ -323,6 +323,41 @@ def test_backward_is_bit_stable(n_stage, train, device):
         assert torch.equal(u, v)
 
 
+@pytest.mark.parametrize("n_stage", [1, 2])
+@pytest.mark.parametrize("B,C,N,k", [(2, 64, 300, 20), (17, 64, 90, 7), (2, 16, 200, 12)])
+def test_two_backward_calls_from_one_saved_state(B, C, N, k, n_stage, device):
+    """retain_graph: the backward runs twice from the same saved state.  For the 64-channel blocks in training mode the
+    counting pass of the reverse neighbour lists rode in the FORWARD, which also zeroed the backward's counters; the backward's
+    last launch leaves them at zero again -- the second call must return the bits of the first."""
+    from ahn3_dgcnn_pytorch_amd import ops
+    import copy
+    x = torch.randn(B, C, N, generator=torch.Generator().manual_seed(31))
+    idx = ke.knn_exact(x.numpy(), k)
+    stages = [copy.deepcopy(s).to(device) for s in make_stages(2 * C, n_stage)]
+    for st in stages:
+        st.train(True)
+    R = cotangent((B, 64, N), tag="twice").to(device)
+    xd = x.to(device).requires_grad_(True)
+    w2 = stages[1][0].weight if n_stage == 2 else None
+    bn2 = stages[1][1] if n_stage == 2 else None
+    y_pm = ops.edgeconv_pm(ops.to_point_major_autograd(xd), torch.from_numpy(idx).to(device), stages[0][0].weight, stages[0][1], w2, bn2,
+                           training=True, slope=0.2)
+    loss = (ops.from_point_major_autograd(y_pm) * R).sum()
+    params = [xd] + [t for s_ in stages for t in (s_[0].weight, s_[1].weight, s_[1].bias)]
+    got = []
+    for rep in range(2):
+        for p_ in params:
+            p_.grad = None
+        loss.backward(retain_graph=(rep == 0))
+        torch.cuda.synchronize()
+        got.append([p_.grad.clone() for p_ in params])
+    for u, v in zip(*got):
+        assert torch.equal(u, v)
+    # and against the path whose backward counts for itself
+    _, gx_ref, st_ref = run_hip(x, idx, make_stages(2 * C, n_stage), True, R.cpu(), device)
+    assert torch.equal(got[0][0].cpu(), gx_ref)
+
+
 def test_get_graph_feature_backward_is_bit_stable(device):
     from ahn3_dgcnn_pytorch_amd import get_graph_feature
     x = torch.randn(2, 64, 3000, generator=torch.Generator().manual_seed(5))
