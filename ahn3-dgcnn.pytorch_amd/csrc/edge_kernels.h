@@ -87,9 +87,10 @@ enum {
     Z_FOLD_A = 0,
     Z_FOLD_B = FOLD_CTR_WORDS,
     Z_FOLD_C = 2 * FOLD_CTR_WORDS,   // the fp32 fallback of edge_mlp_bwd16_kernel
-    Z_ALLOC = 3 * FOLD_CTR_WORDS,    // [0] reverse-list space, [1] extra (point, segment) pairs
-    Z_GMAX = Z_ALLOC + 2,            // bits of max |dL/dy . LReLU'| (bwd_point -> edge_mlp_bwd16)
-    Z_GUARD = Z_ALLOC + 3,           // raised by edge_mlp_bwd16_kernel when an operand leaves the fp16 range
+    Z_GMAX = 3 * FOLD_CTR_WORDS,     // bits of max |dL/dy . LReLU'| (bwd_point -> edge_mlp_bwd16)
+    Z_GUARD = Z_GMAX + 1,            // raised by edge_mlp_bwd16_kernel when an operand leaves the fp16 range
+    Z_ALLOC = 3 * FOLD_CTR_WORDS + 8,  // [0] reverse-list space, [1] extra (point, segment) pairs.  LAST: where the forward has
+                                     // allotted the lists, the backward's last launch zeroes the words in front of this pair only
     Z_WORDS = 3 * FOLD_CTR_WORDS + 16
 };
 // reverse lists built outside the call (the model builds those of its three blocks in one go): the call's Z_WORDS counters
@@ -111,21 +112,26 @@ int edge_grid(int P);
 // survives max-over-k (max if gamma >= 0, min otherwise); usum[i] = sum_j u[i][j]; hitj[i] = slot j of the first edge
 // attaining the extreme (with usel only).  fin != NULL (training): the pass finishes the BatchNorm batch statistics
 // itself (fold.h; fs.ctr must be zero at launch) -> fin->stats, running statistics updated.
+struct RevSlotsArgs;
 void launch_edge_reduce(const float *TP, const float *TQ, const int32_t *idx, int N, int k, int P, const float *gamma,
-                        float *usel, float *usum, uint8_t *hitj, const FoldSet &fs, const BnBatchStats *fin, hipStream_t st);
+                        float *usel, float *usum, uint8_t *hitj, const FoldSet &fs, const BnBatchStats *fin, hipStream_t st,
+                        const struct RevSlotsArgs *slots = nullptr);
 // y = LeakyReLU(sc * usel + sh)
 void launch_edge_out(const float *usel, const float *stats, float slope, int P, float *y, hipStream_t st, int ldy = 0);
 // last-stage BN backward sums from per-point quantities, finished in the same launch: gbn_w, gbn_b and cc = [c1 | c2]
 // gmax_bits (zero at launch): receives the bits of max |gy . LReLU'| (an atomic max: order-independent)
 struct RevSlotsArgs;
+struct RevPlaceArgs;
 void launch_bwd_point(const float *gy, const float *usel, const float *stats, float slope, int P, double count,
                       int training, const FoldSet &fs, float *gbn_w, float *gbn_b, float *cc, unsigned *gmax_bits,
-                      const struct RevSlotsArgs *slots, hipStream_t st, int ldgy, const float *gy2, float *gdv);
+                      const struct RevSlotsArgs *slots, hipStream_t st, int ldgy, const float *gy2, float *gdv,
+                      const struct RevPlaceArgs *place = nullptr);
 // Reverse adjacency of the neighbour graph (depends on idx only), every list sorted by edge id.  Scratch: cnt
 // [B * rev_chunks][N]; results: rowptr [P] (list start), indeg [P], segbase [P], pcnt [P] (zeroed), rev [E], alloc [2]
 // (alloc[1] = number of extra (point, segment) pairs), extra [2 (E / REV_SEG + 1)] ints.  The first kernel also zeroes
 // zero_words[0 .. nzero) (which must contain alloc).
 int rev_chunks(int B, int N, int k);
+constexpr int REV_RIDER_MAX_N = 8192;  // the list passes that ride in other kernels' launches keep their table in 32 KB of static LDS
 constexpr int REV_MAX_N = 40000;  // points per batch element: the list kernels keep an N-int table per wave in LDS
                                   // (160 KB per CU); every backward builds the lists, so this bounds N there
 // with_slots / with_place = false: the caller runs those passes itself -- the list-space pass inside launch_bwd_point's
@@ -137,14 +143,12 @@ struct RevSlotsArgs {
     // a merged build of nblk graphs of Pblk points each (launch_rev_build_merged): alloc / extra of graph g at
     // alloc + g alloc_stride ints, extra + g extra_stride pairs; one graph: nblk = 1, Pblk = P
     int nblk, Pblk, alloc_stride, extra_stride;
-    int *cnt_out = nullptr;  // where the first slots go (NULL: over the counts, in place); the counts of a training forward stay as
-                             // they are -- a second backward from the same saved state reads them again
 };
 RevSlotsArgs rev_slots_args(int B, int N, int k, int *cnt, int *indeg, int *rowptr, int *segbase, int *pcnt, int *alloc,
                             int *extra);
 int launch_rev_build(const int32_t *idx, int B, int N, int k, int *cnt, int *indeg, int *rowptr, int *segbase, int *pcnt,
                      int32_t *rev, int *alloc, int *extra, int *zero_words, int nzero, bool with_slots, bool with_place,
-                     hipStream_t st, bool with_count = true, int *slots_out = nullptr);
+                     hipStream_t st);
 int launch_rev_place(const int32_t *idx, int B, int N, int k, const int *cnt, int32_t *rev, hipStream_t st);
 struct RevPlaceArgs {
     const int32_t *idx;

@@ -47,20 +47,27 @@ static int stream_grid(int P)  // passes without partial records
 // Also written for the backward: usum[i] = sum_j u[i][j] (fp32) and, with WANT_EXT, hitj[i] = the slot j (0..k-1)
 // of the FIRST edge attaining the extreme (PyTorch's max routes the gradient to the first maximum).
 // FIN: the pass also finishes the BatchNorm batch statistics (training mode, fold.h); without it the sums are dropped.
+__device__ __forceinline__ void rev_slots_pass(const RevSlotsArgs &a, int block);
 template <bool WANT_EXT, bool FIN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void edge_reduce_kernel(const float *__restrict__ TP, const float *__restrict__ TQ,
                                                           const int32_t *__restrict__ idx, int N, int k, int P,
                                                           const float *__restrict__ gamma, float *__restrict__ usel,
                                                           float *__restrict__ usum, uint8_t *__restrict__ hitj,
-                                                          FoldSet fs, BnBatchStats fin)
+                                                          FoldSet fs, BnBatchStats fin, int nmain, RevSlotsArgs slots)
 {
+    // workgroups nmain .. (training forward of a block whose per-point product carried the counting pass of the backward's
+    // reverse lists): the list-space pass, which needs those counts and nothing of this pass
+    if (FIN && (int)blockIdx.x >= nmain) {
+        rev_slots_pass(slots, (int)blockIdx.x - nmain);
+        return;
+    }
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // (visibly uniform)
     const bool neg = WANT_EXT ? (gamma[lane] < 0.0f) : false;
     // the extreme is tracked on sign-flipped values where gamma < 0: s p + s q is the exact negation of u = p + q (one
     // fma with s = +-1), so one comparison serves both directions; the sums are flipped back at the end
     const float sgn = neg ? -1.0f : 1.0f;
     double acc[2] = {0.0, 0.0};
-    const PointIter it = point_iter(P, wave, EDGE_WAVES);
+    const PointIter it = point_iter_at(P, wave, EDGE_WAVES, (int)blockIdx.x, nmain);
     // The pass is latency-bound (index row -> neighbour rows -> arithmetic), so every point's loads are issued
     // as one batch of up to 32 rows, and the next point's index row and TQ row are fetched one point ahead.
     // Once the loads are batched the vector instructions per gathered row bound it (measured: 12.6 per row, 62 % VALU
@@ -139,7 +146,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         }
     }
     acc[0] *= (double)sgn;
-    if (FIN) fold_and_finalize<2, EDGE_WAVES>(acc, fs, fin);
+    if (FIN) fold_and_finalize<2, EDGE_WAVES>(acc, fs, fin, nmain);
 }
 
 __global__ void edge_out_kernel(const float *__restrict__ usel, const float *__restrict__ stats, float slope,
@@ -177,11 +184,10 @@ __device__ __forceinline__ void rev_slots_pass(const RevSlotsArgs &a, int block)
     int2 *__restrict__ extra = a.extra + (size_t)blk * a.extra_stride;
     const int g = blk * a.Pblk + gl;
     int deg = 0;
-    int *cb = nullptr, *co = nullptr;
+    int *cb = nullptr;
     if (live) {
         const int b = g / N, m = g - b * N;
         cb = cnt + (size_t)b * chunks * N + m;
-        co = (a.cnt_out ? a.cnt_out : cnt) + (size_t)b * chunks * N + m;
         int c = 0;
         for (; c + 16 <= chunks; c += 16) {  // 16 loads in flight (one workgroup per CU: nothing else hides them)
             int v[16];
@@ -240,13 +246,13 @@ __device__ __forceinline__ void rev_slots_pass(const RevSlotsArgs &a, int block)
             for (int u = 0; u < 16; ++u) v[u] = cb[(size_t)(c + u) * N];
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
-                co[(size_t)(c + u) * N] = slot;
+                cb[(size_t)(c + u) * N] = slot;
                 slot += v[u];
             }
         }
         for (; c < chunks; ++c) {
             const int n = cb[(size_t)c * N];
-            co[(size_t)c * N] = slot;
+            cb[(size_t)c * N] = slot;
             slot += n;
         }
         for (int sg = 0; sg < nseg; ++sg) extra[sb + sg] = int2{gl, sg + 1};  // (the point's number inside its graph)
@@ -263,14 +269,24 @@ __device__ __forceinline__ void rev_slots_pass(const RevSlotsArgs &a, int block)
 // input gradient: one extra stream here instead of a read-modify-write of the strided slice in the product that makes gy2:
 // 8 -> 22 us there at P = 28 000).  gdv [P][64] <- dL/dy . LReLU'(y) (y > 0 <=> sc usel + sh > 0): what every kernel behind
 // this one needs of (dL/dy, y) -- they read ONE dense row per point instead of two rows that may be column slices of wider ones.
+template <bool K2>
+__device__ __forceinline__ void rev_place_pass(const RevPlaceArgs &a, int block, int *table);
 __global__ __launch_bounds__(256) void bwd_point_kernel(const float *__restrict__ gy, int ldgy, const float *__restrict__ gy2,
                                                         float *__restrict__ gdv, const float *__restrict__ usel,
                                                         const float *__restrict__ stats, float slope, int P,
                                                         FoldSet fs, BnBackwardSums fin, unsigned *__restrict__ gmax_bits,
-                                                        int nbp, RevSlotsArgs slots)
+                                                        int nbp, RevSlotsArgs slots, RevPlaceArgs place, int nslots)
 {
     // workgroups nbp .. : the list-space pass of the reverse adjacency (rev_slots_pass), which only needs rev_count_kernel
     // before it and nothing of this pass
+    // workgroups nbp + nslots .. : the placement pass of the reverse lists when the forward has counted and allotted them (one wave
+    // of each workgroup works; the pass is bound by its LDS atomics, this one by its streams: 21.0 + 19.2 us as two launches,
+    // 27.3 as one at B = 8, N = 7000, k = 30)
+    if ((int)blockIdx.x >= nbp + nslots) {
+        __shared__ int table[REV_RIDER_MAX_N];
+        if (threadIdx.x < 64) rev_place_pass<false>(place, (int)blockIdx.x - nbp - nslots, table);
+        return;
+    }
     if ((int)blockIdx.x >= nbp) {
         rev_slots_pass(slots, (int)blockIdx.x - nbp);
         return;
@@ -504,7 +520,7 @@ __global__ __launch_bounds__(256) void rev_slots_kernel(RevSlotsArgs a) { rev_sl
 
 int launch_rev_build(const int32_t *idx, int B, int N, int k, int *cnt, int *indeg, int *rowptr, int *segbase, int *pcnt,
                      int32_t *rev, int *alloc, int *extra, int *zero_words, int nzero, bool with_slots, bool with_place,
-                     hipStream_t st, bool with_count, int *slots_out)
+                     hipStream_t st)
 {
     DG_REQUIRE(N <= REV_MAX_N, "dgcnn: N=%d > %d unsupported in the backward", N, REV_MAX_N);
     const int P = B * N, chunks = rev_chunks(B, N, k), rows_per = ceil_div(N, chunks);
@@ -525,21 +541,16 @@ int launch_rev_build(const int32_t *idx, int B, int N, int k, int *cnt, int *ind
             attr_done[dev] = true;
         }
     }
-    // (with_count = false: cnt comes from the forward, where the counting pass rode in the per-point product, and the call's
-    // counters are already zero)
-    if (!with_count) {
-    } else if (k > 64)
+    if (k > 64)
         hipLaunchKernelGGL((rev_count_kernel<true>), dim3(B * chunks), dim3(64), lds, st, idx, N, k, chunks, rows_per, cnt,
                            zero_words, nzero);
     else
         hipLaunchKernelGGL((rev_count_kernel<false>), dim3(B * chunks), dim3(64), lds, st, idx, N, k, chunks, rows_per, cnt,
                            zero_words, nzero);
     if (!with_slots) return 0;  // (the caller carries the list-space pass in its next launch: launch_bwd_point)
-    RevSlotsArgs sa = rev_slots_args(B, N, k, cnt, indeg, rowptr, segbase, pcnt, alloc, extra);
-    sa.cnt_out = slots_out;
-    hipLaunchKernelGGL(rev_slots_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, st, sa);
+    hipLaunchKernelGGL(rev_slots_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, st, rev_slots_args(B, N, k, cnt, indeg, rowptr, segbase, pcnt, alloc, extra));
     if (!with_place) return 0;
-    return launch_rev_place(idx, B, N, k, slots_out ? slots_out : cnt, rev, st);
+    return launch_rev_place(idx, B, N, k, cnt, rev, st);
 }
 
 // The reverse adjacencies of nblk graphs over the same B x N points (idx [nblk][B][N][k], contiguous) in three launches: the
@@ -816,6 +827,8 @@ __device__ __forceinline__ void rgather_publish(const RgatherCtx &cx, int pt, in
     if (lane == 0) last = ticket(cx.pcnt + pt) == nseg - 1 ? 1 : 0;
     last = __builtin_amdgcn_readfirstlane(last);
     if (!last) return;
+    // (the counter is zero again for the next backward that walks these lists: they may come from the forward, built once)
+    if (lane == 0) __hip_atomic_store((gu32 *)(cx.pcnt + pt), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     float tq = ld_sc1_f32(cx.part0 + (size_t)pt * 128 + lane), td = ld_sc1_f32(cx.part0 + (size_t)pt * 128 + 64 + lane);
     const float *px = cx.partx + (size_t)sb * 128;
     for (int s0 = 0; s0 < nseg - 1; s0 += 8) {  // 8 partials in flight, added in segment order
@@ -1032,21 +1045,27 @@ __global__ void graph_feature_bwd_kernel(const float *__restrict__ gout, const i
 
 // ---------------------------------------------------------------------------------------------
 void launch_edge_reduce(const float *TP, const float *TQ, const int32_t *idx, int N, int k, int P, const float *gamma,
-                        float *usel, float *usum, uint8_t *hitj, const FoldSet &fs, const BnBatchStats *fin, hipStream_t st)
+                        float *usel, float *usum, uint8_t *hitj, const FoldSet &fs, const BnBatchStats *fin, hipStream_t st,
+                        const RevSlotsArgs *slots)
 {
-    const dim3 grid(edge_grid(P)), block(256);
+    const int nmain = edge_grid(P);
+    const dim3 block(256);
     const BnBatchStats f = fin ? *fin : BnBatchStats{};
+    const RevSlotsArgs none{0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0, 0, 0};
+    // (slots: only with fin -- the training forward -- see edge_reduce_kernel)
+    const dim3 grid(nmain + (slots && fin ? slots->nblk * ceil_div(slots->Pblk, 256) : 0));
+    const RevSlotsArgs sa = slots && fin ? *slots : none;
     prof_begin(PROF_EDGE_REDUCE, st);
     if (usel) {
         if (fin)
             hipLaunchKernelGGL((edge_reduce_kernel<true, true>), grid, block, 0, st, TP, TQ, idx, N, k, P, gamma, usel, usum,
-                               hitj, fs, f);
+                               hitj, fs, f, nmain, sa);
         else
             hipLaunchKernelGGL((edge_reduce_kernel<true, false>), grid, block, 0, st, TP, TQ, idx, N, k, P, gamma, usel, usum,
-                               hitj, fs, f);
+                               hitj, fs, f, nmain, sa);
     } else {
         hipLaunchKernelGGL((edge_reduce_kernel<false, true>), grid, block, 0, st, TP, TQ, idx, N, k, P, gamma, usel, usum,
-                           hitj, fs, f);
+                           hitj, fs, f, nmain, sa);
     }
     prof_end(PROF_EDGE_REDUCE, st);
 }
@@ -1060,7 +1079,7 @@ void launch_edge_out(const float *usel, const float *stats, float slope, int P, 
 
 void launch_bwd_point(const float *gy, const float *usel, const float *stats, float slope, int P, double count,
                       int training, const FoldSet &fs, float *gbn_w, float *gbn_b, float *cc, unsigned *gmax_bits,
-                      const RevSlotsArgs *slots, hipStream_t st, int ldgy, const float *gy2, float *gdv)
+                      const RevSlotsArgs *slots, hipStream_t st, int ldgy, const float *gy2, float *gdv, const RevPlaceArgs *place)
 {
     int grid = ceil_div(P, EDGE_WAVES * 8);
     if (grid > 512) grid = 512;
@@ -1068,8 +1087,8 @@ void launch_bwd_point(const float *gy, const float *usel, const float *stats, fl
     // (slots: the list-space pass of the reverse adjacency rides behind this pass's workgroups, see rev_slots_pass)
     const RevSlotsArgs none{0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0, 0, 0};
     const int extra_wgs = slots ? slots->nblk * ceil_div(slots->Pblk, 256) : 0;
-    hipLaunchKernelGGL(bwd_point_kernel, dim3(grid + extra_wgs), dim3(256), 0, st, gy, ldgy > 0 ? ldgy : EC, gy2, gdv, usel, stats,
-                       slope, P, fs, fin, gmax_bits, grid, slots ? *slots : none);
+    hipLaunchKernelGGL(bwd_point_kernel, dim3(grid + extra_wgs + (place ? place->nblocks : 0)), dim3(256), 0, st, gy, ldgy > 0 ? ldgy : EC, gy2, gdv, usel, stats,
+                       slope, P, fs, fin, gmax_bits, grid, slots ? *slots : none, place ? *place : RevPlaceArgs{}, extra_wgs);
 }
 
 void launch_graph_feature_fwd(const float *x, const int32_t *idx, int B, int N, int C, int k, float *out,

@@ -43,13 +43,18 @@ struct Carver {
 struct SavedLayout {
     float *TP, *TQ, *usel, *usum, *stats1, *stats2, *wcat;
     uint8_t *hitj;
-    int *cnt, *bzero;  // lists_in_forward: the count tables of the reverse lists and the backward's counters (zeroed by the forward)
+    // lists_in_forward: the first-slot tables of the reverse lists, their per-point arrays (list start, in-degree, first extra
+    // segment, arrival counter), the extra (point, segment) pairs, and the backward's counters (zeroed by the forward)
+    int *cnt, *bzero, *rowptr, *indeg, *segbase, *pcnt, *extra;
     size_t bytes;
 };
-// Training forward of a 64-channel block: the counting pass of the backward's reverse neighbour lists rides in the forward's
-// per-point product (pointgemm.hip, rev_count_rider), its tables [B rev_chunks][N] wait in the saved state, and the backward
-// starts at its BatchNorm sums.  The forward also zeroes the backward's counters (they live in the saved state too); the
-// backward's last launch zeroes them again, so that a second backward from the same saved state finds them as the first did.
+// Training forward of a 64-channel block: the first two passes of the backward's reverse neighbour lists ride in the forward --
+// the counting pass in the per-point product's launch (pointgemm.hip, rev_count_rider: a kernel bound by its matrix
+// instructions next to one bound by its LDS atomics), the list-space pass in the gather / reduce pass's (rev_slots_pass) -- and
+// the third, the placement, rides in the backward's first launch (bwd_point).  What the forward leaves waits in the saved
+// state: the first-slot tables [B rev_chunks][N], the per-point arrays, the extra-segment pairs and the backward's counters
+// (zeroed by the forward; the list allocation pair keeps its values, the rest is zeroed again by the backward's last launch,
+// the arrival counters by their last arrivers: a second backward from the same saved state finds everything as the first did).
 // A function of the descriptor alone: the two calls must agree.
 static bool lists_in_forward(const dgcnn_edgeconv_desc *d)
 {
@@ -71,8 +76,13 @@ static SavedLayout saved_layout(const dgcnn_edgeconv_desc *d, void *p)
     if (lists_in_forward(d)) {
         s.cnt = c.take<int>((size_t)d->B * rev_chunks(d->B, d->N, d->k) * d->N);
         s.bzero = c.take<int>(Z_WORDS);
+        s.rowptr = c.take<int>(P);
+        s.indeg = c.take<int>(P);
+        s.segbase = c.take<int>(P);
+        s.pcnt = c.take<int>(P);
+        s.extra = c.take<int>(2 * (P * d->k / REV_SEG + 1));
     } else {
-        s.cnt = nullptr, s.bzero = nullptr;
+        s.cnt = s.bzero = s.rowptr = s.indeg = s.segbase = s.pcnt = s.extra = nullptr;
     }
     s.bytes = c.off;
     return s;
@@ -234,19 +244,22 @@ int dgcnn::edgeconv_fwd_ld(const dgcnn_edgeconv_desc *d, const EdgeLd &ld, const
         sd.bn[0] = d->bn1, sd.stats[0] = s.stats1;
         sd.bn[1] = d->bn2, sd.stats[1] = s.stats2;
     }
-    if (lists_in_forward(d) && !ld.no_fwd_lists) {
+    const bool lists = lists_in_forward(d) && !ld.no_fwd_lists;
+    if (lists) {
         const int chunks = rev_chunks(d->B, N, k);
         sd.rc = RevCountRider{idx, N, k, chunks, ceil_div(N, chunks), d->B * chunks, 0, s.cnt, s.bzero, Z_WORDS};
     }
+    const RevSlotsArgs slots_ = rev_slots_args(d->B, N, k, s.cnt, s.indeg, s.rowptr, s.segbase, s.pcnt, s.bzero + Z_ALLOC, s.extra);
+    const RevSlotsArgs *slots = lists ? &slots_ : nullptr;   // (training mode: both forms of the block run edge_reduce)
     launch_rowgemm_fwd(x, C, d->w1, s.TP, s.TQ, sd, P, st, ld.x);
     const FoldSet fs1{w.f1.rec, w.f1.folded, w.zero + Z_FOLD_A}, fs2{w.f2.rec, w.f2.folded, w.zero + Z_FOLD_B};
     const BnBatchStats fin1{d->bn1, E, d->eps, d->momentum, s.stats1}, fin2{d->bn2, E, d->eps, d->momentum, s.stats2};
     if (d->n_stage == 1) {
         launch_edge_reduce(s.TP, s.TQ, idx, N, k, P, d->bn1.weight, s.usel, s.usum, s.hitj, fs1, d->training ? &fin1 : nullptr,
-                           st);
+                           st, slots);
         launch_edge_out(s.usel, s.stats1, d->slope, P, y, st, ld.y);
     } else {
-        if (d->training) launch_edge_reduce(s.TP, s.TQ, idx, N, k, P, d->bn1.weight, nullptr, s.usum, nullptr, fs1, &fin1, st);
+        if (d->training) launch_edge_reduce(s.TP, s.TQ, idx, N, k, P, d->bn1.weight, nullptr, s.usum, nullptr, fs1, &fin1, st, slots);
         const FoldSet fs3{w.f2.rec, w.f2.folded, w.zero + Z_FOLD_C};
         launch_edge_mlp_fwd(s.TP, s.TQ, idx, N, k, P, s.stats1, d->w2, d->bn2.weight, d->slope, s.usel, s.hitj, fs2, fs3,
                             d->training ? &fin2 : nullptr, w.zero + Z_GUARD, st);
@@ -291,26 +304,31 @@ int dgcnn::edgeconv_bwd_ld(const dgcnn_edgeconv_desc *d, const EdgeLd &ld, const
     // per-point pass, costs more in cross-stream barriers than it hides: 0.776 ms against 0.725 ms per step)
     // The reverse adjacency: its counting pass first (it also zeroes the call's counters), its list-space pass inside the
     // launch of bwd_point (two short passes that leave most of the chip idle on their own), then the placement.
-    // Large batches (>= 16 batch elements): the three list passes back to back, in front of bwd_point.  Riding in
-    // bwd_point's launch, the list-space pass put the placement pass BEHIND bwd_point, which since round 4 streams 57 MB of
-    // dL/dy . LReLU'(y) at B = 32: the placement's scattered stores then ran into that write-back (110 us against 91 per
-    // launch).  Small batches keep the rider (two short passes that each leave most of the chip idle).
+    // Large batches (>= 16 batch elements): the list passes that run in this call back to back, in front of bwd_point.  Riding
+    // in bwd_point's launch, the placement pass meets the 57 MB of dL/dy . LReLU'(y) that bwd_point streams at B = 32: its
+    // scattered stores then run into that write-back (110 us against 80 per launch).  Small batches ride.
     const bool lists_first = !pre && d->B >= 16;
-    // (the counts and the zeroed counters come from the forward where its per-point product carried the counting pass)
-    const bool counted = !pre && lists_in_forward(d) && !ld.no_fwd_lists;
-    if (counted) w.zero = s.bzero;
-    int *counts = counted ? s.cnt : w.cnt;  // (the forward's counts are read only: the first slots go to w.cnt)
-    if (!pre && launch_rev_build(idx, d->B, N, k, counts, w.indeg, w.rowptr, w.segbase, w.pcnt, w.rev, w.zero + Z_ALLOC, w.extra,
-                                 w.zero, Z_WORDS, lists_first, lists_first, st, !counted, counted ? w.cnt : nullptr))
-        return 1;
-    RevSlotsArgs slots_ = rev_slots_args(d->B, N, k, counts, w.indeg, w.rowptr, w.segbase, w.pcnt, w.zero + Z_ALLOC, w.extra);
-    if (counted) slots_.cnt_out = w.cnt;
-    const RevSlotsArgs *slots = (pre || lists_first) ? nullptr : &slots_;
-    const bool place_later = !pre && !lists_first;
+    // the forward has counted and allotted the lists (lists_in_forward): only the placement is left -- in bwd_point's launch
+    const bool allotted = !pre && lists_in_forward(d) && !ld.no_fwd_lists;
+    if (allotted) {
+        w.zero = s.bzero, w.cnt = s.cnt, w.indeg = s.indeg, w.rowptr = s.rowptr, w.segbase = s.segbase, w.pcnt = s.pcnt;
+        w.extra = s.extra;
+        if (lists_first && launch_rev_place(idx, d->B, N, k, w.cnt, w.rev, st)) return 1;
+    } else if (!pre) {
+        if (launch_rev_build(idx, d->B, N, k, w.cnt, w.indeg, w.rowptr, w.segbase, w.pcnt, w.rev, w.zero + Z_ALLOC, w.extra, w.zero,
+                             Z_WORDS, lists_first, lists_first, st))
+            return 1;
+    }
+    const RevSlotsArgs slots_ = rev_slots_args(d->B, N, k, w.cnt, w.indeg, w.rowptr, w.segbase, w.pcnt, w.zero + Z_ALLOC, w.extra);
+    const RevSlotsArgs *slots = (pre || lists_first || allotted) ? nullptr : &slots_;
+    const bool place_later = !pre && !lists_first && !allotted;
+    const int rchunks = rev_chunks(d->B, N, k);
+    const RevPlaceArgs place_{idx, N, k, rchunks, ceil_div(N, rchunks), d->B * rchunks, w.cnt, w.rev, d->B, 0};
+    const RevPlaceArgs *place = allotted && !lists_first ? &place_ : nullptr;
     const FoldSet fsa{w.fa.rec, w.fa.folded, w.zero + Z_FOLD_A}, fsb{w.fb.rec, w.fb.folded, w.zero + Z_FOLD_B};
     if (d->n_stage == 1) {
         launch_bwd_point(gy, s.usel, s.stats1, d->slope, P, E, d->training, fsa, g->gbn1_w, g->gbn1_b, w.cc1, nullptr, slots, st,
-                         ld.gy, ld.gy2, w.gdv);
+                         ld.gy, ld.gy2, w.gdv, place);
         if (place_later && launch_rev_place(idx, d->B, N, k, w.cnt, w.rev, st)) return 1;
         if (launch_edge_bwd(s.TP, s.TQ, d->B, N, k, s.stats1, w.cc1, d->slope, w.gdv, s.hitj, s.usum, nullptr, nullptr,
                             w.rowptr, w.indeg, w.segbase, w.pcnt, w.rev, w.zero + Z_ALLOC, w.extra, w.hits, w.G, w.part0,
@@ -318,7 +336,7 @@ int dgcnn::edgeconv_bwd_ld(const dgcnn_edgeconv_desc *d, const EdgeLd &ld, const
             return 1;
     } else {
         launch_bwd_point(gy, s.usel, s.stats2, d->slope, P, E, d->training, fsa, g->gbn2_w, g->gbn2_b, w.cc2,
-                         reinterpret_cast<unsigned *>(w.zero + Z_GMAX), slots, st, ld.gy, ld.gy2, w.gdv);
+                         reinterpret_cast<unsigned *>(w.zero + Z_GMAX), slots, st, ld.gy, ld.gy2, w.gdv, place);
         if (place_later && launch_rev_place(idx, d->B, N, k, w.cnt, w.rev, st)) return 1;
         const BnBackwardSums fin1{E, d->training, g->gbn1_w, g->gbn1_b, w.cc1};
         const FoldSet fsc{w.fb.rec, w.fb.folded, w.zero + Z_FOLD_C};
@@ -334,11 +352,11 @@ int dgcnn::edgeconv_bwd_ld(const dgcnn_edgeconv_desc *d, const EdgeLd &ld, const
             return 1;
     }
     launch_wgrad(w.dR, EC, w.dD, EC, x, C, P, w.wg_partial, st, ld.x);
-    int *rezero = counted ? s.bzero : nullptr;
+    int *rezero = allotted ? s.bzero : nullptr;
     if (g->gx)
-        launch_dgrad_and_dw1(w.dR, w.dD, s.wcat, C, g->gx, ld.gx, ld.gx_acc, P, w.wg_partial, wgrad_chunks(P, C), g->gw1, st, rezero, Z_WORDS);
+        launch_dgrad_and_dw1(w.dR, w.dD, s.wcat, C, g->gx, ld.gx, ld.gx_acc, P, w.wg_partial, wgrad_chunks(P, C), g->gw1, st, rezero, Z_ALLOC);
     else
-        launch_finish_dw1(w.wg_partial, wgrad_chunks(P, C), C, g->gw1, st, rezero, Z_WORDS);
+        launch_finish_dw1(w.wg_partial, wgrad_chunks(P, C), C, g->gw1, st, rezero, Z_ALLOC);
     DG_CHECK_LAUNCH("dgcnn_edgeconv_bwd");
     return 0;
 }
