@@ -98,6 +98,8 @@ enum {
 struct RevPrebuilt {
     int *zero, *indeg, *rowptr, *segbase, *pcnt, *rev, *extra;
 };
+// does the training forward of this block prepare the backward's reverse lists (edgeconv.hip, lists_in_forward)?
+bool edgeconv_lists_in_forward(const dgcnn_edgeconv_desc *d);
 int edgeconv_bwd_ld(const dgcnn_edgeconv_desc *d, const EdgeLd &ld, const float *x, const int32_t *idx, const float *y,
                     const float *gy, const void *saved, const dgcnn_edgeconv_grads *g, void *workspace, size_t workspace_bytes,
                     void *stream, const RevPrebuilt *pre = nullptr);
@@ -143,12 +145,17 @@ struct RevSlotsArgs {
     // a merged build of nblk graphs of Pblk points each (launch_rev_build_merged): alloc / extra of graph g at
     // alloc + g alloc_stride ints, extra + g extra_stride pairs; one graph: nblk = 1, Pblk = P
     int nblk, Pblk, alloc_stride, extra_stride;
+    int *cnt_out = nullptr;  // where the first slots go (NULL: over the counts, in place).  The counts of a training forward stay as
+                             // they are when the list-space pass runs in the backward: a second backward reads them again
 };
 RevSlotsArgs rev_slots_args(int B, int N, int k, int *cnt, int *indeg, int *rowptr, int *segbase, int *pcnt, int *alloc,
                             int *extra);
 int launch_rev_build(const int32_t *idx, int B, int N, int k, int *cnt, int *indeg, int *rowptr, int *segbase, int *pcnt,
                      int32_t *rev, int *alloc, int *extra, int *zero_words, int nzero, bool with_slots, bool with_place,
                      hipStream_t st);
+// the second and third pass alone, from counts that another call left (read only): the first slots go to `slots` [B rev_chunks][N]
+int launch_rev_slots_place(const int32_t *idx, int B, int N, int k, const int *counts, int *slots, int *indeg, int *rowptr, int *segbase,
+                           int *pcnt, int32_t *rev, int *alloc, int *extra, hipStream_t st);
 int launch_rev_place(const int32_t *idx, int B, int N, int k, const int *cnt, int32_t *rev, hipStream_t st);
 struct RevPlaceArgs {
     const int32_t *idx;

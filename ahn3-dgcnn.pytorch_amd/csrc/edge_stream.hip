@@ -47,6 +47,7 @@ static int stream_grid(int P)  // passes without partial records
 // Also written for the backward: usum[i] = sum_j u[i][j] (fp32) and, with WANT_EXT, hitj[i] = the slot j (0..k-1)
 // of the FIRST edge attaining the extreme (PyTorch's max routes the gradient to the first maximum).
 // FIN: the pass also finishes the BatchNorm batch statistics (training mode, fold.h); without it the sums are dropped.
+template <int NB>
 __device__ __forceinline__ void rev_slots_pass(const RevSlotsArgs &a, int block);
 template <bool WANT_EXT, bool FIN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void edge_reduce_kernel(const float *__restrict__ TP, const float *__restrict__ TQ,
@@ -57,8 +58,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
 {
     // workgroups nmain .. (training forward of a block whose per-point product carried the counting pass of the backward's
     // reverse lists): the list-space pass, which needs those counts and nothing of this pass
+    // (four loads in flight per thread instead of sixteen: the rider must fit the register budget of THIS pass, whose eight
+    // waves per SIMD hide its gathers -- with the sixteen-deep form the kernel went from 62 to 73 registers, six waves, and
+    // lost 6 us at B = 8 and 63 us at B = 32; the rider has the whole gather pass to finish in)
     if (FIN && (int)blockIdx.x >= nmain) {
-        rev_slots_pass(slots, (int)blockIdx.x - nmain);
+        rev_slots_pass<4>(slots, (int)blockIdx.x - nmain);
         return;
     }
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // (visibly uniform)
@@ -171,6 +175,8 @@ __global__ void edge_out_kernel(const float *__restrict__ usel, const float *__r
 // arrival counter of its segments in edge_rgather_kernel).
 // (A device function: the pass rides in the launch of bwd_point_kernel -- both are short passes that leave most of the
 // chip idle on their own -- as the workgroups behind that kernel's own; `block` = index among the pass's workgroups.)
+// NB: loads in flight per thread over the chunks of a point's count column
+template <int NB>
 __device__ __forceinline__ void rev_slots_pass(const RevSlotsArgs &a, int block)
 {
     // a merged build (nblk graphs of Pblk points each, side by side: the three blocks of the model in one launch): a workgroup
@@ -184,17 +190,18 @@ __device__ __forceinline__ void rev_slots_pass(const RevSlotsArgs &a, int block)
     int2 *__restrict__ extra = a.extra + (size_t)blk * a.extra_stride;
     const int g = blk * a.Pblk + gl;
     int deg = 0;
-    int *cb = nullptr;
+    int *cb = nullptr, *co = nullptr;
     if (live) {
         const int b = g / N, m = g - b * N;
         cb = cnt + (size_t)b * chunks * N + m;
+        co = (a.cnt_out ? a.cnt_out : cnt) + (size_t)b * chunks * N + m;
         int c = 0;
-        for (; c + 16 <= chunks; c += 16) {  // 16 loads in flight (one workgroup per CU: nothing else hides them)
-            int v[16];
+        for (; c + NB <= chunks; c += NB) {  // NB loads in flight (alone in a launch: one workgroup per CU, nothing else hides them)
+            int v[NB];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = cb[(size_t)(c + u) * N];
+            for (int u = 0; u < NB; ++u) v[u] = cb[(size_t)(c + u) * N];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) deg += v[u];
+            for (int u = 0; u < NB; ++u) deg += v[u];
         }
         for (; c < chunks; ++c) deg += cb[(size_t)c * N];
     }
@@ -240,19 +247,19 @@ __device__ __forceinline__ void rev_slots_pass(const RevSlotsArgs &a, int block)
         segbase[g] = sb;
         pcnt[g] = 0;
         int c = 0;
-        for (; c + 16 <= chunks; c += 16) {
-            int v[16];
+        for (; c + NB <= chunks; c += NB) {
+            int v[NB];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = cb[(size_t)(c + u) * N];
+            for (int u = 0; u < NB; ++u) v[u] = cb[(size_t)(c + u) * N];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                cb[(size_t)(c + u) * N] = slot;
+            for (int u = 0; u < NB; ++u) {
+                co[(size_t)(c + u) * N] = slot;
                 slot += v[u];
             }
         }
         for (; c < chunks; ++c) {
             const int n = cb[(size_t)c * N];
-            cb[(size_t)c * N] = slot;
+            co[(size_t)c * N] = slot;
             slot += n;
         }
         for (int sg = 0; sg < nseg; ++sg) extra[sb + sg] = int2{gl, sg + 1};  // (the point's number inside its graph)
@@ -288,7 +295,7 @@ __global__ __launch_bounds__(256) void bwd_point_kernel(const float *__restrict_
         return;
     }
     if ((int)blockIdx.x >= nbp) {
-        rev_slots_pass(slots, (int)blockIdx.x - nbp);
+        rev_slots_pass<16>(slots, (int)blockIdx.x - nbp);
         return;
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -461,16 +468,26 @@ __device__ __forceinline__ void rev_place_pass(const RevPlaceArgs &a, int block,
     // edge ids local to the graph)
     const int blk = b / a.Bblk, bl = b - blk * a.Bblk;
     int32_t *__restrict__ rev = a.rev + (size_t)blk * a.Eblk;
+    // the first slots of this chunk's edges in every list: 16 loads in flight, then 16 LDS writes
+    auto load_table = [&]() {
+        for (int m0 = 0; m0 < N; m0 += 64 * 16) {
+            int v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = first[m0 + u * 64 + lane < N ? m0 + u * 64 + lane : 0];
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (m0 + u * 64 + lane < N) table[m0 + u * 64 + lane] = v[u];
+        }
+    };
+    // (measured, round 4: a ring of four row groups instead of two, and a branch-free form for k <= 64 -- lanes past k sitting out,
+    // whole groups only, the eight LDS atomics of a group in flight together and its eight stores in one batch: 107 -> 109 us per
+    // launch at B = 32 with the index rows coming from memory, the rider in bwd_point 76 -> 86 us per step at B = 4.  What the
+    // pass follows is the latency of its index rows when they are not in L2: 80 us per launch at B = 32 directly behind the
+    // counting pass, which leaves them there, 107 us since that pass moved into the forward; a probe kernel that reads the rows
+    // ahead brings the 80 back and costs the 26 it saves.)
     RevRows<K2> ra, rb;
     rev_load_rows<K2>(ib, k, r0, r1, lane, ra);
-    for (int m0 = 0; m0 < N; m0 += 64 * 16) {  // 16 loads in flight, then 16 LDS writes
-        int v[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = first[m0 + u * 64 + lane < N ? m0 + u * 64 + lane : 0];
-#pragma unroll
-        for (int u = 0; u < 16; ++u)
-            if (m0 + u * 64 + lane < N) table[m0 + u * 64 + lane] = v[u];
-    }
+    load_table();
     auto place = [&](const RevRows<K2> &v, int r) {
 #pragma unroll
         for (int u = 0; u < REV_ROWS; ++u) {
@@ -516,7 +533,7 @@ RevSlotsArgs rev_slots_args(int B, int N, int k, int *cnt, int *indeg, int *rowp
     return RevSlotsArgs{N, rev_chunks(B, N, k), B * N, cnt, rowptr, indeg, segbase, pcnt, alloc, reinterpret_cast<int2 *>(extra), 1, B * N,
                         0, 0};
 }
-__global__ __launch_bounds__(256) void rev_slots_kernel(RevSlotsArgs a) { rev_slots_pass(a, (int)blockIdx.x); }
+__global__ __launch_bounds__(256) void rev_slots_kernel(RevSlotsArgs a) { rev_slots_pass<16>(a, (int)blockIdx.x); }
 
 int launch_rev_build(const int32_t *idx, int B, int N, int k, int *cnt, int *indeg, int *rowptr, int *segbase, int *pcnt,
                      int32_t *rev, int *alloc, int *extra, int *zero_words, int nzero, bool with_slots, bool with_place,
@@ -551,6 +568,16 @@ int launch_rev_build(const int32_t *idx, int B, int N, int k, int *cnt, int *ind
     hipLaunchKernelGGL(rev_slots_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, st, rev_slots_args(B, N, k, cnt, indeg, rowptr, segbase, pcnt, alloc, extra));
     if (!with_place) return 0;
     return launch_rev_place(idx, B, N, k, cnt, rev, st);
+}
+
+int launch_rev_slots_place(const int32_t *idx, int B, int N, int k, const int *counts, int *slots, int *indeg, int *rowptr, int *segbase,
+                           int *pcnt, int32_t *rev, int *alloc, int *extra, hipStream_t st)
+{
+    DG_REQUIRE(N <= REV_MAX_N && k <= 64, "dgcnn: reverse lists from the forward's counts take N <= %d, k <= 64", REV_MAX_N);
+    RevSlotsArgs sa = rev_slots_args(B, N, k, const_cast<int *>(counts), indeg, rowptr, segbase, pcnt, alloc, extra);
+    sa.cnt_out = slots;
+    hipLaunchKernelGGL(rev_slots_kernel, dim3(ceil_div(B * N, 256)), dim3(256), 0, st, sa);
+    return launch_rev_place(idx, B, N, k, slots, rev, st);
 }
 
 // The reverse adjacencies of nblk graphs over the same B x N points (idx [nblk][B][N][k], contiguous) in three launches: the

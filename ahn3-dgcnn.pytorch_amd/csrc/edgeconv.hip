@@ -60,6 +60,8 @@ static bool lists_in_forward(const dgcnn_edgeconv_desc *d)
 {
     return d->training && rowgemm_fwd_carries_count(d->C, d->N, d->k);
 }
+bool edgeconv_lists_in_forward(const dgcnn_edgeconv_desc *d) { return lists_in_forward(d); }
+constexpr int LISTS_RIDE_BELOW = 16;  // batch elements from which on the list-space and placement passes run as launches of their own
 static SavedLayout saved_layout(const dgcnn_edgeconv_desc *d, void *p)
 {
     Carver c(p);
@@ -249,8 +251,10 @@ int dgcnn::edgeconv_fwd_ld(const dgcnn_edgeconv_desc *d, const EdgeLd &ld, const
         const int chunks = rev_chunks(d->B, N, k);
         sd.rc = RevCountRider{idx, N, k, chunks, ceil_div(N, chunks), d->B * chunks, 0, s.cnt, s.bzero, Z_WORDS};
     }
+    // (the list-space pass rides below sixteen batch elements only: at B = 32 its riders cost the gather / reduce pass 23 us per
+    // launch, more than the 18 us launch they replace; the backward then runs it from the forward's counts)
     const RevSlotsArgs slots_ = rev_slots_args(d->B, N, k, s.cnt, s.indeg, s.rowptr, s.segbase, s.pcnt, s.bzero + Z_ALLOC, s.extra);
-    const RevSlotsArgs *slots = lists ? &slots_ : nullptr;   // (training mode: both forms of the block run edge_reduce)
+    const RevSlotsArgs *slots = lists && d->B < LISTS_RIDE_BELOW ? &slots_ : nullptr;   // (training mode: both forms of the block run edge_reduce)
     launch_rowgemm_fwd(x, C, d->w1, s.TP, s.TQ, sd, P, st, ld.x);
     const FoldSet fs1{w.f1.rec, w.f1.folded, w.zero + Z_FOLD_A}, fs2{w.f2.rec, w.f2.folded, w.zero + Z_FOLD_B};
     const BnBatchStats fin1{d->bn1, E, d->eps, d->momentum, s.stats1}, fin2{d->bn2, E, d->eps, d->momentum, s.stats2};
@@ -307,24 +311,29 @@ int dgcnn::edgeconv_bwd_ld(const dgcnn_edgeconv_desc *d, const EdgeLd &ld, const
     // Large batches (>= 16 batch elements): the list passes that run in this call back to back, in front of bwd_point.  Riding
     // in bwd_point's launch, the placement pass meets the 57 MB of dL/dy . LReLU'(y) that bwd_point streams at B = 32: its
     // scattered stores then run into that write-back (110 us against 80 per launch).  Small batches ride.
-    const bool lists_first = !pre && d->B >= 16;
-    // the forward has counted and allotted the lists (lists_in_forward): only the placement is left -- in bwd_point's launch
-    const bool allotted = !pre && lists_in_forward(d) && !ld.no_fwd_lists;
+    const bool lists_first = !pre && d->B >= LISTS_RIDE_BELOW;
+    // the forward has counted (lists_in_forward) and, below sixteen batch elements, allotted the lists: then only the placement
+    // is left -- in bwd_point's launch; from sixteen on the list-space pass and the placement run here, from the forward's counts
+    const bool counted = !pre && lists_in_forward(d) && !ld.no_fwd_lists;
+    const bool allotted = counted && !lists_first;
     if (allotted) {
         w.zero = s.bzero, w.cnt = s.cnt, w.indeg = s.indeg, w.rowptr = s.rowptr, w.segbase = s.segbase, w.pcnt = s.pcnt;
         w.extra = s.extra;
-        if (lists_first && launch_rev_place(idx, d->B, N, k, w.cnt, w.rev, st)) return 1;
+    } else if (counted) {
+        w.zero = s.bzero;
+        if (launch_rev_slots_place(idx, d->B, N, k, s.cnt, w.cnt, w.indeg, w.rowptr, w.segbase, w.pcnt, w.rev, w.zero + Z_ALLOC, w.extra, st))
+            return 1;
     } else if (!pre) {
         if (launch_rev_build(idx, d->B, N, k, w.cnt, w.indeg, w.rowptr, w.segbase, w.pcnt, w.rev, w.zero + Z_ALLOC, w.extra, w.zero,
                              Z_WORDS, lists_first, lists_first, st))
             return 1;
     }
     const RevSlotsArgs slots_ = rev_slots_args(d->B, N, k, w.cnt, w.indeg, w.rowptr, w.segbase, w.pcnt, w.zero + Z_ALLOC, w.extra);
-    const RevSlotsArgs *slots = (pre || lists_first || allotted) ? nullptr : &slots_;
-    const bool place_later = !pre && !lists_first && !allotted;
+    const RevSlotsArgs *slots = (pre || lists_first || counted) ? nullptr : &slots_;
+    const bool place_later = !pre && !lists_first && !counted;
     const int rchunks = rev_chunks(d->B, N, k);
     const RevPlaceArgs place_{idx, N, k, rchunks, ceil_div(N, rchunks), d->B * rchunks, w.cnt, w.rev, d->B, 0};
-    const RevPlaceArgs *place = allotted && !lists_first ? &place_ : nullptr;
+    const RevPlaceArgs *place = allotted ? &place_ : nullptr;
     const FoldSet fsa{w.fa.rec, w.fa.folded, w.zero + Z_FOLD_A}, fsb{w.fb.rec, w.fb.folded, w.zero + Z_FOLD_B};
     if (d->n_stage == 1) {
         launch_bwd_point(gy, s.usel, s.stats1, d->slope, P, E, d->training, fsa, g->gbn1_w, g->gbn1_b, w.cc1, nullptr, slots, st,
@@ -352,11 +361,13 @@ int dgcnn::edgeconv_bwd_ld(const dgcnn_edgeconv_desc *d, const EdgeLd &ld, const
             return 1;
     }
     launch_wgrad(w.dR, EC, w.dD, EC, x, C, P, w.wg_partial, st, ld.x);
-    int *rezero = allotted ? s.bzero : nullptr;
+    // (the counters in the saved state are left at zero for the next backward; allotted lists keep their allocation pair)
+    int *rezero = counted ? s.bzero : nullptr;
+    const int nrezero = allotted ? Z_ALLOC : Z_WORDS;
     if (g->gx)
-        launch_dgrad_and_dw1(w.dR, w.dD, s.wcat, C, g->gx, ld.gx, ld.gx_acc, P, w.wg_partial, wgrad_chunks(P, C), g->gw1, st, rezero, Z_ALLOC);
+        launch_dgrad_and_dw1(w.dR, w.dD, s.wcat, C, g->gx, ld.gx, ld.gx_acc, P, w.wg_partial, wgrad_chunks(P, C), g->gw1, st, rezero, nrezero);
     else
-        launch_finish_dw1(w.wg_partial, wgrad_chunks(P, C), C, g->gw1, st, rezero, Z_ALLOC);
+        launch_finish_dw1(w.wg_partial, wgrad_chunks(P, C), C, g->gw1, st, rezero, nrezero);
     DG_CHECK_LAUNCH("dgcnn_edgeconv_bwd");
     return 0;
 }

@@ -306,11 +306,16 @@ extern "C" size_t dgcnn_model_bwd_workspace_bytes(const dgcnn_model_desc *d)
     return bwd_ws(d, nullptr).bytes;
 }
 
-// the backward builds the reverse lists of the three graphs in one go (see dgcnn_model_bwd); the forward must know: its blocks
-// then leave the counting pass of their own lists alone (EdgeLd::no_fwd_lists)
+// the backward builds the reverse lists of the three graphs in one go (see dgcnn_model_bwd) -- where the blocks' training
+// forwards do not prepare them (edgeconv.hip, lists_in_forward: then the list passes ride in launches that run anyway and the
+// backward has nothing to build).  The forward must know the answer too (EdgeLd::no_fwd_lists).
 static bool lists_merged(const dgcnn_model_desc *d)
 {
     const size_t En = (size_t)d->B * d->N * d->k;
+    for (int b = 0; b < 3; ++b) {
+        const dgcnn_edgeconv_desc e = block_desc(d, b);
+        if (edgeconv_lists_in_forward(&e)) return false;
+    }
     return d->idx[1] == d->idx[0] + En && d->idx[2] == d->idx[1] + En && (size_t)3 * En < ((size_t)1 << 31) &&
            (size_t)3 * En * sizeof(int) <= (size_t)8 * 3584 * 1024;
 }

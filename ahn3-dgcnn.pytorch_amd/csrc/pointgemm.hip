@@ -93,6 +93,10 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(const float *__restrict__ 
     // the weights are read by every wave at every step: stage them in LDS (the kernel was bound by the
     // latency of those loads: 73 % of its wave cycles in s_waitcnt)
     __shared__ float wl[RG_LDS_FLOATS];
+    if (FROM_W1 && sd.rc.cnt && (int)blockIdx.x >= sd.rc.main_blocks) {  // the counting pass of the backward's reverse lists
+        rev_count_rider(sd.rc, (int)blockIdx.x - sd.rc.main_blocks, reinterpret_cast<int *>(wl));
+        return;
+    }
     const int K = K0 + K1, KH = (K + 1) >> 1;
     const bool staged = K * NO <= RG_LDS_FLOATS;
     if (FROM_W1) {  // K = C <= 64, NO = 128: always staged
@@ -178,7 +182,7 @@ __global__ __launch_bounds__(256) void rowgemm_fast_kernel(const float *__restri
 {
     constexpr int K = 2 * KH, NO = 32 * NT;
     __shared__ float wl[K * NO];
-    if (FROM_W1 && sd.rc.cnt && (int)blockIdx.x >= sd.rc.main_blocks) {
+    if (FROM_W1 && sd.rc.cnt && (int)blockIdx.x >= sd.rc.main_blocks) {  // the counting pass of the backward's reverse lists
         rev_count_rider(sd.rc, (int)blockIdx.x - sd.rc.main_blocks, reinterpret_cast<int *>(wl));
         return;
     }
@@ -566,8 +570,8 @@ static bool rowgemm_split_fwd()
 
 bool rowgemm_fwd_carries_count(int C, int N, int k)
 {
-    static const bool off = getenv("DGCNN_NO_FWD_LISTS") != nullptr;   // experiments / tests: the backward counts itself
-    return !off && C == 64 && !rowgemm_split_fwd() && N <= RG_LDS_FLOATS && k <= 64;
+    const bool off = getenv("DGCNN_NO_FWD_LISTS") != nullptr;   // experiments / tests (read per call: a test flips it): the backward builds its lists itself
+    return !off && !(C == 64 && rowgemm_split_fwd()) && N <= RG_LDS_FLOATS && k <= 64;
 }
 
 void launch_rowgemm_fwd(const float *x, int C, const float *w1, float *TP, float *TQ, const FwdSide &sd, int P, hipStream_t st,
@@ -577,14 +581,16 @@ void launch_rowgemm_fwd(const float *x, int C, const float *w1, float *TP, float
     const RowLd ld{ldx > 0 ? ldx : C, EC, 0};
     if (C == 64 && rowgemm_split_fwd())
         hipLaunchKernelGGL((rowgemm_split_kernel<32, 4, true>), grid, block, 0, st, x, C, nullptr, 0, w1, TP, EC, TQ, P, sd, ld, Dw1Rider{});
-    else if (C == 64) {
+    else {
+        // (sd.rc: the counting pass of the backward's reverse lists as workgroups behind the product's, see RevCountRider)
         FwdSide s2 = sd;
         s2.rc.main_blocks = (int)grid.x;
         const dim3 g2(grid.x + (sd.rc.cnt ? sd.rc.nblocks : 0));
-        hipLaunchKernelGGL((rowgemm_fast_kernel<32, 4, true>), g2, block, 0, st, x, C, nullptr, 0, w1, TP, EC, TQ, P, s2, ld);
+        if (C == 64)
+            hipLaunchKernelGGL((rowgemm_fast_kernel<32, 4, true>), g2, block, 0, st, x, C, nullptr, 0, w1, TP, EC, TQ, P, s2, ld);
+        else
+            hipLaunchKernelGGL((rowgemm_kernel<4, true>), g2, block, 0, st, x, C, nullptr, 0, w1, 128, TP, EC, TQ, P, s2, ld);
     }
-    else
-        hipLaunchKernelGGL((rowgemm_kernel<4, true>), grid, block, 0, st, x, C, nullptr, 0, w1, 128, TP, EC, TQ, P, sd, ld);
 }
 
 void launch_rowgemm(const float *A0, int K0, const float *A1, int K1, const float *W, int NO, float *Y0, int NO0,

@@ -382,10 +382,10 @@ def test_full_model_eval_at_stress_size(device):
 
 @pytest.mark.parametrize("F_,k,N,B", [(4, 9, 260, 3), (3, 20, 131, 2), (6, 33, 300, 1), (4, 6, 130, 18)])   # (the CLI's default is 3 features, k = 20)
 def test_model_level_call_against_the_per_layer_path(F_, k, N, B, device, monkeypatch):
-    """DGCNN.forward at depth 10 runs as dgcnn_model_fwd / _bwd (one call each way).  Three ways through the same kernels
-    must agree: (1) own kNN, the three graphs in ONE array -> the backward builds the three reverse lists in one go;
-    (2) the same graphs injected as three separate tensors -> per-block list builds: bit-identical to (1) (the lists are
-    sorted by edge id whoever builds them); (3) DGCNN_PER_LAYER=1: the per-layer entry points composed in Python, where the
+    """DGCNN.forward at depth 10 runs as dgcnn_model_fwd / _bwd (one call each way).  The ways through the same kernels
+    must agree: (1) own kNN, the reverse lists prepared by riders in the forward (training mode); (0) DGCNN_NO_FWD_LISTS=1: the
+    backward builds them -- the three graphs in ONE array -> in one go; (2) the same graphs injected as three separate tensors:
+    all bit-identical to (1) (the lists are sorted by edge id whoever builds them); (3) DGCNN_PER_LAYER=1: the per-layer entry points composed in Python, where the
     gradient fan-in of x1 / x2 / x3 is added by autograd in another order: equal within rounding."""
     from ahn3_dgcnn_pytorch_amd import DGCNN
     g = torch.Generator().manual_seed(12)
@@ -401,8 +401,17 @@ def test_model_level_call_against_the_per_layer_path(F_, k, N, B, device, monkey
         (y * R).sum().backward()
         return y.detach().clone(), used, {n: p.grad.detach().clone() for n, p in m.named_parameters()}
 
-    y1, used, g1 = run(None)
-    assert used[1].data_ptr() == used[0].data_ptr() + 4 * used[0].numel()          # one array: the merged build ran
+    y1, used, g1 = run(None)   # (training forward: the list passes of the three blocks ride in the forward's / backward's launches)
+    # (0) the backward builds the lists itself: the three graphs in ONE array -> one merged build; three tensors -> per block
+    monkeypatch.setenv("DGCNN_NO_FWD_LISTS", "1")
+    y0, used0, g0 = run(None)
+    assert used0[1].data_ptr() == used0[0].data_ptr() + 4 * used0[0].numel()       # one array: the merged build ran
+    y0b, _, g0b = run([u.clone() for u in used])
+    monkeypatch.delenv("DGCNN_NO_FWD_LISTS")
+    for ya, ga in ((y0, g0), (y0b, g0b)):
+        assert torch.equal(y1, ya)
+        for n in g1:
+            assert torch.equal(g1[n], ga[n]), n
     y2, _, g2 = run([u.clone() for u in used])
     assert torch.equal(y1, y2)
     for n in g1:
