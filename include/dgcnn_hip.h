@@ -86,7 +86,11 @@ int dgcnn_graph_feature_bwd(const float *gout, const int32_t *idx, int B, int N,
  * y   : point-major [B][N][64]
  * saved : opaque buffer of dgcnn_edgeconv_saved_bytes() that the forward fills and the
  *         backward reads (per-point projections, selected pre-activation extremes, BatchNorm
- *         batch statistics).
+ *         batch statistics; after a TRAINING forward with N <= 8192 and k <= 64 also the first two
+ *         passes of the backward's reverse neighbour lists and the backward's counters, which the
+ *         backward leaves ready for another backward from the same buffer).  The backward must be
+ *         given the descriptor the forward was given (the layout follows it), and a buffer belongs
+ *         to ONE forward at a time.
  * BatchNorm semantics are PyTorch's: training = biased batch variance for normalisation,
  * running_var updated with the unbiased one, running = (1 - momentum) * running + momentum *
  * batch; eval = running statistics.  num_batches_tracked: incremented by a training-mode forward when the
