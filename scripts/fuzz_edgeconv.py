@@ -13,7 +13,7 @@ rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 bad = skipped = 0
 for it in range(n_cases):
-    B = int(rng.choice([1, 2, 3])); C = int(rng.choice([3, 4, 9, 16, 64])); N = int(rng.choice([40, 100, 257, 400, 700]))
+    B = int(rng.choice([1, 2, 3, 16])); C = int(rng.choice([3, 4, 9, 16, 64])); N = int(rng.choice([40, 100, 257, 400, 700]))
     k = int(rng.choice([3, 8, 16, 20, 30, 40])); k = min(k, N - 1)
     n_stage = int(rng.choice([1, 2])); train = bool(rng.integers(0, 2))
     graph = str(rng.choice(["knn", "random", "hub"]))
