@@ -61,7 +61,14 @@ struct Dw1Rider {
     int main_blocks;
     int *zero_words;  // counters the call leaves at zero behind itself (its last launch), or NULL
     int nzero;
+    // INSTEAD of the fold: the weight-gradient product itself rides (wgrad_split64_body; x, its row stride, the partials)
+    const float *wg_x;
+    int wg_ldx;
+    float *wg_partial;
 };
+bool dgrad_wgrad64_fused(int C);
+void launch_dgrad_wgrad64(const float *dR, const float *dD, const float *wcat, float *gx, int ldgx, int gx_acc, int P, const float *x,
+                          int ldx, float *partial, float *gw1, hipStream_t st, int *zero_words = nullptr, int nzero = 0);
 void launch_dgrad_and_dw1(const float *dR, const float *dD, const float *wcat, int C, float *gx, int ldgx, int gx_acc, int P,
                           const float *partial, int nchunk, float *gw1, hipStream_t st, int *zero_words = nullptr, int nzero = 0);
 // out[e] = sum_chunk partial[chunk][e]   (fixed order: deterministic)

@@ -360,6 +360,12 @@ int dgcnn::edgeconv_bwd_ld(const dgcnn_edgeconv_desc *d, const EdgeLd &ld, const
                             w.part0, w.partx, w.dR, w.dD, st, &fold_gw2))
             return 1;
     }
+    if (g->gx && dgrad_wgrad64_fused(C)) {   // the two products of the first convolution's backward in one launch, then the fold
+        launch_dgrad_wgrad64(w.dR, w.dD, s.wcat, g->gx, ld.gx, ld.gx_acc, P, x, ld.x, w.wg_partial, g->gw1, st, counted ? s.bzero : nullptr,
+                             allotted ? Z_ALLOC : Z_WORDS);
+        DG_CHECK_LAUNCH("dgcnn_edgeconv_bwd");
+        return 0;
+    }
     launch_wgrad(w.dR, EC, w.dD, EC, x, C, P, w.wg_partial, st, ld.x);
     // (the counters in the saved state are left at zero for the next backward; allotted lists keep their allocation pair)
     int *rezero = counted ? s.bzero : nullptr;

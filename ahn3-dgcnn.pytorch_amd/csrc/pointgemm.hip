@@ -310,6 +310,90 @@ __global__ __launch_bounds__(1024) void finish_dw1_kernel(const float *__restric
     finish_dw1_body<16>(partial, nchunk, C, gw1, (int)blockIdx.x, zero_words, nzero);
 }
 
+constexpr int WGRAD_FAST_POINTS = 256;
+// The same product on the fp16 matrix cores (the fp32 kernel above is bound by its 256 matrix instructions of 64 cycles per
+// wave: 21.5 us at P = 56 000 against 9.4 at the fp32 MFMA peak).  The contraction runs over the POINTS, so a lane's eight
+// consecutive k of an operand are eight points of its channel: eight 4-byte loads, each a 128-byte row segment per half
+// wave.  A wave takes its 256 points in four chunks of 64: the chunk's values wait in registers (32 of A, 64 of X per
+// lane), their largest magnitudes give the chunk's two exact power-of-two scales (gradients of any size, no range check),
+// both operands are split in two fp16 halves (edge_mlp16.h) and four steps of three v_mfma_f32_32x32x16_f16 per tile go
+// to a chunk accumulator, which joins the total with 1 / (sA sB): 96 matrix instructions of 32 cycles per wave.
+// (`block`: the index among the product's workgroups -- the body of wgrad_split64_kernel and of the workgroups that ride in the
+// input-gradient product's launch, rowgemm_split_kernel)
+__device__ __forceinline__ void wgrad_split64_body(const float *__restrict__ A0, const float *__restrict__ A1,
+                                                   const float *__restrict__ X, int ldx, int P, float *__restrict__ partial, int block)
+{
+    const int lane = threadIdx.x & 63, mt = threadIdx.x >> 6, h = lane >> 5, i32 = lane & 31;
+    const int pbeg = block * WGRAD_FAST_POINTS;
+    const int pend = pbeg + WGRAD_FAST_POINTS < P ? pbeg + WGRAD_FAST_POINTS : P;
+    const float *A = (mt < 2 ? A0 : A1) + (mt & 1) * 32;
+    f32x16 acc[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
+    for (int p0 = pbeg; p0 < pend; p0 += 64) {
+        float av[32], bv[2][32];
+        float amax = 0.0f, bmax = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {  // value q of the lane: point p0 + 16 (q / 8) + 8 h + q % 8
+            const int pp = p0 + 16 * (q >> 3) + 8 * h + (q & 7);
+            const bool pv = pp < pend;
+            const size_t ro = (size_t)(pv ? pp : pbeg) * 64 + i32;  // clamped row: unconditional loads, masked values
+            const size_t rx = (size_t)(pv ? pp : pbeg) * (size_t)ldx + i32;
+            const float a0 = A[ro], b0 = X[rx], b1 = X[rx + 32];
+            av[q] = pv ? a0 : 0.0f;
+            bv[0][q] = pv ? b0 : 0.0f;
+            bv[1][q] = pv ? b1 : 0.0f;
+        }
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+            amax = fmaxf(amax, fabsf(av[q]));
+            bmax = fmaxf(bmax, fmaxf(fabsf(bv[0][q]), fabsf(bv[1][q])));
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            amax = fmaxf(amax, __shfl_xor(amax, o));
+            bmax = fmaxf(bmax, __shfl_xor(bmax, o));
+        }
+        const float sA = scale_to(amax, 15), sB = scale_to(bmax, 15);
+        f32x16 cacc[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cacc[nt][r] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            unsigned H[4], L[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) split_pair(av[8 * s + 2 * j] * sA, av[8 * s + 2 * j + 1] * sA, H[j], L[j]);
+            const half8 ahi = words_as_half8(H[0], H[1], H[2], H[3]), alo = words_as_half8(L[0], L[1], L[2], L[3]);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) split_pair(bv[nt][8 * s + 2 * j] * sB, bv[nt][8 * s + 2 * j + 1] * sB, H[j], L[j]);
+                const half8 bhi = words_as_half8(H[0], H[1], H[2], H[3]), blo = words_as_half8(L[0], L[1], L[2], L[3]);
+                cacc[nt] = mfma3(ahi, alo, bhi, blo, cacc[nt]);
+            }
+        }
+        const float un = 1.0f / (sA * sB);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = __builtin_fmaf(cacc[nt][r], un, acc[nt][r]);
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            partial[((size_t)block * 128 + mt * 32 + mfma32_row(r, h)) * 64 + nt * 32 + i32] = acc[nt][r];
+}
+__global__ __launch_bounds__(256) void wgrad_split64_kernel(const float *__restrict__ A0, const float *__restrict__ A1,
+                                                            const float *__restrict__ X, int ldx, int P, float *__restrict__ partial)
+{
+    wgrad_split64_body(A0, A1, X, ldx, P, partial, (int)blockIdx.x);
+}
+
 // The same two products on the fp16 matrix cores: both operands scaled by an exact power of two and split in two fp16
 // halves, x' = hi + lo (edge_mlp16.h), three v_mfma_f32_32x32x16_f16 per 16 k (hi.hi + hi.lo + lo.hi, fp32 accumulate):
 // 48 matrix instructions of 32 cycles per 32-row tile instead of 128 of 64 -- the fp32 kernel above is bound by exactly
@@ -325,6 +409,13 @@ __global__ __launch_bounds__(256) void rowgemm_split_kernel(const float *__restr
                                                             float *__restrict__ Y1, int P, const FwdSide sd, const RowLd ld,
                                                             const Dw1Rider rd)
 {
+    // workgroups rd.main_blocks .. with rd.wg_x: the first convolution's WEIGHT gradient (wgrad_split64_body) beside its input
+    // gradient -- both read [dR | dD], neither needs the other, and the weight gradient's 219 workgroups of two waves per SIMD
+    // leave most of the chip idle on their own (16.2 + 15.3 us as two launches at B = 8, N = 7000)
+    if (!FROM_W1 && KH == 64 && rd.wg_x && (int)blockIdx.x >= rd.main_blocks) {
+        wgrad_split64_body(A0, A1, rd.wg_x, rd.wg_ldx, P, rd.wg_partial, (int)blockIdx.x - rd.main_blocks);
+        return;
+    }
     // workgroups rd.main_blocks .. : the weight gradient's fold (finish_dw1_body), riding in this launch
     if (!FROM_W1 && rd.gw1 && (int)blockIdx.x >= rd.main_blocks) {
         finish_dw1_body<4>(rd.partial, rd.nchunk, rd.C, rd.gw1, (int)blockIdx.x - rd.main_blocks, rd.zero_words, rd.nzero);
@@ -634,7 +725,6 @@ void launch_rowgemm(const float *A0, int K0, const float *A1, int K1, const floa
 // the 32 output rows w of [A0 | A1]^T X (two accumulator tiles), so a workgroup leaves ONE 128 x 64 partial per 256
 // points.  (One wave per 64 points, the first form, wrote 28 MB of partials at P = 56 000 -- more than the 43 MB the
 // product reads -- and finish_dw1_kernel read them back: 27 + 11 us.)
-constexpr int WGRAD_FAST_POINTS = 256;
 __global__ __launch_bounds__(256) void wgrad_fast64_kernel(const float *__restrict__ A0, const float *__restrict__ A1,
                                                            const float *__restrict__ X, int ldx, int P, float *__restrict__ partial)
 {
@@ -684,81 +774,6 @@ __global__ __launch_bounds__(256) void wgrad_fast64_kernel(const float *__restri
             partial[((size_t)blockIdx.x * 128 + mt * 32 + mfma32_row(r, h)) * 64 + nt * 32 + i32] = acc[nt][r];
 }
 
-// The same product on the fp16 matrix cores (the fp32 kernel above is bound by its 256 matrix instructions of 64 cycles per
-// wave: 21.5 us at P = 56 000 against 9.4 at the fp32 MFMA peak).  The contraction runs over the POINTS, so a lane's eight
-// consecutive k of an operand are eight points of its channel: eight 4-byte loads, each a 128-byte row segment per half
-// wave.  A wave takes its 256 points in four chunks of 64: the chunk's values wait in registers (32 of A, 64 of X per
-// lane), their largest magnitudes give the chunk's two exact power-of-two scales (gradients of any size, no range check),
-// both operands are split in two fp16 halves (edge_mlp16.h) and four steps of three v_mfma_f32_32x32x16_f16 per tile go
-// to a chunk accumulator, which joins the total with 1 / (sA sB): 96 matrix instructions of 32 cycles per wave.
-__global__ __launch_bounds__(256) void wgrad_split64_kernel(const float *__restrict__ A0, const float *__restrict__ A1,
-                                                            const float *__restrict__ X, int ldx, int P, float *__restrict__ partial)
-{
-    const int lane = threadIdx.x & 63, mt = threadIdx.x >> 6, h = lane >> 5, i32 = lane & 31;
-    const int pbeg = blockIdx.x * WGRAD_FAST_POINTS;
-    const int pend = pbeg + WGRAD_FAST_POINTS < P ? pbeg + WGRAD_FAST_POINTS : P;
-    const float *A = (mt < 2 ? A0 : A1) + (mt & 1) * 32;
-    f32x16 acc[2];
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
-    for (int p0 = pbeg; p0 < pend; p0 += 64) {
-        float av[32], bv[2][32];
-        float amax = 0.0f, bmax = 0.0f;
-#pragma unroll
-        for (int q = 0; q < 32; ++q) {  // value q of the lane: point p0 + 16 (q / 8) + 8 h + q % 8
-            const int pp = p0 + 16 * (q >> 3) + 8 * h + (q & 7);
-            const bool pv = pp < pend;
-            const size_t ro = (size_t)(pv ? pp : pbeg) * 64 + i32;  // clamped row: unconditional loads, masked values
-            const size_t rx = (size_t)(pv ? pp : pbeg) * (size_t)ldx + i32;
-            const float a0 = A[ro], b0 = X[rx], b1 = X[rx + 32];
-            av[q] = pv ? a0 : 0.0f;
-            bv[0][q] = pv ? b0 : 0.0f;
-            bv[1][q] = pv ? b1 : 0.0f;
-        }
-#pragma unroll
-        for (int q = 0; q < 32; ++q) {
-            amax = fmaxf(amax, fabsf(av[q]));
-            bmax = fmaxf(bmax, fmaxf(fabsf(bv[0][q]), fabsf(bv[1][q])));
-        }
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-            amax = fmaxf(amax, __shfl_xor(amax, o));
-            bmax = fmaxf(bmax, __shfl_xor(bmax, o));
-        }
-        const float sA = scale_to(amax, 15), sB = scale_to(bmax, 15);
-        f32x16 cacc[2];
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) cacc[nt][r] = 0.0f;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            unsigned H[4], L[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) split_pair(av[8 * s + 2 * j] * sA, av[8 * s + 2 * j + 1] * sA, H[j], L[j]);
-            const half8 ahi = words_as_half8(H[0], H[1], H[2], H[3]), alo = words_as_half8(L[0], L[1], L[2], L[3]);
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) split_pair(bv[nt][8 * s + 2 * j] * sB, bv[nt][8 * s + 2 * j + 1] * sB, H[j], L[j]);
-                const half8 bhi = words_as_half8(H[0], H[1], H[2], H[3]), blo = words_as_half8(L[0], L[1], L[2], L[3]);
-                cacc[nt] = mfma3(ahi, alo, bhi, blo, cacc[nt]);
-            }
-        }
-        const float un = 1.0f / (sA * sB);
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[nt][r] = __builtin_fmaf(cacc[nt][r], un, acc[nt][r]);
-    }
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            partial[((size_t)blockIdx.x * 128 + mt * 32 + mfma32_row(r, h)) * 64 + nt * 32 + i32] = acc[nt][r];
-}
 static bool wgrad_force_f32()  // experiments / tests: the fp32-MFMA form of the first convolution's weight gradient
 {
     static const int v = getenv("DGCNN_WGRAD1_F32") ? atoi(getenv("DGCNN_WGRAD1_F32")) : 0;
@@ -809,6 +824,26 @@ void launch_dgrad_and_dw1(const float *dR, const float *dD, const float *wcat, i
     }
     launch_finish_dw1(partial, nchunk, C, gw1, st, zero_words, nzero);
     launch_rowgemm(dR, EC, dD, EC, wcat, C, gx, C, nullptr, P, st, ldgx, gx_acc);
+}
+
+// the weight gradient and the input gradient of a 64-channel block's first convolution in ONE launch (the weight gradient's
+// workgroups ride behind the input gradient's), then the fold of the weight gradient's partials
+void launch_dgrad_wgrad64(const float *dR, const float *dD, const float *wcat, float *gx, int ldgx, int gx_acc, int P, const float *x,
+                          int ldx, float *partial, float *gw1, hipStream_t st, int *zero_words, int nzero)
+{
+    const int C = 64, main_blocks = ceil_div(ceil_div(P, 32), 4), nchunk = wgrad_chunks(P, C);
+    Dw1Rider rd{};
+    rd.main_blocks = main_blocks;
+    rd.wg_x = x, rd.wg_ldx = ldx > 0 ? ldx : C, rd.wg_partial = partial;
+    const RowLd ld{EC, ldgx > 0 ? ldgx : C, gx_acc};
+    hipLaunchKernelGGL((rowgemm_split_kernel<64, 2, false>), dim3(main_blocks + nchunk), dim3(256), 0, st, dR, EC, dD, EC, wcat, gx, C,
+                       nullptr, P, FwdSide{}, ld, rd);
+    launch_finish_dw1(partial, nchunk, C, gw1, st, zero_words, nzero);
+}
+bool dgrad_wgrad64_fused(int C)
+{
+    static const bool off = getenv("DGCNN_NO_DGRAD_WGRAD_FUSION") != nullptr;   // experiments
+    return C == 64 && !off && !rowgemm_force_f32() && !wgrad_force_f32();
 }
 
 void launch_finish_dw1(const float *partial, int nchunk, int C, float *gw1, hipStream_t st, int *zero_words, int nzero)
