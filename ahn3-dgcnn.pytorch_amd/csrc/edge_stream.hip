@@ -671,7 +671,13 @@ __global__ __launch_bounds__(256) void edge_point_bwd_kernel(const float *__rest
 #pragma unroll
                 for (int u = 0; u < 8; ++u) s += v[u];
             }
-            for (; ch < c1; ++ch) s += sr.partial[(size_t)ch * sr.n + e];
+            if (ch < c1) {  // the last, partial batch: loads in flight together, past-the-end chunks masked
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = sr.partial[(size_t)(ch + u < c1 ? ch + u : ch) * sr.n + e];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s += ch + u < c1 ? v[u] : 0.0f;
+            }
         }
         red[wave * 64 + lane] = s;
         __syncthreads();

@@ -286,9 +286,19 @@ __device__ __forceinline__ void finish_dw1_body(const float *__restrict__ partia
                 sr += vr[u];
             }
         }
-        for (; ch < c1; ++ch) {
-            sd += partial[(size_t)ch * n + ed];
-            sr += first ? partial[(size_t)ch * n + er] : 0.0f;
+        if (ch < c1) {  // the last, partial batch: loads in flight together, past-the-end chunks masked
+            float vr[8], vd[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int cu = ch + u < c1 ? ch + u : ch;
+                vd[u] = partial[(size_t)cu * n + ed];
+                vr[u] = first ? partial[(size_t)cu * n + er] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                sd += ch + u < c1 ? vd[u] : 0.0f;
+                sr += ch + u < c1 ? vr[u] : 0.0f;
+            }
         }
     }
     red[w][0][lane] = sr;
@@ -632,7 +642,13 @@ __global__ __launch_bounds__(1024) void sum_partials_kernel(const float *__restr
 #pragma unroll
             for (int u = 0; u < 8; ++u) s += v[u];
         }
-        for (; ch < c1; ++ch) s += partial[(size_t)ch * n + e];
+        if (ch < c1) {  // the last, partial batch: loads in flight together, past-the-end chunks masked
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(ch + u < c1 ? ch + u : ch) * n + e];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += ch + u < c1 ? v[u] : 0.0f;
+        }
     }
     red[w][lane] = s;
     __syncthreads();
