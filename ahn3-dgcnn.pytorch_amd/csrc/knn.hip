@@ -1292,6 +1292,16 @@ __global__ __launch_bounds__(64, 2) void knn_kernel(const float *__restrict__ xt
 // result never depends on the filter.
 constexpr int KNN_QCAP = 256;     // LDS staging ring of the filter kernel (entries: row << 27 | candidate)
 constexpr int KNN_MAXPARTS = 4;   // candidate parts of the filter (list segments per row block)
+// Balanced form of the filter's work split (wpb > 0 workgroups per batch element): the (row group, candidate chunk) units of a batch
+// element, row group major, are cut into wpb equal runs -- a workgroup takes one run, i.e. a candidate range of one row group
+// and, where the run crosses a group boundary, a second range at the start of the next group.  The uniform split (every row
+// group cut into `parts` equal parts: 896 workgroups at B = 8, N = 7000) fills the chip's 512 workgroup slots 1.75 times,
+// i.e. runs two rounds; 512 runs of 24 - 25 chunks fill them once.  The list segment of a range is its ordinal among the runs
+// that touch its row group: knn_bal_owner(first unit of the group) is the first of them.
+__host__ __device__ inline int knn_bal_owner(int unit, int wpb, int total)  // the run that holds `unit`: boundary(j) = floor(j total / wpb)
+{
+    return (int)(((long long)(unit + 1) * wpb + total - 1) / total) - 1;
+}
 // survivor list per (32-row block, candidate part) in HBM: 4096 entries = 128 per row, so that a row block whose
 // neighbours all lie in ONE candidate part (spatially ordered points: the neighbours of consecutive rows are close in
 // index) fits, with room for the filter's slack on low-dimensional data (points on a sheet: the fp16 error bound is of
@@ -1308,7 +1318,7 @@ __global__ __launch_bounds__(KNN_ST_THREADS, 2) void knn_filter16_kernel(const h
                                                            int parts, unsigned *__restrict__ lists,
                                                            int *__restrict__ lcount, int *__restrict__ rbflag,
                                                            const unsigned *__restrict__ exch, const float *__restrict__ xx_raw,
-                                                           int k, float *__restrict__ tau_out)
+                                                           int k, float *__restrict__ tau_out, int wpb)
 {
     // exch != NULL (the pre-pass ran over two candidate halves and k <= 32): the thresholds are formed HERE from the halves'
     // sorted class maxima (knn_tau_merge32), one lane per row, instead of by knn_bound_merge32_kernel in front of this launch;
@@ -1321,11 +1331,35 @@ __global__ __launch_bounds__(KNN_ST_THREADS, 2) void knn_filter16_kernel(const h
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, j32 = lane & 31;
     // workgroup = (batch element, candidate part, group of row blocks) as in knn_bound16s_kernel; every
     // (row block, part) owns 1 / parts of the row block's list.  rbflag is zero-filled by the launcher.
-    const int b = blockIdx.x % B, part = (blockIdx.x / B) % parts;
-    const int rb0 = (blockIdx.x / B / parts) * KNN_ST_ROWS + wave * RT;  // this wave's first row block
+    const int b = blockIdx.x % B;
     const int ntiles = Npad / 32, nchunks = ntiles / KNN_ST_TILES;
-    const int c0 = part * nchunks / parts, c1 = (part + 1) * nchunks / parts;
     const int listcap = KNN_LISTCAP;
+    // the workgroup's one or two items (row group, list segment, candidate chunks [c0, c1)): see knn_bal_owner
+    int nitems = 1, i_rg0, i_part0, i_c00, i_c10, i_rg1 = 0, i_part1 = 0, i_c01 = 0, i_c11 = 0;
+    if (wpb == 0) {
+        i_part0 = (blockIdx.x / B) % parts;
+        i_rg0 = blockIdx.x / B / parts;
+        i_c00 = i_part0 * nchunks / parts;
+        i_c10 = (i_part0 + 1) * nchunks / parts;
+    } else {
+        const int j = blockIdx.x / B, total = ((ntiles + KNN_ST_ROWS - 1) / KNN_ST_ROWS) * nchunks;
+        const int u0 = (int)((long long)j * total / wpb), u1 = (int)((long long)(j + 1) * total / wpb);
+        i_rg0 = u0 / nchunks;
+        i_c00 = u0 - i_rg0 * nchunks;
+        i_c10 = i_c00 + (u1 - u0) < nchunks ? i_c00 + (u1 - u0) : nchunks;
+        i_part0 = j - knn_bal_owner(i_rg0 * nchunks, wpb, total);
+        if (u0 + (i_c10 - i_c00) < u1) {  // the run goes on in the next row group (the launcher keeps runs no longer than a group)
+            nitems = 2;
+            i_rg1 = i_rg0 + 1;
+            i_c01 = 0;
+            i_c11 = u1 - (u0 + (i_c10 - i_c00));
+            i_part1 = j - knn_bal_owner(i_rg1 * nchunks, wpb, total);
+        }
+        if (u0 >= u1) nitems = 0;
+    }
+    for (int item = 0; item < nitems; ++item) {
+    const int part = item ? i_part1 : i_part0, c0 = item ? i_c01 : i_c00, c1 = item ? i_c11 : i_c10;
+    const int rb0 = (item ? i_rg1 : i_rg0) * KNN_ST_ROWS + wave * RT;  // this wave's first row block
 #ifdef KNN_STAMP
     const unsigned long long tsA = __builtin_amdgcn_s_memtime();
 #endif
@@ -1336,7 +1370,7 @@ __global__ __launch_bounds__(KNN_ST_THREADS, 2) void knn_filter16_kernel(const h
             rbflag[b * ntiles + rb0 + lane] = 1;
             lcount[KNN_MAXPARTS * (b * ntiles + rb0 + lane) + part] = 0;
         }
-        return;
+        continue;
     }
     const half8 *xbatch = xh + (size_t)b * ntiles * KS1 * 64;
     const float *yb = xxc + (size_t)b * Npad;
@@ -1551,6 +1585,7 @@ __global__ __launch_bounds__(KNN_ST_THREADS, 2) void knn_filter16_kernel(const h
             if (overflow[rt]) rbflag[wid] = 1;
         }
     }
+    }  // items
 }
 
 // The same filter for small C (CP = 4, 8: the raw coordinates of the first block), where fp16 is useless (the
@@ -1689,7 +1724,7 @@ __global__ __launch_bounds__(64, (CP <= 32 ? 3 : 2)) void knn_refine_kernel(cons
                                                         const int *__restrict__ lcount, int *__restrict__ rbflag,
                                                         int B, int N, int C, int Npad, int k, int parts,
                                                         int32_t *__restrict__ idx, const float *__restrict__ xt,
-                                                        const float *__restrict__ tau0)
+                                                        const float *__restrict__ tau0, int wpb = 0)
 {
     constexpr int XS = CP + 1;  // LDS row stride of the raw query rows (odd: conflict-free column reads)
     // key storage per row: 48 entries for k <= 32 (the filter leaves ~42 survivors per row; a fuller row is
@@ -1740,6 +1775,12 @@ __global__ __launch_bounds__(64, (CP <= 32 ? 3 : 2)) void knn_refine_kernel(cons
     const int listcap = KNN_LISTCAP;
     int ncum[KNN_MAXPARTS + 1];
     ncum[0] = 0;
+    // (balanced filter, wpb > 0: the row group's segments are those of the runs that touch it, see knn_bal_owner)
+    if (wpb > 0) {
+        const int nchunks_ = ntiles / KNN_ST_TILES, total = ((ntiles + KNN_ST_ROWS - 1) / KNN_ST_ROWS) * nchunks_;
+        const int s0 = (rb / KNN_ST_ROWS) * nchunks_;
+        parts = knn_bal_owner(s0 + nchunks_ - 1, wpb, total) - knn_bal_owner(s0, wpb, total) + 1;
+    }
 #pragma unroll
     for (int pp = 0; pp < KNN_MAXPARTS; ++pp) ncum[pp + 1] = ncum[pp] + (pp < parts ? lcount[KNN_MAXPARTS * wid + pp] : 0);
     const int n = ncum[KNN_MAXPARTS];
@@ -1980,22 +2021,40 @@ static KnnWs knn_ws(int B, int C, int N, void *base)
     return w;
 }
 
+// Workgroups per batch element of the balanced filter (0: the uniform split into `parts` candidate parts stays).  Balanced when
+// the uniform grid does not fill the chip's 512 workgroup slots (two per CU) a whole number of times AND 512 / B runs per batch
+// element are no longer than a row group (a run then has at most two items) and long enough that no row group is touched by
+// more than KNN_MAXPARTS of them (2 + floor((U - 2) / L) <= 4).
+static int knn_filter_balance(int B, int Npad, int parts)
+{
+    static const bool off = getenv("DGCNN_KNN_UNIFORM_FILTER") != nullptr;   // experiments
+    const int ntiles = Npad / 32, U = ntiles / KNN_ST_TILES, ngroups = ceil_div(ntiles, KNN_ST_ROWS), total = ngroups * U;
+    const int slots = 512;
+    if (off || (B * parts * ngroups) % slots == 0) return 0;
+    const int wpb = (slots + B / 2) / B;
+    if (wpb < 1) return 0;
+    const int lmin = total / wpb, lmax = ceil_div(total, wpb);
+    if (lmin < 1 || lmax > U || 3 * lmin <= U - 2) return 0;
+    return wpb;
+}
+
 template <int CP>
 static void knn_f16_launch(int cap, int parts, const KnnWs &w, const float *x, int ldx, int B, int N, int C, int Npad, int k,
                            int32_t *idx, hipStream_t st, bool merge_here)
 {
     const dim3 grid(B * (Npad / 32)), block(64);
+    const int wpb = cap == 64 ? knn_filter_balance(B, Npad, parts) : 0;
     prof_begin(PROF_KNN_FILTER, st);
-    hipLaunchKernelGGL((knn_filter16_kernel<CP>), dim3(B * parts * ceil_div(Npad / 32, KNN_ST_ROWS)), dim3(KNN_ST_THREADS), 0,
+    hipLaunchKernelGGL((knn_filter16_kernel<CP>), dim3(wpb ? B * wpb : B * parts * ceil_div(Npad / 32, KNN_ST_ROWS)), dim3(KNN_ST_THREADS), 0,
                        st, w.xh, w.xxc, w.tau0, w.eps, w.bmax, B, Npad, parts, w.lists, w.lcount, w.rbflag,
-                       merge_here ? w.exch : (const unsigned *)nullptr, w.xx, k, w.tau0);
+                       merge_here ? w.exch : (const unsigned *)nullptr, w.xx, k, w.tau0, wpb);
     prof_end(PROF_KNN_FILTER, st);
     prof_begin(PROF_KNN_REFINE, st);
     // (two waves per block for k <= 32 as well -- knn_refine_kernel<CP, 64, 2> -- measured: 125 us against 80 at B = 8,
     // N = 7000: at 21 KB per wave that variant is not short of resident waves, and half-inert batches double its work)
     if (cap == 64)
         hipLaunchKernelGGL((knn_refine_kernel<CP, 64>), grid, block, 0, st, x, ldx, w.xx, w.lists, w.lcount, w.rbflag, B, N, C,
-                           Npad, k, parts, idx, w.xt, w.tau0);
+                           Npad, k, parts, idx, w.xt, w.tau0, wpb);
     else  // (two waves per row block: knn_refine_kernel)
         hipLaunchKernelGGL((knn_refine_kernel<CP, 128>), dim3(2 * grid.x), block, 0, st, x, ldx, w.xx, w.lists, w.lcount, w.rbflag, B,
                            N, C, Npad, k, parts, idx, w.xt, w.tau0);
@@ -2126,15 +2185,16 @@ int dgcnn::knn_ld(const float *x, int ldx, int B, int N, int C, int k, int32_t *
         // two-piece fp16 filter + exact refine; the exact fp32 kernel below only runs the row blocks these kernels flagged
         rbflag = w.rbflag;
         prof_begin(PROF_KNN_FILTER, st);
-        hipLaunchKernelGGL((knn_filter16_kernel<16, true>), dim3(B * fparts * ceil_div(Npad / 32, KNN_ST_ROWS)), dim3(KNN_ST_THREADS),
+        const int wpb = cap == 64 ? knn_filter_balance(B, Npad, fparts) : 0;
+        hipLaunchKernelGGL((knn_filter16_kernel<16, true>), dim3(wpb ? B * wpb : B * fparts * ceil_div(Npad / 32, KNN_ST_ROWS)), dim3(KNN_ST_THREADS),
                            0, st, w.xh, w.xxc, w.tau0, w.eps, w.bmax, B, Npad, fparts, w.lists, w.lcount, w.rbflag,
-                           merge_here ? w.exch : (const unsigned *)nullptr, xx, k, w.tau0);
+                           merge_here ? w.exch : (const unsigned *)nullptr, xx, k, w.tau0, wpb);
         prof_end(PROF_KNN_FILTER, st);
         prof_begin(PROF_KNN_REFINE, st);
         const dim3 rgrid(B * (Npad / 32));
         if (cap == 64)
             hipLaunchKernelGGL((knn_refine_kernel<4, 64>), rgrid, dim3(64), 0, st, x, ldx, w.xx, w.lists, w.lcount, w.rbflag, B, N, C, Npad,
-                               k, fparts, idx, xt, w.tau0);
+                               k, fparts, idx, xt, w.tau0, wpb);
         else
             hipLaunchKernelGGL((knn_refine_kernel<4, 128>), dim3(2 * rgrid.x), dim3(64), 0, st, x, ldx, w.xx, w.lists, w.lcount, w.rbflag,
                                B, N, C, Npad, k, fparts, idx, xt, w.tau0);

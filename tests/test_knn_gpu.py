@@ -197,6 +197,29 @@ def test_knn_randomised_shapes_scales_and_ties(device):
         np.testing.assert_array_equal(_run(x, k, device), ke.knn_exact(x, k), err_msg="case %d: %s" % (it, what))
 
 
+@pytest.mark.parametrize("B,C,N,k,mode", [(6, 4, 7000, 30, "plain"), (9, 64, 7000, 20, "mixed"), (12, 16, 4096, 8, "dups"),
+                                          (24, 32, 2048, 32, "quant"), (8, 64, 7000, 30, "quant"), (7, 3, 8192, 16, "offset")])
+def test_knn_balanced_filter_split_is_exact(B, C, N, k, mode, device):
+    """Shapes at which the filter's workgroups take BALANCED runs of (row group, candidate chunk) units (knn.hip,
+    knn_filter_balance: the uniform split would not fill the chip's workgroup slots a whole number of times): a run may cross
+    a row-group boundary, a row group's list has three or four segments of unequal length.  Ties, duplicates (long lists), a
+    batch element outside the fp16 range (flagged: the exact pass inside the refine) -- indices bit-exact as everywhere."""
+    rng = np.random.default_rng(100 * B + C)
+    x = rng.standard_normal((B, C, N)).astype(np.float32)
+    if mode == "mixed":
+        x[1] *= 1e-3
+        x[2] = x[2] * 50.0 - 7.0
+        x[3] *= 3.0e4          # centred features beyond the fp16 range: the whole batch element goes to the exact pass
+    elif mode == "dups":
+        x[:, :, N // 2:] = x[:, :, : N - N // 2]
+    elif mode == "quant":
+        x = np.round(x * 1.5).astype(np.float32) * np.float32(0.5)
+    elif mode == "offset":
+        x = x * 10.0 + np.array([5.0e5, 4.0e6, 50.0], np.float32)[None, :C, None]
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    np.testing.assert_array_equal(_run(x, k, device), ke.knn_exact(x, k))
+
+
 def test_knn_k_out_of_range(device):
     from ahn3_dgcnn_pytorch_amd import ops
     x = torch.zeros((1, 10, 4), device=device)
