@@ -570,13 +570,47 @@ int launch_rev_build(const int32_t *idx, int B, int N, int k, int *cnt, int *ind
     return launch_rev_place(idx, B, N, k, cnt, rev, st);
 }
 
+// The list-space pass with riders that READ the index rows of every placement chunk (results dropped): the placement pass
+// behind this launch follows the latency of its index rows, and since the counting pass runs in the forward nothing has left
+// them in the L2 of the XCD that will place them (107 us per launch at B = 32 against 80 directly behind the counting pass).
+// A rider wave reads the rows of the placement workgroup with the same blockIdx % 8 -- the same XCD under the round-robin
+// dispatch; a different placement would only leave the rows in another L2, as before.
+__global__ __launch_bounds__(256) void rev_slots_warm_kernel(RevSlotsArgs a, int nslots, const int32_t *__restrict__ idx, int k, int rows_per,
+                                                             int nplace, int *__restrict__ sink)
+{
+    if ((int)blockIdx.x < nslots) {
+        rev_slots_pass<16>(a, (int)blockIdx.x);
+        return;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = (int)blockIdx.x - nslots, x = (int)blockIdx.x & 7;
+    // the placement blocks p with p % 8 == x, four per rider workgroup
+    const int p = x + 8 * (4 * (r >> 3) + wave);
+    if (p >= nplace) return;
+    const int B_ = nplace / a.chunks, b = p % B_, chunk = p / B_;
+    const int r0 = chunk * rows_per, r1 = r0 + rows_per < a.N ? r0 + rows_per : a.N;
+    const int32_t *ib = idx + (size_t)b * a.N * k;
+    int acc = 0;
+    for (int row = r0; row < r1; row += 8) {
+        int v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = ib[(size_t)(row + u < r1 ? row + u : r1 - 1) * k + (lane < k ? lane : 0)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc |= v[u];
+    }
+    if (acc == (int)0x80000000) sink[0] = acc;   // (never: indices are non-negative; keeps the loads alive)
+}
 int launch_rev_slots_place(const int32_t *idx, int B, int N, int k, const int *counts, int *slots, int *indeg, int *rowptr, int *segbase,
                            int *pcnt, int32_t *rev, int *alloc, int *extra, hipStream_t st)
 {
     DG_REQUIRE(N <= REV_MAX_N && k <= 64, "dgcnn: reverse lists from the forward's counts take N <= %d, k <= 64", REV_MAX_N);
     RevSlotsArgs sa = rev_slots_args(B, N, k, const_cast<int *>(counts), indeg, rowptr, segbase, pcnt, alloc, extra);
     sa.cnt_out = slots;
-    hipLaunchKernelGGL(rev_slots_kernel, dim3(ceil_div(B * N, 256)), dim3(256), 0, st, sa);
+    const int nslots = ceil_div(B * N, 256), chunks = rev_chunks(B, N, k), nplace = B * chunks;
+    // (eight consecutive riders cover the eight residues of blockIdx % 8 once, wherever the riders start: rider r takes the
+    // (r / 8)-th group of four placement blocks of its residue)
+    hipLaunchKernelGGL(rev_slots_warm_kernel, dim3(nslots + 8 * ceil_div(ceil_div(nplace, 8), 4)), dim3(256), 0, st, sa, nslots, idx, k,
+                       ceil_div(N, chunks), nplace, pcnt);
     return launch_rev_place(idx, B, N, k, slots, rev, st);
 }
 
