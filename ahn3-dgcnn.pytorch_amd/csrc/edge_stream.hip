@@ -672,7 +672,8 @@ static_assert(sizeof(HitRec) == 32, "HitRec is one 32-byte sector");
 // Per-point part of the stage-1 backward:  dD[i] = sum_j sc dv[i][j] + k A[i] - alpha (usum[i] - k TQ[i]).
 // DENSE: `dv` here is the per-point sum of dv1 over the k edges [P][64] (edge_mlp_bwd_kernel).
 // Sparse (single-stage block): dL/dy of (i, c) belongs to the ONE edge that won max-over-k, slot hitj[i][c] from the
-// forward.  The kernel writes G[i][c] = sc dv of that edge and the HitRec of every edge of the point; the records of a
+// forward.  The kernel writes the HitRec of every edge of the point (values sc . gdv; an edge with more hits than its record
+// holds sends the gather to gdv itself: `G` there IS gdv since round 4, the per-point copy sc . gdv is not written any more); the records of a
 // point are assembled in LDS: one 64-bit atomic-or per channel lane builds the masks, then lane j owns edge j.
 template <bool DENSE>
 __global__ __launch_bounds__(256) void edge_point_bwd_kernel(const float *__restrict__ TQ, int k, int P,
@@ -733,7 +734,6 @@ __global__ __launch_bounds__(256) void edge_point_bwd_kernel(const float *__rest
             dsum = sc * dv[o];
         } else {
             dsum = sc * gdv[o];  // gdv = dL/dy . LReLU'(y), left by bwd_point_kernel
-            G[o] = dsum;
             const int hj = hitj[o];
             sm[lane] = 0;
             sm[64 + lane] = 0;
@@ -778,7 +778,8 @@ __global__ __launch_bounds__(256) void edge_point_bwd_kernel(const float *__rest
 template <bool DENSE>
 __device__ __forceinline__ void rgather_segment(const __amdgpu_buffer_rsrc_t TQb, int k, const float *__restrict__ dv,
                                                 const HitRec *__restrict__ hits, const float *__restrict__ G, int cnt,
-                                                int ev, u64 hm, float4 rec, float *sacc, int lane, float &sq, float &sd)
+                                                int ev, u64 hm, float4 rec, float *sacc, int lane, float &sq, float &sd,
+                                                const float *__restrict__ sc_tab)
 {
     float s0 = 0.0f, s1 = 0.0f, d0 = 0.0f, d1 = 0.0f;
     const int src = (int)((unsigned)ev / (unsigned)k);
@@ -850,7 +851,7 @@ __device__ __forceinline__ void rgather_segment(const __amdgpu_buffer_rsrc_t TQb
         while (__ballot(hm != 0)) {  // rare: more hits on one edge than its record holds
             if (hm) {
                 const int c = __builtin_ctzll(hm);
-                atomicAdd(&sacc[c], G[(size_t)src * EC + c]);
+                atomicAdd(&sacc[c], sc_tab[c] * G[(size_t)src * EC + c]);   // (= the value a record would hold: sc . gdv, the same product)
                 hm &= hm - 1ull;
             }
         }
@@ -931,8 +932,8 @@ __global__ __launch_bounds__(256) void edge_rgather_kernel(const float *__restri
 {
     // Workgroups 0 .. main_blocks - 1 walk the points (segment 0 of every list), the others the extra segments of the
     // long lists, concurrently (one launch; dispatching the extra workgroups first was measured slower).
-    // DENSE: dv [E][64] rows by edge id (sc applied here).  Sparse: hits[e] by edge id and G [P][64] = sc dL/dv of the
-    // centre's surviving edge per channel, both written by edge_point_bwd_kernel.
+    // DENSE: dv [E][64] rows by edge id (sc applied here).  Sparse: hits[e] by edge id (edge_point_bwd_kernel) and G [P][64] =
+    // gdv, dL/dv of the centre's surviving edge per channel as bwd_point left it (times sc where a record overflows).
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float mean = stats[ST_MEAN + lane], rstd = stats[ST_RSTD + lane], sc = stats[ST_SC + lane];
     const float c1 = cc[lane], c2 = cc[64 + lane];
@@ -973,7 +974,7 @@ __global__ __launch_bounds__(256) void edge_rgather_kernel(const float *__restri
             }
 #endif
             float sq, sd;
-            rgather_segment<DENSE>(TQb, k, dv, hits, G, cnt, ev, hm, rec, sacc, lane, sq, sd);
+            rgather_segment<DENSE>(TQb, k, dv, hits, G, cnt, ev, hm, rec, sacc, lane, sq, sd, stats + ST_SC);
             rgather_publish(cx, pt, seg, deg, sq, sd, lane);
         }
         return;
@@ -1024,7 +1025,7 @@ __global__ __launch_bounds__(256) void edge_rgather_kernel(const float *__restri
         }
 #endif
         float sq, sd;
-        rgather_segment<DENSE>(TQb, k, dv, hits, G, cnt, ev, hm, rec, sacc, lane, sq, sd);
+        rgather_segment<DENSE>(TQb, k, dv, hits, G, cnt, ev, hm, rec, sacc, lane, sq, sd, stats + ST_SC);
         if (deg <= REV_SEG) {
             const float fdeg = (float)deg;
             dR[(size_t)pt * EC + lane] = fdeg * cx.a0 - cx.alpha * (sq + fdeg * TP[(size_t)pt * EC + lane]) + cx.dscale * sd;

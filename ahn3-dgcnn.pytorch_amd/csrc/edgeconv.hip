@@ -150,7 +150,7 @@ static BwdWs bwd_ws(const dgcnn_edgeconv_desc *d, void *p)
     w.part0 = c.take<float>(P * 128);
     w.partx = c.take<float>((P * d->k / REV_SEG + 1) * 128);
     w.hits = d->n_stage == 1 ? (void *)c.take<u64>(P * d->k * 4) : nullptr;  // 32 bytes per edge
-    w.G = d->n_stage == 1 ? c.take<float>(P * EC) : nullptr;
+    w.G = nullptr;   // (the per-point copy sc . gdv of the sparse backward: the gather reads gdv itself since round 4)
     if (d->n_stage == 2) {
         w.dv1 = c.take<float>(P * d->k * EC);
         w.dvsum = c.take<float>(P * EC);
@@ -340,7 +340,7 @@ int dgcnn::edgeconv_bwd_ld(const dgcnn_edgeconv_desc *d, const EdgeLd &ld, const
                          ld.gy, ld.gy2, w.gdv, place);
         if (place_later && launch_rev_place(idx, d->B, N, k, w.cnt, w.rev, st)) return 1;
         if (launch_edge_bwd(s.TP, s.TQ, d->B, N, k, s.stats1, w.cc1, d->slope, w.gdv, s.hitj, s.usum, nullptr, nullptr,
-                            w.rowptr, w.indeg, w.segbase, w.pcnt, w.rev, w.zero + Z_ALLOC, w.extra, w.hits, w.G, w.part0,
+                            w.rowptr, w.indeg, w.segbase, w.pcnt, w.rev, w.zero + Z_ALLOC, w.extra, w.hits, w.gdv, w.part0,
                             w.partx, w.dR, w.dD, st))
             return 1;
     } else {
