@@ -183,7 +183,7 @@ struct SumRider {
     int main_blocks;
 };
 // stage-1 backward as a gather over the reverse lists (see edge_stream.hip): dR and dD are overwritten.
-// dv == NULL: sparse dv from (gdv = dL/dy . LReLU'(y) as launch_bwd_point leaves it, hitj) -- hits [E] x 32 bytes and G [P][64] are scratch; else dense dv [E][64] with
+// dv == NULL: sparse dv from (gdv = dL/dy . LReLU'(y) as launch_bwd_point leaves it, hitj) -- hits [E] x 32 bytes is scratch, G = gdv again (read where a hit record overflows; a per-point copy sc . gdv until round 4); else dense dv [E][64] with
 // dvsum [P][64] = its sums over k.  part0 [P][128], partx [E / REV_SEG + 1][128] floats: segment partials of long lists.
 // cc = 0 (eval mode) drops the BatchNorm mean terms.
 int launch_edge_bwd(const float *TP, const float *TQ, int B, int N, int k, const float *stats, const float *cc, float slope,
