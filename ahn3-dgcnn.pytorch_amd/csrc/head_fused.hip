@@ -118,6 +118,7 @@ struct HGemmArgs {
     double *pdv;         // [nrb][2][3][N]: per batch-element slot of the tile: sum dv, sum dv uhat, sum uhat
     unsigned *oa, *ob;   // [nrb + 1]: bits of max |dv|, max |uhat| of the row tile (zero at launch); [nrb] = over all tiles
     int ncb, nrb;
+    int csplit;          // hrow_kernel: workgroups per row block, each taking a contiguous share of the column blocks (0 / 1: one)
 };
 
 struct XRegs {
@@ -568,11 +569,16 @@ __global__ __launch_bounds__(256, 2) void hrow_kernel(const HGemmArgs a)
     __shared__ __attribute__((aligned(16))) double csum[4][2][GN];           // per wave: sum, sum of squares
     __shared__ __attribute__((aligned(16))) unsigned long long cx[4][2][GN];  // E_COLRED: keys per batch-element slot; E_STATS: min, max (floats)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, i32 = lane & 31;
-    const int rb = blockIdx.x, row0 = rb * GM;
+    // (csplit workgroups per row block: each prepares the row block's operand itself and walks its share of the column blocks --
+    // between the row-stationary form, one workgroup per row block, which leaves CUs empty below ~320 row blocks, and the tiled
+    // product, which prepares the operand once per column block)
+    const int S = a.csplit > 1 ? a.csplit : 1;
+    const int rb = (int)blockIdx.x / S, cs = (int)blockIdx.x - rb * S, row0 = rb * GM;
+    const int t0 = cs * a.ncb / S, t1 = (cs + 1) * a.ncb / S;
     const int P = a.P, N = a.N;
     const float sx = pow2_scale(__uint_as_float(*a.xmax), H_TOP);
-    if (EMODE == E_STATS && rb == 0 && threadIdx.x == 0 && a.zero) *a.zero = 0u;
-    const int total = a.ncb * RCH;  // W chunks of the walk
+    if (EMODE == E_STATS && blockIdx.x == 0 && threadIdx.x == 0 && a.zero) *a.zero = 0u;
+    const int total = t1 * RCH;  // end of this workgroup's walk over the W chunks (flat index f = t RCH + kc)
 
     half8 Ah[RCH][2], Al[RCH][2];
     WRegs rw;
@@ -580,7 +586,7 @@ __global__ __launch_bounds__(256, 2) void hrow_kernel(const HGemmArgs a)
         XRegs rx[RCH];
 #pragma unroll
         for (int c = 0; c < RCH; ++c) load_x(a.X, a.ldx, row0, P, c * GK, rx[c]);
-        load_w_flat(a, 0, rw);
+        load_w_flat(a, t0 * RCH, rw);
 #pragma unroll
         for (int c = 0; c < RCH; ++c) {
             // (stage c & 1 was last read two chunks ago, before the barrier of the chunk between)
@@ -594,14 +600,14 @@ __global__ __launch_bounds__(256, 2) void hrow_kernel(const HGemmArgs a)
         }
     }
     store_w(rw, ring[0][0], ring[0][1]);  // (stage 0 held x chunk 4: read before the barrier of chunk 5)
-    load_w_flat(a, 1, rw);
+    load_w_flat(a, t0 * RCH + 1, rw);
     __syncthreads();
 
     const float isx = 1.0f / sx;
     const int wrow0 = row0 + wave * 32;
     const int b0 = row0 / a.rows_per_batch, rsplit = (b0 + 1) * a.rows_per_batch;
     const bool two = rsplit < P && row0 + GM > rsplit;  // the tile reaches into a second batch element
-    for (int t = 0; t < a.ncb; ++t) {
+    for (int t = t0; t < t1; ++t) {
         f32x16 acc[4];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
@@ -738,16 +744,23 @@ __global__ __launch_bounds__(256, 2) void hrow_kernel(const HGemmArgs a)
         }
     }
 }
-static bool row_form(const HGemmArgs &a)
+// 0: the tiled product; otherwise the row-stationary form with that many workgroups per row block (HGemmArgs::csplit)
+static int row_form(const HGemmArgs &a)
 {
     // DGCNN_HF_ROW: 0 = never, 2 = whenever the shape allows (tests of the small, ragged shapes), otherwise by size
     static const int mode = getenv("DGCNN_HF_ROW") ? atoi(getenv("DGCNN_HF_ROW")) : 1;
+    static const int split_lo = getenv("DGCNN_HF_ROW_SPLIT") ? atoi(getenv("DGCNN_HF_ROW_SPLIT")) : 160;  // experiments: 0 = no split form
     const bool off = mode == 0;
-    if (mode == 2) return a.K == RK && a.N % GN == 0;
+    if (mode == 2) return a.K == RK && a.N % GN == 0 ? 1 : 0;
+    // (two workgroups per row block between 160 and 320 row blocks -- B = 3 .. 5 at N = 7000 --, when there are at least two
+    // column blocks to share)
+    if (!off && split_lo > 0 && a.K == RK && a.N % GN == 0 && a.nrb >= split_lo && a.nrb < 320 && a.ncb >= 2) return 2;
+    // (four between 80 and 160 -- B = 2 --: measured below)
+    if (!off && split_lo > 0 && a.K == RK && a.N % GN == 0 && a.nrb >= split_lo / 2 && a.nrb < split_lo && a.ncb >= 4) return 4;
     // (below about one and a half row blocks per CU the walk leaves CUs with one workgroup or none, and the product with a
     // workgroup per (row block, column block) is the faster one again: training step at B = 4, 219 row blocks: 2.134 ms
     // against 2.146; at B = 8, 438: 3.282 against 3.254)
-    return !off && a.K == RK && a.N % GN == 0 && a.nrb >= 320;
+    return !off && a.K == RK && a.N % GN == 0 && a.nrb >= 320 ? 1 : 0;
 }
 
 // ---- weight gradient dW[M][Nn] = sum_p aeff[p][m] beff[p][n] with prologues on both operands ---------------------------
@@ -1930,7 +1943,7 @@ extern "C" int dgcnn_head_tail_fwd(const dgcnn_head_tail_desc *d, const float *c
         a.psum = d->training ? w.psum7 : nullptr, a.pext = w.pext7, a.zero = s.zmax;
         a.ncb = ceil_div(C7, GN), a.nrb = nrb;
         prof_begin(PROF_HEAD_CONV7, st);
-        if (row_form(a)) hipLaunchKernelGGL((hrow_kernel<E_STATS>), dim3(nrb), dim3(256), 0, st, a);
+        if ((a.csplit = row_form(a)) > 0) hipLaunchKernelGGL((hrow_kernel<E_STATS>), dim3(nrb * a.csplit), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((hgemm_kernel<X_RAW, E_STATS, 3>), dim3((unsigned)align_up((size_t)a.ncb * nrb, 8)), dim3(256), 0, st, a);
         prof_end(PROF_HEAD_CONV7, st);
         launch_stats_finalize(w.psum7, w.pext7, nrb, P, C7, d->training, d->bn7, d->eps7, d->momentum7, d->slope, s.stats7, s.zmax,
@@ -2237,7 +2250,7 @@ extern "C" int dgcnn_embed_fwd(const float *cat, int ldc, const float *w, int ld
         a.keys = ws.keys, a.gamma = bn->weight;
         a.ncb = ceil_div(C, GN), a.nrb = nrb;
         prof_begin(PROF_HEAD_CONV6, st);
-        if (row_form(a)) hipLaunchKernelGGL((hrow_kernel<E_COLRED>), dim3(nrb), dim3(256), 0, st, a);
+        if ((a.csplit = row_form(a)) > 0) hipLaunchKernelGGL((hrow_kernel<E_COLRED>), dim3(nrb * a.csplit), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((hgemm_kernel<X_RAW, E_COLRED, 3>), dim3((unsigned)align_up((size_t)a.ncb * nrb, 8)), dim3(256), 0, st, a);
         prof_end(PROF_HEAD_CONV6, st);
     }
